@@ -1,0 +1,88 @@
+"""ctypes binding of libbsmrocm.so -- the C ABI declared in include/bsm_rocm.h.
+
+There is NO CPU fallback: if the HIP library is missing or a call fails, an exception is
+raised.  (The CPU oracle under oracle/ is test infrastructure and is never imported here.)
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libbsmrocm.so")
+
+BSM_F32, BSM_F64, BSM_C64, BSM_C128 = 0, 1, 2, 3
+BSM_OP_N, BSM_OP_T, BSM_OP_C = 0, 1, 2
+BSM_MEM_HOST, BSM_MEM_DEVICE = 0, 1
+BSM_SCHED_SERIAL, BSM_SCHED_DYNAMIC = 0, 1
+BSM_ACC_AUTO, BSM_ACC_ATOMIC, BSM_ACC_COLORED = 0, 1, 2
+BSM_DEVICE_CURRENT, BSM_DEVICE_NONE = -1, -2
+(BSM_BK_VBCRS_PERM, BSM_BK_VBCRS_ROWPTR, BSM_BK_VBCRS_COLINDICES, BSM_BK_VBCRS_ROWINDICES,
+ BSM_BK_COLORS, BSM_BK_TRANSPOSECOLORS, BSM_BK_DIAGONALCOLORS) = range(7)
+
+
+class BsmOptions(C.Structure):
+    _fields_ = [("struct_size", C.c_int32), ("device", C.c_int32), ("scheduler", C.c_int32),
+                ("accumulate", C.c_int32), ("validate", C.c_int32), ("reserved0", C.c_int32),
+                ("own_lo", C.c_int64), ("own_hi", C.c_int64), ("reserved", C.c_int64 * 4)]
+
+
+class BsmStats(C.Structure):
+    _fields_ = [("nnz", C.c_int64), ("stored_entries", C.c_int64), ("alg_bytes", C.c_int64),
+                ("device_bytes", C.c_int64), ("npanels", C.c_int64), ("ntasks", C.c_int64),
+                ("nworkgroups", C.c_int64), ("exclusive", C.c_int64), ("reserved", C.c_int64 * 8)]
+
+
+class BsmError(RuntimeError):
+    pass
+
+
+_PP = C.POINTER(C.c_void_p)
+_I64P = C.POINTER(C.c_int64)
+_lib = None
+
+# every symbol include/bsm_rocm.h declares
+EXPORTS = ["bsm_options_default", "bsm_vbcrs_create", "bsm_blocksparse_create",
+           "bsm_symmetric_create", "bsm_mul", "bsm_get_bookkeeping", "bsm_get_image", "bsm_stats",
+           "bsm_destroy",
+           "bsm_last_error", "bsm_version"]
+
+
+def lib():
+    """Loads libbsmrocm.so once; raises loudly when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: the HIP extension has not been built. Run "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (hipcc --offload-arch=gfx950). "
+            "There is no CPU fallback for the product path.")
+    L = C.CDLL(LIB_PATH)
+    L.bsm_options_default.argtypes = [C.POINTER(BsmOptions)]
+    L.bsm_options_default.restype = None
+    L.bsm_vbcrs_create.argtypes = [C.c_int, C.c_int64, C.c_int64, C.c_int64, _PP, _I64P, _I64P,
+                                   _I64P, _I64P, _I64P, C.POINTER(BsmOptions),
+                                   C.POINTER(C.c_void_p)]
+    L.bsm_blocksparse_create.argtypes = [C.c_int, C.c_int64, C.c_int64, C.c_int64, _PP, _I64P,
+                                         _I64P, _I64P, _PP, _PP, C.POINTER(BsmOptions),
+                                         C.POINTER(C.c_void_p)]
+    L.bsm_symmetric_create.argtypes = [C.c_int, C.c_int64, C.c_int64, C.c_int64, _PP, _I64P,
+                                       _I64P, _PP, C.c_int64, _PP, _I64P, _I64P, _I64P, _PP,
+                                       _PP, C.POINTER(BsmOptions), C.POINTER(C.c_void_p)]
+    L.bsm_mul.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                          C.c_int, C.c_int, C.c_void_p]
+    L.bsm_get_bookkeeping.argtypes = [C.c_void_p, C.c_int, _I64P, _I64P]
+    L.bsm_get_image.argtypes = [C.c_void_p, C.c_int, C.c_void_p, _I64P]
+    L.bsm_stats.argtypes = [C.c_void_p, C.POINTER(BsmStats)]
+    L.bsm_destroy.argtypes = [C.c_void_p]
+    L.bsm_last_error.restype = C.c_char_p
+    L.bsm_version.restype = C.c_char_p
+    for name in ("bsm_vbcrs_create", "bsm_blocksparse_create", "bsm_symmetric_create", "bsm_mul",
+                 "bsm_get_bookkeeping", "bsm_get_image", "bsm_stats", "bsm_destroy"):
+        getattr(L, name).restype = C.c_int
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        raise BsmError(f"libbsmrocm error {rc}: {lib().bsm_last_error().decode()}")

@@ -1,0 +1,555 @@
+// bsm_analysis.cpp -- host analysis: reference bookkeeping + GPU schedule.  See bsm_analysis.h.
+#include "bsm_analysis.h"
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <numeric>
+#include <set>
+#include <thread>
+#include <tuple>
+#include <unordered_map>
+
+namespace bsm {
+
+Tunables Tunables::from_env() {
+    Tunables t;
+    auto geti = [](const char *name, int64_t dflt) -> int64_t {
+        const char *s = std::getenv(name);
+        if (!s || !*s) return dflt;
+        return std::strtoll(s, nullptr, 10);
+    };
+    t.split2_bytes = geti("BSM_SPLIT2_BYTES", t.split2_bytes);
+    t.split4_bytes = geti("BSM_SPLIT4_BYTES", t.split4_bytes);
+    t.wgitem_max_bytes = geti("BSM_WGITEM_MAX_BYTES", t.wgitem_max_bytes);
+    t.pack_threads = (int)geti("BSM_PACK_THREADS", t.pack_threads);
+    if (t.pack_threads < 1) t.pack_threads = 1;
+    return t;
+}
+
+// ---------------------------------------------------------------------------------------
+// DSATUR colouring (specification in bsm_analysis.h / oracle/bsm_oracle.c).
+// Heap-free formulation on an ordered set keyed by (-saturation, -degree, id).
+// ---------------------------------------------------------------------------------------
+std::vector<std::vector<int64_t>> color_dsatur(const std::vector<const int64_t *> &lists,
+                                               const std::vector<int64_t> &lens) {
+    const int64_t nb = (int64_t)lists.size();
+    std::vector<std::vector<int64_t>> classes;
+    if (nb == 0) return classes;
+    int64_t maxindex = 0;
+    for (int64_t b = 0; b < nb; b++)
+        for (int64_t k = 0; k < lens[b]; k++) maxindex = std::max(maxindex, lists[b][k]);
+    // incidence index -> blocks
+    std::vector<int64_t> ptr(maxindex + 2, 0);
+    for (int64_t b = 0; b < nb; b++)
+        for (int64_t k = 0; k < lens[b]; k++) ptr[lists[b][k] + 1]++;
+    for (int64_t i = 0; i <= maxindex; i++) ptr[i + 1] += ptr[i];
+    std::vector<int64_t> inc(ptr[maxindex + 1]);
+    {
+        std::vector<int64_t> fill(ptr.begin(), ptr.end() - 1);
+        for (int64_t b = 0; b < nb; b++)
+            for (int64_t k = 0; k < lens[b]; k++) inc[fill[lists[b][k]]++] = b;
+    }
+    // adjacency (distinct neighbours)
+    std::vector<std::vector<int32_t>> adj(nb);
+    {
+        std::vector<int64_t> stamp(nb, -1);
+        for (int64_t v = 0; v < nb; v++) {
+            stamp[v] = v;
+            for (int64_t k = 0; k < lens[v]; k++) {
+                int64_t i = lists[v][k];
+                for (int64_t p = ptr[i]; p < ptr[i + 1]; p++) {
+                    int64_t w = inc[p];
+                    if (stamp[w] != v) {
+                        stamp[w] = v;
+                        adj[v].push_back((int32_t)w);
+                    }
+                }
+            }
+        }
+    }
+    std::vector<int32_t> color(nb, -1), sat(nb, 0);
+    std::vector<std::vector<int32_t>> seen(nb);  // sorted colours among neighbours
+    using Key = std::tuple<int32_t, int64_t, int64_t>;  // (-sat, -deg, id)
+    std::set<Key> queue;
+    for (int64_t v = 0; v < nb; v++) queue.insert(Key(0, -(int64_t)adj[v].size(), v));
+    int32_t ncolors = 0;
+    while (!queue.empty()) {
+        auto it = queue.begin();
+        int64_t v = std::get<2>(*it);
+        queue.erase(it);
+        int32_t c = 0;
+        for (int32_t s : seen[v]) {  // sorted: first gap
+            if (s == c)
+                c++;
+            else if (s > c)
+                break;
+        }
+        color[v] = c;
+        ncolors = std::max(ncolors, c + 1);
+        for (int32_t w : adj[v]) {
+            if (color[w] >= 0) continue;
+            auto pos = std::lower_bound(seen[w].begin(), seen[w].end(), c);
+            if (pos != seen[w].end() && *pos == c) continue;
+            queue.erase(Key(-sat[w], -(int64_t)adj[w].size(), w));
+            seen[w].insert(pos, c);
+            sat[w]++;
+            queue.insert(Key(-sat[w], -(int64_t)adj[w].size(), w));
+        }
+    }
+    classes.assign(ncolors, {});
+    for (int64_t v = 0; v < nb; v++) classes[color[v]].push_back(v + 1);
+    return classes;
+}
+
+// ---------------------------------------------------------------------------------------
+namespace {
+
+struct Chunk {
+    int32_t blk;      // input block
+    int32_t ra;       // first row of the block in this chunk
+    int32_t mc;       // rows (<= 64)
+    int64_t group;    // row group id
+    uint64_t val_off; // 16-byte units
+    int32_t nstrips;
+};
+
+struct Group {
+    int32_t mc = 0;
+    int32_t rbase = -1;    // 0-based first row when contiguous
+    int32_t row_off = -1;  // rows pool offset when indexed
+    std::vector<int32_t> chunks;
+    int64_t strips = 0;
+};
+
+struct Item {
+    int64_t group;
+    int64_t s_begin, s_end;  // over the group's concatenated strips
+    int64_t bytes;
+    int nw;
+};
+
+template <typename U>
+void pack_chunk(const U *src, int64_t ld, int ra, int mc, int64_t n, int E, U *dst) {
+    // dst[(s*mc + i)*E + e] = src[(ra+i) + (s*E+e)*ld]
+    for (int64_t w = 0; w < n; w++) {
+        const int64_t s = w / E;
+        const int e = (int)(w % E);
+        const U *col = src + ra + w * ld;
+        U *d = dst + (s * mc) * E + e;
+        for (int i = 0; i < mc; i++) d[(int64_t)i * E] = col[i];
+    }
+}
+
+struct U16 {
+    uint64_t a, b;
+};
+
+uint64_t hash_list(const int64_t *p, int64_t n) {
+    uint64_t h = 0xcbf29ce484222325ull ^ (uint64_t)n;
+    for (int64_t i = 0; i < n; i++) {
+        h ^= (uint64_t)p[i];
+        h *= 0x100000001b3ull;
+        h ^= h >> 29;
+    }
+    return h;
+}
+
+}  // namespace
+
+std::string Analysis::build(int mtype_, int dtype_, int64_t nrows_, int64_t ncols_,
+                            const std::vector<BlockIn> &blocks, const AnalysisOptions &opt_) {
+    mtype = mtype_;
+    dtype = dtype_;
+    nrows = nrows_;
+    ncols = ncols_;
+    opt = opt_;
+    tun = Tunables::from_env();
+    static const int kEs[4] = {4, 8, 8, 16};
+    if (dtype < 0 || dtype > 3) return "unknown dtype";
+    es = kEs[dtype];
+    E = 16 / es;
+    if (nrows < 0 || ncols < 0) return "negative matrix size";
+    if (nrows > INT32_MAX - 64 || ncols > INT32_MAX - 64) return "matrix dimension exceeds int32 range";
+    const int64_t nb = (int64_t)blocks.size();
+    const bool sym = (mtype == MT_SYMMETRIC);
+    // rows index y for op N and x for op T; for a symmetric matrix every list indexes both
+    const int64_t rlim = sym ? std::min(nrows, ncols) : nrows;
+    const int64_t clim = sym ? std::min(nrows, ncols) : ncols;
+
+    // ---- validation ------------------------------------------------------------------
+    nnz = 0;
+    stored_entries = 0;
+    int64_t idx_meta = 0;
+    for (int64_t b = 0; b < nb; b++) {
+        const BlockIn &B = blocks[b];
+        if (B.m < 0 || B.n < 0) return "block " + std::to_string(b + 1) + ": negative size";
+        if (B.m > 0 && B.n > 0 && !B.data) return "block " + std::to_string(b + 1) + ": null data";
+        if (B.ld < std::max<int64_t>(B.m, 1)) return "block " + std::to_string(b + 1) + ": ld < m";
+        if (B.m > 0 && !B.ridx && (B.r0 < 1 || B.r0 + B.m - 1 > rlim))
+            return "block " + std::to_string(b + 1) + ": row range outside matrix";
+        if (B.n > 0 && !B.cidx && (B.c0 < 1 || B.c0 + B.n - 1 > clim))
+            return "block " + std::to_string(b + 1) + ": column range outside matrix";
+        if (opt.validate) {
+            if (B.ridx)
+                for (int64_t i = 0; i < B.m; i++)
+                    if (B.ridx[i] < 1 || B.ridx[i] > rlim)
+                        return "block " + std::to_string(b + 1) + ": row index out of range";
+            if (B.cidx)
+                for (int64_t i = 0; i < B.n; i++)
+                    if (B.cidx[i] < 1 || B.cidx[i] > clim)
+                        return "block " + std::to_string(b + 1) + ": column index out of range";
+        }
+        stored_entries += B.m * B.n;
+        nnz += (B.kind == KIND_OFF ? 2 : 1) * B.m * B.n;
+        idx_meta += (B.kind == KIND_DIAG) ? B.m : (B.m + B.n);
+    }
+    // algorithmic bytes of one mul with beta = 0
+    {
+        int64_t meta;
+        if (mtype == MT_VBCRS)
+            meta = 8 * ((int64_t)rowptr.size() + (int64_t)rowindices.size() + 4 * nb);
+        else
+            meta = 8 * idx_meta;
+        alg_bytes = stored_entries * es + meta + ncols * es + nrows * es;
+    }
+
+    // ---- chunks (<= 64 rows) and row groups ------------------------------------------
+    std::vector<Chunk> chunks;
+    std::vector<Group> groups;
+    std::unordered_map<uint64_t, std::vector<int64_t>> gmap;  // hash -> candidate groups
+    std::vector<const int64_t *> glist;  // representative index list of indexed groups
+    rows.clear();
+    cols.clear();
+    std::vector<int32_t> blk_xbase(nb, -1), blk_coloff(nb, -1);
+    uint64_t val_units = 0;
+    for (int64_t b = 0; b < nb; b++) {
+        const BlockIn &B = blocks[b];
+        if (B.m == 0 || B.n == 0) continue;
+        // column identity of the block
+        bool ccontig = true;
+        if (B.cidx)
+            for (int64_t k = 1; k < B.n; k++)
+                if (B.cidx[k] != B.cidx[0] + k) {
+                    ccontig = false;
+                    break;
+                }
+        if (ccontig) {
+            blk_xbase[b] = (int32_t)((B.cidx ? B.cidx[0] : B.c0) - 1);
+        } else {
+            if ((int64_t)cols.size() + B.n + 8 > INT32_MAX) return "column index pool exceeds int32";
+            blk_coloff[b] = (int32_t)cols.size();
+            for (int64_t k = 0; k < B.n; k++) cols.push_back((int32_t)(B.cidx[k] - 1));
+        }
+        const int64_t nstrips = (B.n + E - 1) / E;
+        if (nstrips > INT32_MAX / 2) return "block too wide";
+        for (int64_t ra = 0; ra < B.m; ra += kMaxRowsPerChunk) {
+            const int mc = (int)std::min<int64_t>(kMaxRowsPerChunk, B.m - ra);
+            bool rcontig = true;
+            if (B.ridx)
+                for (int i = 1; i < mc; i++)
+                    if (B.ridx[ra + i] != B.ridx[ra] + i) {
+                        rcontig = false;
+                        break;
+                    }
+            const int64_t rbase = rcontig ? (B.ridx ? B.ridx[ra] : B.r0 + ra) - 1 : -1;
+            uint64_t h;
+            if (rcontig)
+                h = ((uint64_t)rbase * 0x9E3779B97F4A7C15ull) ^ ((uint64_t)mc << 56) ^ 0x51ull;
+            else
+                h = hash_list(B.ridx + ra, mc);
+            int64_t gid = -1;
+            auto &cand = gmap[h];
+            for (int64_t g : cand) {
+                const Group &G = groups[g];
+                if (G.mc != mc) continue;
+                if (rcontig) {
+                    if (G.rbase == rbase) gid = g;
+                } else if (G.rbase < 0 &&
+                           std::memcmp(glist[g], B.ridx + ra, sizeof(int64_t) * mc) == 0) {
+                    gid = g;
+                }
+                if (gid >= 0) break;
+            }
+            if (gid < 0) {
+                gid = (int64_t)groups.size();
+                Group G;
+                G.mc = mc;
+                G.rbase = (int32_t)rbase;
+                if (!rcontig) {
+                    if ((int64_t)rows.size() + mc + 8 > INT32_MAX) return "row index pool exceeds int32";
+                    G.row_off = (int32_t)rows.size();
+                    for (int i = 0; i < mc; i++) rows.push_back((int32_t)(B.ridx[ra + i] - 1));
+                }
+                groups.push_back(G);
+                glist.push_back(rcontig ? nullptr : B.ridx + ra);
+                cand.push_back(gid);
+            }
+            Chunk c;
+            c.blk = (int32_t)b;
+            c.ra = (int32_t)ra;
+            c.mc = mc;
+            c.group = gid;
+            c.val_off = val_units;
+            c.nstrips = (int32_t)nstrips;
+            val_units += (uint64_t)mc * (uint64_t)nstrips;
+            groups[gid].chunks.push_back((int32_t)chunks.size());
+            groups[gid].strips += nstrips;
+            chunks.push_back(c);
+        }
+    }
+    ngroups = (int64_t)groups.size();
+
+    // ---- forward exclusivity + coverage ------------------------------------------------
+    const int64_t own_lo = (opt.own_lo > 0) ? opt.own_lo - 1 : 0;
+    const int64_t own_hi = (opt.own_hi > 0) ? std::min(opt.own_hi, nrows) : nrows;  // exclusive
+    std::vector<uint8_t> cover(nrows, 0);
+    bool excl = true;
+    for (const Group &G : groups) {
+        for (int i = 0; i < G.mc; i++) {
+            int64_t r = (G.rbase >= 0) ? (int64_t)G.rbase + i : rows[G.row_off + i];
+            if (cover[r]) excl = false;
+            cover[r] = 1;
+        }
+    }
+    // a symmetric matrix adds transposed contributions into the same y: never exclusive
+    if (sym) {
+        bool any_off = false;
+        for (const BlockIn &B : blocks) any_off |= (B.kind == KIND_OFF && B.m > 0 && B.n > 0);
+        if (any_off) excl = false;
+    }
+    exclusive_fwd = excl;
+
+    // ---- pack values ---------------------------------------------------------------------
+    values.assign((size_t)val_units * 16, 0);
+    {
+        const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(tun.pack_threads, (int64_t)chunks.size() / 64 + 1));
+        auto worker = [&](int t) {
+            for (size_t ci = t; ci < chunks.size(); ci += nt) {
+                const Chunk &c = chunks[ci];
+                const BlockIn &B = blocks[c.blk];
+                char *dst = values.data() + (size_t)c.val_off * 16;
+                if (es == 4)
+                    pack_chunk<uint32_t>((const uint32_t *)B.data, B.ld, c.ra, c.mc, B.n, E, (uint32_t *)dst);
+                else if (es == 8)
+                    pack_chunk<uint64_t>((const uint64_t *)B.data, B.ld, c.ra, c.mc, B.n, E, (uint64_t *)dst);
+                else
+                    pack_chunk<U16>((const U16 *)B.data, B.ld, c.ra, c.mc, B.n, E, (U16 *)dst);
+            }
+        };
+        std::vector<std::thread> th;
+        for (int t = 1; t < nt; t++) th.emplace_back(worker, t);
+        worker(0);
+        for (auto &x : th) x.join();
+    }
+
+    // ---- work items ----------------------------------------------------------------------
+    std::vector<Item> items;
+    for (int64_t g = 0; g < ngroups; g++) {
+        const Group &G = groups[g];
+        const int64_t strip_bytes = (int64_t)G.mc * 16;
+        int64_t per_item = G.strips;
+        if (!exclusive_fwd) {
+            int64_t maxs = std::max<int64_t>(1, tun.wgitem_max_bytes / strip_bytes);
+            int64_t nitem = (G.strips + maxs - 1) / maxs;
+            per_item = (G.strips + nitem - 1) / nitem;
+        }
+        for (int64_t s = 0; s < G.strips; s += per_item) {
+            Item it;
+            it.group = g;
+            it.s_begin = s;
+            it.s_end = std::min(G.strips, s + per_item);
+            it.bytes = (it.s_end - it.s_begin) * strip_bytes;
+            it.nw = it.bytes >= tun.split4_bytes ? 4 : (it.bytes >= tun.split2_bytes ? 2 : 1);
+            items.push_back(it);
+        }
+    }
+    std::stable_sort(items.begin(), items.end(), [](const Item &a, const Item &b) {
+        if (a.nw != b.nw) return a.nw > b.nw;
+        return a.bytes > b.bytes;
+    });
+
+    // ---- waves ---------------------------------------------------------------------------
+    waves.clear();
+    pieces.clear();
+    auto emit_nop = [&]() {
+        WaveWork w;
+        std::memset(&w, 0, sizeof w);
+        w.work = WORK_NOP;
+        w.grp = 1;
+        w.rbase = -1;
+        waves.push_back(w);
+    };
+    for (const Item &it : items) {
+        // align the start of a multi-wave item to its group size inside the workgroup
+        while ((int)(waves.size() % kWavesPerWg) % it.nw != 0) emit_nop();
+        const Group &G = groups[it.group];
+        const int64_t total = it.s_end - it.s_begin;
+        const int64_t per_wave = (total + it.nw - 1) / it.nw;
+        for (int w = 0; w < it.nw; w++) {
+            const int64_t wa = it.s_begin + std::min<int64_t>(total, (int64_t)w * per_wave);
+            const int64_t wb = it.s_begin + std::min<int64_t>(total, (int64_t)(w + 1) * per_wave);
+            WaveWork W;
+            std::memset(&W, 0, sizeof W);
+            W.work = WORK_PANEL;
+            W.m = (uint16_t)G.mc;
+            W.grp = (uint8_t)it.nw;
+            W.lead = (w == 0) ? 1 : 0;
+            W.rbase = G.rbase;
+            W.row_off = G.row_off;
+            W.piece_begin = (int32_t)pieces.size();
+            W.npieces = 0;
+            // walk the group's chunks and cut [wa, wb)
+            int64_t pos = 0;
+            for (int32_t ci : G.chunks) {
+                const Chunk &c = chunks[ci];
+                const int64_t ca = pos, cb = pos + c.nstrips;
+                pos = cb;
+                const int64_t a = std::max(ca, wa), bnd = std::min(cb, wb);
+                if (a >= bnd) continue;
+                const BlockIn &B = blocks[c.blk];
+                Piece P;
+                std::memset(&P, 0, sizeof P);
+                const int64_t sa = a - ca;  // first strip inside the chunk
+                P.val_off = c.val_off + (uint64_t)sa * (uint64_t)c.mc;
+                P.nstrips = (int32_t)(bnd - a);
+                P.ncols = (int32_t)std::min<int64_t>(B.n - sa * E, (bnd - a) * E);
+                P.xbase = blk_xbase[c.blk] >= 0 ? (int32_t)(blk_xbase[c.blk] + sa * E) : -1;
+                P.col_off = blk_coloff[c.blk] >= 0 ? (int32_t)(blk_coloff[c.blk] + sa * E) : 0;
+                P.kind = B.kind;
+                if (W.npieces == 0)
+                    W.first = P;
+                else
+                    pieces.push_back(P);
+                W.npieces++;
+            }
+            waves.push_back(W);
+        }
+    }
+    while (waves.size() % kWavesPerWg) emit_nop();
+    nwg_main = (int64_t)waves.size() / kWavesPerWg;
+
+    // ---- scale work for rows no group covers (exclusive forward launch) -------------------
+    if (exclusive_fwd) {
+        int64_t r = own_lo;
+        while (r < own_hi) {
+            if (cover[r]) {
+                r++;
+                continue;
+            }
+            int64_t e = r;
+            while (e < own_hi && !cover[e] && e - r < kScaleRowsPerWave) e++;
+            WaveWork W;
+            std::memset(&W, 0, sizeof W);
+            W.work = WORK_SCALE;
+            W.grp = 1;
+            W.rbase = (int32_t)r;
+            W.first.ncols = (int32_t)(e - r);
+            waves.push_back(W);
+            r = e;
+        }
+        while (waves.size() % kWavesPerWg) emit_nop();
+    }
+    nwg_total = (int64_t)waves.size() / kWavesPerWg;
+    if (pieces.empty()) {  // keep the device array non-empty
+        Piece P;
+        std::memset(&P, 0, sizeof P);
+        pieces.push_back(P);
+    }
+    if (rows.empty()) rows.push_back(0);
+    if (cols.empty()) cols.push_back(0);
+    if (values.empty()) values.assign(16, 0);
+
+    // ---- colouring (reference bookkeeping) ---------------------------------------------------
+    for (auto &c : colors) c.clear();
+    auto single = [](int64_t n) {
+        std::vector<std::vector<int64_t>> out(1);
+        out[0].resize(n);
+        std::iota(out[0].begin(), out[0].end(), (int64_t)1);
+        return out;
+    };
+    if (mtype == MT_BLOCKSPARSE) {
+        if (opt.scheduler == 0) {  // reference src/blockmatrix.jl:91-92
+            colors[0] = single(nb);
+            colors[1] = single(nb);
+        } else {  // src/blockmatrix.jl:94-98
+            std::vector<const int64_t *> rl(nb), cl(nb);
+            std::vector<int64_t> rn(nb), cn(nb);
+            for (int64_t b = 0; b < nb; b++) {
+                rl[b] = blocks[b].ridx;
+                rn[b] = blocks[b].ridx ? blocks[b].m : 0;
+                cl[b] = blocks[b].cidx;
+                cn[b] = blocks[b].cidx ? blocks[b].n : 0;
+            }
+            colors[0] = color_dsatur(rl, rn);
+            colors[1] = color_dsatur(cl, cn);
+        }
+    } else if (mtype == MT_SYMMETRIC) {
+        // always three colourings, also for the serial scheduler: src/symmetricblockmatrix.jl:104-110
+        std::vector<const int64_t *> dl, rl, cl;
+        std::vector<int64_t> dn, rn, cn;
+        for (const BlockIn &B : blocks) {
+            if (B.kind == KIND_DIAG) {
+                dl.push_back(B.ridx);
+                dn.push_back(B.ridx ? B.m : 0);
+            } else {
+                rl.push_back(B.ridx);
+                rn.push_back(B.ridx ? B.m : 0);
+                cl.push_back(B.cidx);
+                cn.push_back(B.cidx ? B.n : 0);
+            }
+        }
+        colors[0] = color_dsatur(rl, rn);
+        colors[1] = color_dsatur(cl, cn);
+        colors[2] = color_dsatur(dl, dn);
+    }
+    return "";
+}
+
+std::string Analysis::build_vbcrs(int dtype_, int64_t nrows_, int64_t ncols_, int64_t nblocks,
+                                  const void *const *blocks, const int64_t *m, const int64_t *n,
+                                  const int64_t *ld, const int64_t *rowstart,
+                                  const int64_t *colstart, const AnalysisOptions &opt_) {
+    if (nblocks < 1) return "VBCRS needs at least one block (reference src/vbcrs.jl:81)";
+    // perm = sortperm(1:n; by = i -> (rowindices[i], colindices[i]))   (src/vbcrs.jl:84), stable
+    std::vector<int64_t> p(nblocks);
+    std::iota(p.begin(), p.end(), (int64_t)0);
+    std::stable_sort(p.begin(), p.end(), [&](int64_t a, int64_t b) {
+        if (rowstart[a] != rowstart[b]) return rowstart[a] < rowstart[b];
+        return colstart[a] < colstart[b];
+    });
+    perm.resize(nblocks);
+    colindices.resize(nblocks);
+    rowptr.clear();
+    rowindices.clear();
+    // src/vbcrs.jl:103-117
+    rowptr.push_back(1);
+    rowindices.push_back(rowstart[p[0]]);
+    for (int64_t out = 0; out < nblocks; out++) {
+        const int64_t in = p[out];
+        if (rowstart[in] != rowindices.back()) {
+            rowptr.push_back(out + 1);
+            rowindices.push_back(rowstart[in]);
+        }
+        perm[out] = in + 1;
+        colindices[out] = colstart[in];
+    }
+    rowptr.push_back(nblocks + 1);
+    std::vector<BlockIn> in(nblocks);
+    for (int64_t out = 0; out < nblocks; out++) {
+        const int64_t i = p[out];
+        BlockIn &B = in[out];
+        B.data = (const char *)blocks[i];
+        B.m = m[i];
+        B.n = n[i];
+        B.ld = ld[i];
+        B.ridx = nullptr;
+        B.cidx = nullptr;
+        B.r0 = rowstart[i];
+        B.c0 = colstart[i];
+        B.kind = KIND_PLAIN;
+    }
+    return build(MT_VBCRS, dtype_, nrows_, ncols_, in, opt_);
+}
+
+}  // namespace bsm

@@ -1,0 +1,79 @@
+// bsm_analysis.h -- host-side analysis stage: everything the reference does at
+// construction time (VBCRS sort + rowptr, colouring) plus what the GPU path needs
+// (row grouping, strip packing, wave/workgroup schedule).  Pure C++, no HIP calls.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "bsm_layout.h"
+
+namespace bsm {
+
+enum MatType { MT_VBCRS = 0, MT_BLOCKSPARSE = 1, MT_SYMMETRIC = 2 };
+
+struct BlockIn {
+    const char *data;     // column-major m x n, leading dimension ld (elements)
+    int64_t m, n, ld;
+    const int64_t *ridx;  // 1-based row index list (m entries) or nullptr -> contiguous at r0
+    const int64_t *cidx;  // 1-based col index list (n entries) or nullptr -> contiguous at c0
+    int64_t r0, c0;       // 1-based first row / column when the lists are null
+    int kind;             // KIND_*
+};
+
+struct Tunables {
+    int64_t split2_bytes = 8 << 10;     // row groups at least this big get 2 waves
+    int64_t split4_bytes = 24 << 10;    // ... and 4 waves
+    int64_t wgitem_max_bytes = 512 << 10;  // non-exclusive groups are cut into items this big
+    int pack_threads = 8;
+    static Tunables from_env();
+};
+
+struct AnalysisOptions {
+    int scheduler = 0;   // 0 serial, 1 dynamic (colour like the reference)
+    int validate = 1;
+    int64_t own_lo = 0, own_hi = 0;  // 1-based inclusive, 0,0 = all rows
+};
+
+// Deterministic DSATUR colouring of blocks by index-list conflicts (two blocks conflict
+// iff their lists share an index -- reference src/coloring.jl:45-61).  Specification
+// identical to oracle/bsm_oracle.c:orc_color_dsatur.  Returns classes of 1-based ids.
+std::vector<std::vector<int64_t>> color_dsatur(const std::vector<const int64_t *> &lists,
+                                               const std::vector<int64_t> &lens);
+
+class Analysis {
+  public:
+    int mtype = 0, dtype = 0;
+    int es = 8;  // element size in bytes
+    int E = 2;   // columns per strip
+    int64_t nrows = 0, ncols = 0;
+    AnalysisOptions opt;
+    Tunables tun;
+
+    // ---- reference bookkeeping (1-based) ----
+    std::vector<int64_t> perm, rowptr, colindices, rowindices;  // VBCRS, src/vbcrs.jl:84-117
+    std::vector<std::vector<int64_t>> colors[3];  // 0 colors/offdiag, 1 transpose, 2 diagonal
+    int64_t nnz = 0, stored_entries = 0, alg_bytes = 0;
+
+    // ---- device image (host copy) ----
+    std::vector<char> values;
+    std::vector<int32_t> rows, cols;
+    std::vector<Piece> pieces;
+    std::vector<WaveWork> waves;
+    int64_t nwg_main = 0;   // workgroups holding panel work
+    int64_t nwg_total = 0;  // + workgroups of scale work (exclusive forward launch only)
+    int64_t ngroups = 0;
+    bool exclusive_fwd = false;  // every y row is produced by at most one row group
+
+    // Builds everything.  Returns "" on success, else an error message.
+    std::string build(int mtype, int dtype, int64_t nrows, int64_t ncols,
+                      const std::vector<BlockIn> &blocks, const AnalysisOptions &opt);
+
+    // VBCRS front end: sorts, fills perm/rowptr/..., then calls build with sorted blocks.
+    std::string build_vbcrs(int dtype, int64_t nrows, int64_t ncols, int64_t nblocks,
+                            const void *const *blocks, const int64_t *m, const int64_t *n,
+                            const int64_t *ld, const int64_t *rowstart, const int64_t *colstart,
+                            const AnalysisOptions &opt);
+};
+
+}  // namespace bsm

@@ -1,0 +1,424 @@
+// bsm_capi.cpp -- the extern "C" surface of libbsmrocm.so (include/bsm_rocm.h).
+// Plain pointers and sizes only; converts arguments, runs the host analysis, uploads the
+// packed image and forwards bsm_mul to the HIP launchers.  Never throws across the ABI.
+#include <hip/hip_runtime_api.h>
+
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/bsm_rocm.h"
+#include "bsm_analysis.h"
+#include "bsm_kernels.h"
+
+using namespace bsm;
+
+struct bsm_matrix_s {
+    Analysis an;
+    DeviceImage img;
+    bool on_device = false;
+};
+
+static thread_local std::string g_err;
+
+static int fail(int code, const std::string &msg) {
+    g_err = msg;
+    return code;
+}
+
+static int hip_fail(hipError_t e, const char *what) {
+    return fail(BSM_ERR_DEVICE, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+extern "C" const char *bsm_last_error(void) { return g_err.c_str(); }
+
+extern "C" const char *bsm_version(void) { return "bsmrocm 0.1 gfx950"; }
+
+extern "C" void bsm_options_default(bsm_options *o) {
+    if (!o) return;
+    std::memset(o, 0, sizeof *o);
+    o->struct_size = (int32_t)sizeof(bsm_options);
+    o->device = BSM_DEVICE_CURRENT;
+    o->scheduler = BSM_SCHED_SERIAL;
+    o->accumulate = BSM_ACC_AUTO;
+    o->validate = 1;
+}
+
+namespace {
+
+struct DeviceGuard {
+    int prev = -1;
+    bool active = false;
+    hipError_t enter(int dev) {
+        hipError_t e = hipGetDevice(&prev);
+        if (e != hipSuccess) return e;
+        if (prev != dev) {
+            e = hipSetDevice(dev);
+            if (e != hipSuccess) return e;
+            active = true;
+        }
+        return hipSuccess;
+    }
+    ~DeviceGuard() {
+        if (active) (void)hipSetDevice(prev);
+    }
+};
+
+int read_options(const bsm_options *opts, bsm_options &o) {
+    bsm_options_default(&o);
+    if (opts) {
+        if (opts->struct_size != (int32_t)sizeof(bsm_options))
+            return fail(BSM_ERR_INVALID, "bsm_options.struct_size mismatch (call bsm_options_default)");
+        o = *opts;
+    }
+    if (o.accumulate == BSM_ACC_COLORED)
+        return fail(BSM_ERR_UNSUPPORTED, "BSM_ACC_COLORED is not implemented yet");
+    if (o.accumulate != BSM_ACC_AUTO && o.accumulate != BSM_ACC_ATOMIC)
+        return fail(BSM_ERR_INVALID, "unknown accumulate mode");
+    if (o.own_lo < 0 || o.own_hi < 0 || (o.own_hi > 0 && o.own_hi < o.own_lo))
+        return fail(BSM_ERR_INVALID, "bad own_lo/own_hi");
+    return BSM_OK;
+}
+
+template <typename V> hipError_t upload(const V &v, void **dptr, long long &total) {
+    const size_t bytes = v.size() * sizeof(v[0]);
+    hipError_t e = hipMalloc(dptr, bytes ? bytes : 16);
+    if (e != hipSuccess) return e;
+    total += (long long)bytes;
+    if (bytes) e = hipMemcpy(*dptr, v.data(), bytes, hipMemcpyHostToDevice);
+    return e;
+}
+
+void free_image(DeviceImage &img) {
+    for (void **p : {&img.d_values, &img.d_rows, &img.d_cols, &img.d_pieces, &img.d_waves}) {
+        if (*p) (void)hipFree(*p);
+        *p = nullptr;
+    }
+}
+
+int finish_create(bsm_matrix_s *A, const bsm_options &o, bsm_matrix_t *out) {
+    Analysis &an = A->an;
+    DeviceImage &img = A->img;
+    img.dtype = an.dtype;
+    img.nrows = an.nrows;
+    img.ncols = an.ncols;
+    img.own_lo = (o.own_lo > 0) ? o.own_lo - 1 : 0;
+    img.own_hi = (o.own_hi > 0) ? std::min<long long>(o.own_hi, an.nrows) : an.nrows;
+    img.nwg_main = an.nwg_main;
+    img.nwg_total = an.nwg_total;
+    img.exclusive_fwd = an.exclusive_fwd && o.accumulate == BSM_ACC_AUTO;
+    img.has_off = false;
+    for (const WaveWork &w : an.waves)
+        if (w.work == WORK_PANEL && w.npieces > 0 && w.first.kind == KIND_OFF) img.has_off = true;
+    for (const Piece &p : an.pieces)
+        if (p.kind == KIND_OFF && p.nstrips > 0) img.has_off = true;
+    if (!img.exclusive_fwd) img.nwg_total = img.nwg_main;
+
+    if (o.device != BSM_DEVICE_NONE) {
+        int dev = o.device;
+        hipError_t e;
+        if (dev == BSM_DEVICE_CURRENT) {
+            e = hipGetDevice(&dev);
+            if (e != hipSuccess) {
+                delete A;
+                return hip_fail(e, "hipGetDevice");
+            }
+        }
+        DeviceGuard guard;
+        e = guard.enter(dev);
+        if (e != hipSuccess) {
+            delete A;
+            return hip_fail(e, "hipSetDevice");
+        }
+        img.device = dev;
+        long long total = 0;
+        e = upload(an.values, &img.d_values, total);
+        if (e == hipSuccess) e = upload(an.rows, &img.d_rows, total);
+        if (e == hipSuccess) e = upload(an.cols, &img.d_cols, total);
+        if (e == hipSuccess) e = upload(an.pieces, &img.d_pieces, total);
+        if (e == hipSuccess) e = upload(an.waves, &img.d_waves, total);
+        if (e != hipSuccess) {
+            free_image(img);
+            delete A;
+            return hip_fail(e, "device upload");
+        }
+        img.device_bytes = total;
+        A->on_device = true;
+        // the packed host copy is no longer needed
+        std::vector<char>().swap(an.values);
+    } else {
+        img.device_bytes = (long long)(an.values.size() + an.rows.size() * 4 + an.cols.size() * 4 +
+                                       an.pieces.size() * sizeof(Piece) + an.waves.size() * sizeof(WaveWork));
+    }
+    *out = A;
+    return BSM_OK;
+}
+
+AnalysisOptions to_aopt(const bsm_options &o) {
+    AnalysisOptions a;
+    a.scheduler = o.scheduler;
+    a.validate = 1;  // indices are always range-checked: a bad index must never reach a kernel
+    a.own_lo = o.own_lo;
+    a.own_hi = o.own_hi;
+    return a;
+}
+
+}  // namespace
+
+extern "C" int bsm_vbcrs_create(int dtype, int64_t nrows, int64_t ncols, int64_t nblocks,
+                                const void *const *blocks, const int64_t *m, const int64_t *n,
+                                const int64_t *ld, const int64_t *rowstart, const int64_t *colstart,
+                                const bsm_options *opts, bsm_matrix_t *out) {
+    try {
+        if (!out) return fail(BSM_ERR_INVALID, "out is null");
+        *out = nullptr;
+        if (nblocks < 1) return fail(BSM_ERR_INVALID, "VBCRS needs at least one block");
+        if (!blocks || !m || !n || !ld || !rowstart || !colstart)
+            return fail(BSM_ERR_INVALID, "null argument");
+        bsm_options o;
+        int rc = read_options(opts, o);
+        if (rc) return rc;
+        bsm_matrix_s *A = new bsm_matrix_s();
+        std::string err = A->an.build_vbcrs(dtype, nrows, ncols, nblocks, blocks, m, n, ld, rowstart,
+                                            colstart, to_aopt(o));
+        if (!err.empty()) {
+            delete A;
+            return fail(BSM_ERR_INVALID, err);
+        }
+        return finish_create(A, o, out);
+    } catch (const std::bad_alloc &) {
+        return fail(BSM_ERR_ALLOC, "out of host memory");
+    } catch (const std::exception &e) {
+        return fail(BSM_ERR_INVALID, e.what());
+    }
+}
+
+extern "C" int bsm_blocksparse_create(int dtype, int64_t nrows, int64_t ncols, int64_t nblocks,
+                                      const void *const *blocks, const int64_t *m, const int64_t *n,
+                                      const int64_t *ld, const int64_t *const *rowidx,
+                                      const int64_t *const *colidx, const bsm_options *opts,
+                                      bsm_matrix_t *out) {
+    try {
+        if (!out) return fail(BSM_ERR_INVALID, "out is null");
+        *out = nullptr;
+        if (nblocks < 0) return fail(BSM_ERR_INVALID, "negative block count");
+        if (nblocks > 0 && (!blocks || !m || !n || !ld || !rowidx || !colidx))
+            return fail(BSM_ERR_INVALID, "null argument");
+        bsm_options o;
+        int rc = read_options(opts, o);
+        if (rc) return rc;
+        std::vector<BlockIn> in((size_t)nblocks);
+        for (int64_t b = 0; b < nblocks; b++) {
+            BlockIn &B = in[b];
+            B.data = (const char *)blocks[b];
+            B.m = m[b];
+            B.n = n[b];
+            B.ld = ld[b];
+            B.ridx = rowidx[b];
+            B.cidx = colidx[b];
+            B.r0 = B.c0 = 0;
+            B.kind = KIND_PLAIN;
+            if ((B.m > 0 && !B.ridx) || (B.n > 0 && !B.cidx))
+                return fail(BSM_ERR_INVALID, "block " + std::to_string(b + 1) + ": null index list");
+        }
+        bsm_matrix_s *A = new bsm_matrix_s();
+        std::string err = A->an.build(MT_BLOCKSPARSE, dtype, nrows, ncols, in, to_aopt(o));
+        if (!err.empty()) {
+            delete A;
+            return fail(BSM_ERR_INVALID, err);
+        }
+        return finish_create(A, o, out);
+    } catch (const std::bad_alloc &) {
+        return fail(BSM_ERR_ALLOC, "out of host memory");
+    } catch (const std::exception &e) {
+        return fail(BSM_ERR_INVALID, e.what());
+    }
+}
+
+extern "C" int bsm_symmetric_create(int dtype, int64_t nrows, int64_t ncols, int64_t ndiag,
+                                    const void *const *diag, const int64_t *dsize, const int64_t *dld,
+                                    const int64_t *const *diagidx, int64_t noff,
+                                    const void *const *off, const int64_t *m, const int64_t *n,
+                                    const int64_t *ld, const int64_t *const *rowidx,
+                                    const int64_t *const *colidx, const bsm_options *opts,
+                                    bsm_matrix_t *out) {
+    try {
+        if (!out) return fail(BSM_ERR_INVALID, "out is null");
+        *out = nullptr;
+        if (ndiag < 0 || noff < 0) return fail(BSM_ERR_INVALID, "negative block count");
+        if (ndiag > 0 && (!diag || !dsize || !dld || !diagidx)) return fail(BSM_ERR_INVALID, "null argument");
+        if (noff > 0 && (!off || !m || !n || !ld || !rowidx || !colidx))
+            return fail(BSM_ERR_INVALID, "null argument");
+        bsm_options o;
+        int rc = read_options(opts, o);
+        if (rc) return rc;
+        std::vector<BlockIn> in;
+        in.reserve((size_t)(ndiag + noff));
+        for (int64_t d = 0; d < ndiag; d++) {
+            BlockIn B;
+            B.data = (const char *)diag[d];
+            B.m = B.n = dsize[d];
+            B.ld = dld[d];
+            B.ridx = B.cidx = diagidx[d];
+            B.r0 = B.c0 = 0;
+            B.kind = KIND_DIAG;
+            if (B.m > 0 && !B.ridx)
+                return fail(BSM_ERR_INVALID, "diagonal block " + std::to_string(d + 1) + ": null index list");
+            in.push_back(B);
+        }
+        for (int64_t b = 0; b < noff; b++) {
+            BlockIn B;
+            B.data = (const char *)off[b];
+            B.m = m[b];
+            B.n = n[b];
+            B.ld = ld[b];
+            B.ridx = rowidx[b];
+            B.cidx = colidx[b];
+            B.r0 = B.c0 = 0;
+            B.kind = KIND_OFF;
+            if ((B.m > 0 && !B.ridx) || (B.n > 0 && !B.cidx))
+                return fail(BSM_ERR_INVALID, "off-diagonal block " + std::to_string(b + 1) + ": null index list");
+            in.push_back(B);
+        }
+        bsm_matrix_s *A = new bsm_matrix_s();
+        std::string err = A->an.build(MT_SYMMETRIC, dtype, nrows, ncols, in, to_aopt(o));
+        if (!err.empty()) {
+            delete A;
+            return fail(BSM_ERR_INVALID, err);
+        }
+        return finish_create(A, o, out);
+    } catch (const std::bad_alloc &) {
+        return fail(BSM_ERR_ALLOC, "out of host memory");
+    } catch (const std::exception &e) {
+        return fail(BSM_ERR_INVALID, e.what());
+    }
+}
+
+extern "C" int bsm_mul(bsm_matrix_t A, int op, const void *x, void *y, const void *alpha,
+                       const void *beta, int beta_strong_zero, int memspace, void *stream) {
+    if (!A) return fail(BSM_ERR_INVALID, "null handle");
+    if (op < 0 || op > 2) return fail(BSM_ERR_INVALID, "bad op");
+    if (!x || !y) return fail(BSM_ERR_INVALID, "null vector");
+    if (!A->on_device)
+        return fail(BSM_ERR_DEVICE, "handle has no device image (created with BSM_DEVICE_NONE)");
+    const DeviceImage &img = A->img;
+    DeviceGuard guard;
+    hipError_t e = guard.enter(img.device);
+    if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
+    hipStream_t st = (hipStream_t)stream;
+    if (memspace == BSM_MEM_DEVICE) {
+        e = launch_mul(img, op, x, y, alpha, beta, beta_strong_zero, st);
+        if (e != hipSuccess) return hip_fail(e, "kernel launch");
+        return BSM_OK;
+    }
+    if (memspace != BSM_MEM_HOST) return fail(BSM_ERR_INVALID, "bad memspace");
+    // host vectors: stage through device buffers (PCIe), synchronous
+    const size_t es = (size_t)A->an.es;
+    const size_t xlen = (size_t)(op == 0 ? img.ncols : img.nrows);
+    const size_t ylen = (size_t)(op == 0 ? img.nrows : img.ncols);
+    void *dx = nullptr, *dy = nullptr;
+    e = hipMalloc(&dx, xlen * es + 16);
+    if (e == hipSuccess) e = hipMalloc(&dy, ylen * es + 16);
+    if (e == hipSuccess) e = hipMemcpyAsync(dx, x, xlen * es, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess && !beta_strong_zero)
+        e = hipMemcpyAsync(dy, y, ylen * es, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = launch_mul(img, op, dx, dy, alpha, beta, beta_strong_zero, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(y, dy, ylen * es, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (dx) (void)hipFree(dx);
+    if (dy) (void)hipFree(dy);
+    if (e != hipSuccess) return hip_fail(e, "host-staged mul");
+    return BSM_OK;
+}
+
+static int copy_out(const std::vector<int64_t> &v, int64_t *out, int64_t *len) {
+    if (!len) return fail(BSM_ERR_INVALID, "len is null");
+    if (out) {
+        if (*len < (int64_t)v.size()) return fail(BSM_ERR_INVALID, "output buffer too small");
+        std::memcpy(out, v.data(), v.size() * sizeof(int64_t));
+    }
+    *len = (int64_t)v.size();
+    return BSM_OK;
+}
+
+extern "C" int bsm_get_bookkeeping(bsm_matrix_t A, int which, int64_t *out, int64_t *len) {
+    if (!A) return fail(BSM_ERR_INVALID, "null handle");
+    const Analysis &an = A->an;
+    switch (which) {
+        case BSM_BK_VBCRS_PERM:
+        case BSM_BK_VBCRS_ROWPTR:
+        case BSM_BK_VBCRS_COLINDICES:
+        case BSM_BK_VBCRS_ROWINDICES: {
+            if (an.mtype != MT_VBCRS) return fail(BSM_ERR_INVALID, "not a VBCRS handle");
+            const std::vector<int64_t> *v = which == BSM_BK_VBCRS_PERM         ? &an.perm
+                                            : which == BSM_BK_VBCRS_ROWPTR     ? &an.rowptr
+                                            : which == BSM_BK_VBCRS_COLINDICES ? &an.colindices
+                                                                               : &an.rowindices;
+            return copy_out(*v, out, len);
+        }
+        case BSM_BK_COLORS:
+        case BSM_BK_TRANSPOSECOLORS:
+        case BSM_BK_DIAGONALCOLORS: {
+            if (an.mtype == MT_VBCRS) return fail(BSM_ERR_INVALID, "VBCRS has no colours");
+            if (which == BSM_BK_DIAGONALCOLORS && an.mtype != MT_SYMMETRIC)
+                return fail(BSM_ERR_INVALID, "not a symmetric handle");
+            const auto &cs = an.colors[which - BSM_BK_COLORS];
+            std::vector<int64_t> flat;
+            flat.push_back((int64_t)cs.size());
+            for (const auto &c : cs) {
+                flat.push_back((int64_t)c.size());
+                flat.insert(flat.end(), c.begin(), c.end());
+            }
+            return copy_out(flat, out, len);
+        }
+    }
+    return fail(BSM_ERR_INVALID, "unknown bookkeeping id");
+}
+
+extern "C" int bsm_get_image(bsm_matrix_t A, int which, void *out, int64_t *nbytes) {
+    if (!A || !nbytes) return fail(BSM_ERR_INVALID, "null argument");
+    if (A->on_device) return fail(BSM_ERR_UNSUPPORTED, "image dump needs an analysis-only handle");
+    const Analysis &an = A->an;
+    const void *src = nullptr;
+    size_t bytes = 0;
+    switch (which) {
+        case 0: src = an.values.data(); bytes = an.values.size(); break;
+        case 1: src = an.rows.data(); bytes = an.rows.size() * 4; break;
+        case 2: src = an.cols.data(); bytes = an.cols.size() * 4; break;
+        case 3: src = an.pieces.data(); bytes = an.pieces.size() * sizeof(Piece); break;
+        case 4: src = an.waves.data(); bytes = an.waves.size() * sizeof(WaveWork); break;
+        default: return fail(BSM_ERR_INVALID, "unknown image array");
+    }
+    if (out) {
+        if (*nbytes < (int64_t)bytes) return fail(BSM_ERR_INVALID, "output buffer too small");
+        std::memcpy(out, src, bytes);
+    }
+    *nbytes = (int64_t)bytes;
+    return BSM_OK;
+}
+
+extern "C" int bsm_stats(bsm_matrix_t A, bsm_stats_t *out) {
+    if (!A || !out) return fail(BSM_ERR_INVALID, "null argument");
+    std::memset(out, 0, sizeof *out);
+    out->nnz = A->an.nnz;
+    out->stored_entries = A->an.stored_entries;
+    out->alg_bytes = A->an.alg_bytes;
+    out->device_bytes = A->img.device_bytes;
+    out->npanels = A->an.ngroups;
+    out->ntasks = (int64_t)A->an.waves.size();
+    out->nworkgroups = A->img.nwg_total;
+    out->exclusive = A->img.exclusive_fwd ? 1 : 0;
+    return BSM_OK;
+}
+
+extern "C" int bsm_destroy(bsm_matrix_t A) {
+    if (!A) return BSM_OK;
+    if (A->on_device) {
+        DeviceGuard guard;
+        (void)guard.enter(A->img.device);
+        free_image(A->img);
+    }
+    delete A;
+    return BSM_OK;
+}

@@ -1,0 +1,27 @@
+// bsm_kernels.h -- interface between the C ABI glue and the HIP kernels.
+#pragma once
+#include <hip/hip_runtime_api.h>
+
+#include <cstdint>
+
+namespace bsm {
+
+struct DeviceImage {
+    int dtype = 1;
+    int device = 0;
+    long long nrows = 0, ncols = 0;
+    long long own_lo = 0, own_hi = 0;  // 0-based [lo, hi) rows of y scaled by this handle
+    void *d_values = nullptr, *d_rows = nullptr, *d_cols = nullptr;
+    void *d_pieces = nullptr, *d_waves = nullptr;
+    long long nwg_main = 0, nwg_total = 0;
+    bool exclusive_fwd = false;
+    bool has_off = false;  // SymmetricBlockMatrix off-diagonal pieces present
+    long long device_bytes = 0;
+};
+
+// Enqueues y = alpha*op(A)*x + beta*y on `stream`.  x, y device pointers.  No allocation,
+// no synchronisation (graph-capturable).
+hipError_t launch_mul(const DeviceImage &img, int op, const void *x, void *y, const void *alpha,
+                      const void *beta, int strong_zero, hipStream_t stream);
+
+}  // namespace bsm

@@ -1,0 +1,414 @@
+// bsm_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the block-sparse
+// mat-vec engine.  One kernel family streams STRIP-packed pieces (bsm_layout.h):
+//
+//   forward    u[i]  = sum_w B[i,w] * x[col(w)]     lane owns a row, 16-byte lane loads,
+//                                                    x slice staged through LDS per wave
+//   transposed v[w]  = sum_i B[i,w] * x[row(i)]     same bytes, halving butterfly across the
+//                                                    P lanes of a strip, then y[col(w)] += v
+//
+// Both directions are taken from ONE read of the piece (SymmetricBlockMatrix off-diagonal
+// blocks: reference src/symmetricblockmatrix.jl:394-418 reads them twice).
+// The kernels are HBM-bound (0.25-0.5 FLOP/B): no MFMA, everything is about keeping
+// >= 8 KB per wave in flight with perfectly coalesced 16-byte loads.
+#include <hip/hip_runtime.h>
+
+#include "bsm_kernels.h"
+#include "bsm_layout.h"
+
+namespace bsm {
+
+// ----------------------------------------------------------------------------------------
+// element types
+// ----------------------------------------------------------------------------------------
+struct c64 {
+    float re, im;
+};
+struct c128 {
+    double re, im;
+};
+
+template <typename T> struct TT;
+template <> struct TT<float> {
+    static constexpr int E = 4;
+};
+template <> struct TT<double> {
+    static constexpr int E = 2;
+};
+template <> struct TT<c64> {
+    static constexpr int E = 2;
+};
+template <> struct TT<c128> {
+    static constexpr int E = 1;
+};
+
+template <typename T> struct alignas(16) Vec16 {
+    T v[TT<T>::E];
+};
+
+__device__ __forceinline__ float zero_of(float) { return 0.f; }
+__device__ __forceinline__ double zero_of(double) { return 0.0; }
+__device__ __forceinline__ c64 zero_of(c64) { return c64{0.f, 0.f}; }
+__device__ __forceinline__ c128 zero_of(c128) { return c128{0.0, 0.0}; }
+
+__device__ __forceinline__ float add(float a, float b) { return a + b; }
+__device__ __forceinline__ double add(double a, double b) { return a + b; }
+__device__ __forceinline__ c64 add(c64 a, c64 b) { return c64{a.re + b.re, a.im + b.im}; }
+__device__ __forceinline__ c128 add(c128 a, c128 b) { return c128{a.re + b.re, a.im + b.im}; }
+
+__device__ __forceinline__ float mul(float a, float b) { return a * b; }
+__device__ __forceinline__ double mul(double a, double b) { return a * b; }
+__device__ __forceinline__ c64 mul(c64 a, c64 b) {
+    return c64{a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re};
+}
+__device__ __forceinline__ c128 mul(c128 a, c128 b) {
+    return c128{a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re};
+}
+
+// acc + a*b
+__device__ __forceinline__ float madd(float acc, float a, float b) { return fmaf(a, b, acc); }
+__device__ __forceinline__ double madd(double acc, double a, double b) { return fma(a, b, acc); }
+__device__ __forceinline__ c64 madd(c64 acc, c64 a, c64 b) {
+    acc.re = fmaf(a.re, b.re, acc.re);
+    acc.re = fmaf(-a.im, b.im, acc.re);
+    acc.im = fmaf(a.re, b.im, acc.im);
+    acc.im = fmaf(a.im, b.re, acc.im);
+    return acc;
+}
+__device__ __forceinline__ c128 madd(c128 acc, c128 a, c128 b) {
+    acc.re = fma(a.re, b.re, acc.re);
+    acc.re = fma(-a.im, b.im, acc.re);
+    acc.im = fma(a.re, b.im, acc.im);
+    acc.im = fma(a.im, b.re, acc.im);
+    return acc;
+}
+
+__device__ __forceinline__ float cj(float a, bool) { return a; }
+__device__ __forceinline__ double cj(double a, bool) { return a; }
+__device__ __forceinline__ c64 cj(c64 a, bool c) { return c64{a.re, c ? -a.im : a.im}; }
+__device__ __forceinline__ c128 cj(c128 a, bool c) { return c128{a.re, c ? -a.im : a.im}; }
+
+__device__ __forceinline__ float shx(float a, int d) { return __shfl_xor(a, d, 64); }
+__device__ __forceinline__ double shx(double a, int d) { return __shfl_xor(a, d, 64); }
+__device__ __forceinline__ c64 shx(c64 a, int d) {
+    return c64{__shfl_xor(a.re, d, 64), __shfl_xor(a.im, d, 64)};
+}
+__device__ __forceinline__ c128 shx(c128 a, int d) {
+    return c128{__shfl_xor(a.re, d, 64), __shfl_xor(a.im, d, 64)};
+}
+
+// hardware floating-point atomics (global_atomic_add_f32 / _f64; built with
+// -munsafe-fp-atomics so no compare-and-swap loop is emitted)
+__device__ __forceinline__ void atomic_acc(float *p, float v) { atomicAdd(p, v); }
+__device__ __forceinline__ void atomic_acc(double *p, double v) { atomicAdd(p, v); }
+__device__ __forceinline__ void atomic_acc(c64 *p, c64 v) {
+    atomicAdd(&p->re, v.re);
+    atomicAdd(&p->im, v.im);
+}
+__device__ __forceinline__ void atomic_acc(c128 *p, c128 v) {
+    atomicAdd(&p->re, v.re);
+    atomicAdd(&p->im, v.im);
+}
+
+// ----------------------------------------------------------------------------------------
+// halving butterfly: every lane of a P-lane group holds CUR partial values; afterwards the
+// group's sums are spread over its lanes: lane i keeps max(1, V/P) of them, starting at
+// value index `pos`; lanes with (i & dup) != 0 hold duplicates and must not emit.
+// ----------------------------------------------------------------------------------------
+template <typename T, int CUR, int D, int P> struct Butterfly {
+    static __device__ __forceinline__ void run(T *v, int i, int &pos, int &dup) {
+        if constexpr (D < P) {
+            const bool hi = (i & D) != 0;
+            if constexpr (CUR >= 2) {
+                constexpr int H = CUR / 2;
+#pragma unroll
+                for (int j = 0; j < H; ++j) {
+                    const T keep = hi ? v[H + j] : v[j];
+                    const T send = hi ? v[j] : v[H + j];
+                    v[j] = add(keep, shx(send, D));
+                }
+                if (hi) pos += H;
+                Butterfly<T, H, D * 2, P>::run(v, i, pos, dup);
+            } else {
+                v[0] = add(v[0], shx(v[0], D));
+                dup |= D;
+                Butterfly<T, 1, D * 2, P>::run(v, i, pos, dup);
+            }
+        }
+    }
+};
+
+constexpr int FLAG_STRONG_ZERO = 1;
+constexpr int FLAG_DIRECT = 2;
+constexpr int FLAG_CONJ = 4;
+constexpr int FLAG_OPT = 8;
+
+// ----------------------------------------------------------------------------------------
+// one wave streams its pieces; returns the forward partial sum of row (lane % P)
+// ----------------------------------------------------------------------------------------
+template <typename T, int L, int P, bool FWD, bool TRN>
+__device__ __forceinline__ T run_panel(const WaveWork *__restrict__ wp,
+                                       const Piece *__restrict__ pieces,
+                                       const uint4 *__restrict__ values,
+                                       const int *__restrict__ rows, const int *__restrict__ cols,
+                                       const T *__restrict__ x, T *__restrict__ y, T alpha,
+                                       int flags, int lane, T *xs, T *vs) {
+    constexpr int E = TT<T>::E;
+    constexpr int G = 64 / P;
+    constexpr int V = L * E;
+    constexpr int NC = G * L * E;  // columns covered per iteration
+    const bool opT = (flags & FLAG_OPT) != 0;
+    const bool cjf = (flags & FLAG_CONJ) != 0;
+    const int m = wp->m;
+    const int npieces = wp->npieces;
+    const int rbase = wp->rbase;
+    const int row_off = wp->row_off;
+    const int piece_begin = wp->piece_begin;
+    const int i = lane & (P - 1);
+    const int g = lane / P;
+    const bool row_ok = i < m;
+
+    T acc = zero_of(T{});
+    T xr = zero_of(T{});
+    if (TRN && row_ok) {
+        const int ri = (rbase >= 0) ? rbase + i : rows[row_off + i];
+        xr = x[ri];
+    }
+
+    for (int pi = 0; pi < npieces; ++pi) {
+        const Piece *pp = (pi == 0) ? &wp->first : (pieces + piece_begin + pi - 1);
+        const uint64_t val_off = pp->val_off;
+        const int xbase = pp->xbase;
+        const int col_off = pp->col_off;
+        const int nstrips = pp->nstrips;
+        const int ncols = pp->ncols;
+        const int kind = pp->kind;
+        const bool fwd_en = FWD && (!opT || kind == KIND_OFF);
+        const bool trn_en = TRN && (opT || kind == KIND_OFF);
+        const Vec16<T> *vb = reinterpret_cast<const Vec16<T> *>(values + val_off);
+
+        for (int s0 = 0; s0 < nstrips; s0 += G * L) {
+            Vec16<T> b[L];
+#pragma unroll
+            for (int l = 0; l < L; ++l) {
+                const int s = s0 + l * G + g;
+                if (row_ok && s < nstrips) {
+                    b[l] = vb[(size_t)s * m + i];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < E; ++e) b[l].v[e] = zero_of(T{});
+                }
+            }
+            if (fwd_en) {
+#pragma unroll
+                for (int c = lane; c < NC; c += 64) {
+                    const int w = s0 * E + c;
+                    T xv = zero_of(T{});
+                    if (w < ncols) {
+                        const int xi = (xbase >= 0) ? xbase + w : cols[col_off + w];
+                        xv = x[xi];
+                    }
+                    xs[c] = xv;
+                }
+#pragma unroll
+                for (int l = 0; l < L; ++l) {
+                    const Vec16<T> xv = *reinterpret_cast<const Vec16<T> *>(&xs[(l * G + g) * E]);
+#pragma unroll
+                    for (int e = 0; e < E; ++e) acc = madd(acc, cj(b[l].v[e], cjf), xv.v[e]);
+                }
+            }
+            if (trn_en) {
+                T vals[V];
+#pragma unroll
+                for (int l = 0; l < L; ++l)
+#pragma unroll
+                    for (int e = 0; e < E; ++e) vals[l * E + e] = mul(cj(b[l].v[e], cjf), xr);
+                int pos = 0, dup = 0;
+                Butterfly<T, V, 1, P>::run(vals, i, pos, dup);
+                constexpr int CF = (V / P) > 1 ? (V / P) : 1;
+                if ((i & dup) == 0) {
+#pragma unroll
+                    for (int j = 0; j < CF; ++j) {
+                        const int q = pos + j;  // original value index l*E + e
+                        const int l = q / E, e = q % E;
+                        vs[(l * G + g) * E + e] = vals[j];
+                    }
+                }
+#pragma unroll
+                for (int c = lane; c < NC; c += 64) {
+                    const int w = s0 * E + c;
+                    if (w < ncols) {
+                        const int yi = (xbase >= 0) ? xbase + w : cols[col_off + w];
+                        atomic_acc(&y[yi], mul(alpha, vs[c]));
+                    }
+                }
+            }
+        }
+    }
+    if (FWD) {
+#pragma unroll
+        for (int d = P; d < 64; d <<= 1) acc = add(acc, shx(acc, d));
+    }
+    return acc;
+}
+
+template <typename T, int L, bool FWD, bool TRN>
+__global__ void __launch_bounds__(256)
+    panel_kernel(const WaveWork *__restrict__ waves, const Piece *__restrict__ pieces,
+                 const uint4 *__restrict__ values, const int *__restrict__ rows,
+                 const int *__restrict__ cols, const T *__restrict__ x, T *__restrict__ y, T alpha,
+                 T beta, int flags) {
+    constexpr int E = TT<T>::E;
+    constexpr int XS = 8 * L * E;
+    __shared__ __attribute__((aligned(16))) T xs[kWavesPerWg][XS];
+    __shared__ __attribute__((aligned(16))) T vs[kWavesPerWg][TRN ? XS : 1];
+    __shared__ T red[kWavesPerWg][64];
+
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const WaveWork *wp = waves + ((size_t)blockIdx.x * kWavesPerWg + wave);
+    const int work = wp->work;
+    const int m = wp->m;
+
+    T u = zero_of(T{});
+    if (work == WORK_PANEL) {
+        if (m <= 8)
+            u = run_panel<T, L, 8, FWD, TRN>(wp, pieces, values, rows, cols, x, y, alpha, flags, lane, xs[wave], vs[wave]);
+        else if (m <= 16)
+            u = run_panel<T, L, 16, FWD, TRN>(wp, pieces, values, rows, cols, x, y, alpha, flags, lane, xs[wave], vs[wave]);
+        else if (m <= 32)
+            u = run_panel<T, L, 32, FWD, TRN>(wp, pieces, values, rows, cols, x, y, alpha, flags, lane, xs[wave], vs[wave]);
+        else
+            u = run_panel<T, L, 64, FWD, TRN>(wp, pieces, values, rows, cols, x, y, alpha, flags, lane, xs[wave], vs[wave]);
+    }
+    const bool direct = (flags & FLAG_DIRECT) != 0;
+    const bool sz = (flags & FLAG_STRONG_ZERO) != 0;
+    if (FWD) {
+        const int grp = wp->grp;
+        red[wave][lane] = u;
+        __syncthreads();
+        if (work == WORK_PANEL && wp->lead) {
+            for (int k = 1; k < grp; ++k) u = add(u, red[wave + k][lane]);
+            if (lane < m) {
+                const int rbase = wp->rbase;
+                const int yi = (rbase >= 0) ? rbase + lane : rows[wp->row_off + lane];
+                const T val = mul(alpha, u);
+                if (direct) {
+                    y[yi] = sz ? val : madd(val, beta, y[yi]);
+                } else {
+                    atomic_acc(&y[yi], val);
+                }
+            }
+        }
+    }
+    if (work == WORK_SCALE && direct) {
+        const int rbase = wp->rbase;
+        const int cnt = wp->first.ncols;
+        for (int r = lane; r < cnt; r += 64) y[rbase + r] = sz ? zero_of(T{}) : mul(beta, y[rbase + r]);
+    }
+}
+
+// y[lo .. hi) = beta * y  (or 0 for the strong zero) -- `y .*= beta`,
+// reference src/blockmatrix.jl:231, src/symmetricblockmatrix.jl:392, src/vbcrs.jl:273,313
+template <typename T>
+__global__ void __launch_bounds__(256) scale_kernel(T *__restrict__ y, long long lo, long long hi,
+                                                    T beta, int strong_zero) {
+    long long i = lo + (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (; i < hi; i += stride) y[i] = strong_zero ? zero_of(T{}) : mul(beta, y[i]);
+}
+
+// ----------------------------------------------------------------------------------------
+// launchers
+// ----------------------------------------------------------------------------------------
+template <typename T> static T make_scalar(double v);
+template <> float make_scalar<float>(double v) { return (float)v; }
+template <> double make_scalar<double>(double v) { return v; }
+template <> c64 make_scalar<c64>(double v) { return c64{(float)v, 0.f}; }
+template <> c128 make_scalar<c128>(double v) { return c128{v, 0.0}; }
+
+template <typename T> static T load_scalar(const void *p, double dflt) {
+    return p ? *reinterpret_cast<const T *>(p) : make_scalar<T>(dflt);
+}
+
+template <typename T> static bool is_one(T v);
+template <> bool is_one(float v) { return v == 1.f; }
+template <> bool is_one(double v) { return v == 1.0; }
+template <> bool is_one(c64 v) { return v.re == 1.f && v.im == 0.f; }
+template <> bool is_one(c128 v) { return v.re == 1.0 && v.im == 0.0; }
+
+template <typename T>
+static hipError_t launch_typed(const DeviceImage &img, int op, const void *x, void *y,
+                               const void *alpha_p, const void *beta_p, int strong_zero,
+                               hipStream_t stream) {
+    constexpr int L = 8;
+    const T alpha = load_scalar<T>(alpha_p, 1.0);
+    const T beta = load_scalar<T>(beta_p, 0.0);
+    const bool opT = (op != 0);
+    int flags = 0;
+    if (strong_zero) flags |= FLAG_STRONG_ZERO;
+    if (op == 2) flags |= FLAG_CONJ;
+    if (opT) flags |= FLAG_OPT;
+    const WaveWork *waves = (const WaveWork *)img.d_waves;
+    const Piece *pieces = (const Piece *)img.d_pieces;
+    const uint4 *values = (const uint4 *)img.d_values;
+    const int *rows = (const int *)img.d_rows;
+    const int *cols = (const int *)img.d_cols;
+    const T *xd = (const T *)x;
+    T *yd = (T *)y;
+    const dim3 block(256);
+
+    if (!opT && img.exclusive_fwd) {
+        // one launch: every y row has exactly one producer; beta is fused into its store and
+        // the rows no block covers are scaled by WORK_SCALE waves of the same grid.
+        flags |= FLAG_DIRECT;
+        if (img.nwg_total > 0)
+            hipLaunchKernelGGL((panel_kernel<T, L, true, false>), dim3((unsigned)img.nwg_total), block, 0,
+                               stream, waves, pieces, values, rows, cols, xd, yd, alpha, beta, flags);
+        return hipGetLastError();
+    }
+    // accumulate mode: y .*= beta over the owned range, then hardware atomics
+    const long long ylen = opT ? img.ncols : img.nrows;
+    long long lo = 0, hi = ylen;
+    if (!opT) {
+        lo = img.own_lo;
+        hi = img.own_hi;
+    }
+    if (hi > lo && (strong_zero || !is_one(beta))) {
+        long long nblk = (hi - lo + 255) / 256;
+        if (nblk > 2048) nblk = 2048;
+        hipLaunchKernelGGL((scale_kernel<T>), dim3((unsigned)nblk), block, 0, stream, yd, lo, hi, beta,
+                           strong_zero);
+    }
+    if (img.nwg_main > 0) {
+        const dim3 grid((unsigned)img.nwg_main);
+        if (!opT) {
+            if (img.has_off)
+                hipLaunchKernelGGL((panel_kernel<T, L, true, true>), grid, block, 0, stream, waves, pieces,
+                                   values, rows, cols, xd, yd, alpha, beta, flags);
+            else
+                hipLaunchKernelGGL((panel_kernel<T, L, true, false>), grid, block, 0, stream, waves, pieces,
+                                   values, rows, cols, xd, yd, alpha, beta, flags);
+        } else {
+            if (img.has_off)
+                hipLaunchKernelGGL((panel_kernel<T, L, true, true>), grid, block, 0, stream, waves, pieces,
+                                   values, rows, cols, xd, yd, alpha, beta, flags);
+            else
+                hipLaunchKernelGGL((panel_kernel<T, L, false, true>), grid, block, 0, stream, waves, pieces,
+                                   values, rows, cols, xd, yd, alpha, beta, flags);
+        }
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_mul(const DeviceImage &img, int op, const void *x, void *y, const void *alpha,
+                      const void *beta, int strong_zero, hipStream_t stream) {
+    switch (img.dtype) {
+        case 0: return launch_typed<float>(img, op, x, y, alpha, beta, strong_zero, stream);
+        case 1: return launch_typed<double>(img, op, x, y, alpha, beta, strong_zero, stream);
+        case 2: return launch_typed<c64>(img, op, x, y, alpha, beta, strong_zero, stream);
+        case 3: return launch_typed<c128>(img, op, x, y, alpha, beta, strong_zero, stream);
+    }
+    return hipErrorInvalidValue;
+}
+
+}  // namespace bsm

@@ -1,0 +1,611 @@
+"""Host-side mirror of the reference's operator surface for the mul! hot path.
+
+Same names, argument meaning and error behaviour as BlockSparseMatrices.jl:
+
+    BlockSparseMatrix(blocks, rowindices, colindices, size; scheduler, coloringalgorithm)
+        -- reference src/blockmatrix.jl:26-109
+    SymmetricBlockMatrix(diagonals, diagonalindices, offdiagonals, rowindices, colindices,
+                         size; scheduler)            -- src/symmetricblockmatrix.jl:33-126
+    VariableBlockCompressedRowStorage(matrices, rowindices, colindices, size; scheduler)
+    VariableBlockCompressedRowStorage(bsm | sbm)     -- src/vbcrs.jl:36-199
+    mul(y, A, x[, alpha, beta])  == LinearAlgebra.mul!   (LinearMaps._unsafe_mul!)
+    A @ x / A * x, transpose(A) / A.T, adjoint(A) / A.H  (LinearMaps wrappers, field .lmap)
+    nnz, size, eltype, block, eachblockindex, rowindices, colindices, colors, ...
+
+Julia conventions are kept on purpose so the parity tests read like the reference's tests:
+index lists are 1-BASED, blocks are column-major 2-D arrays.  Every product runs in
+libbsmrocm.so (HIP, gfx950); this module only marshals arguments.  x / y may be numpy
+arrays (host memory: the library stages them over PCIe) or torch CUDA tensors (device
+memory, enqueued on torch's current stream).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+try:  # torch is plumbing only (device memory, streams)
+    import torch
+except Exception:  # pragma: no cover
+    torch = None
+
+__all__ = [
+    "SerialScheduler", "DynamicScheduler", "isserial", "AbstractBlockMatrix", "BlockSparseMatrix",
+    "SymmetricBlockMatrix", "VariableBlockCompressedRowStorage", "TransposeMap", "AdjointMap",
+    "transpose", "adjoint", "mul", "MulPlan", "nnz", "size", "eltype", "scheduler", "block", "eachblockindex",
+    "rowindices", "colindices", "colors", "transposecolors", "diagonal", "offdiagonal",
+    "eachdiagonalindex", "eachoffdiagonalindex", "diagonalindices", "diagonalcolors",
+    "offdiagonalcolors", "transposeoffdiagonalcolors", "rowcolvals", "sparse",
+]
+
+_DT = {np.dtype(np.float32): L.BSM_F32, np.dtype(np.float64): L.BSM_F64,
+       np.dtype(np.complex64): L.BSM_C64, np.dtype(np.complex128): L.BSM_C128}
+
+
+# ---- schedulers (OhMyThreads names; reference src/BlockSparseMatrices.jl:12-18) --------------
+class SerialScheduler:
+    def __repr__(self):
+        return "SerialScheduler()"
+
+
+class DynamicScheduler:
+    def __repr__(self):
+        return "DynamicScheduler()"
+
+
+def isserial(s):
+    return isinstance(s, SerialScheduler)
+
+
+# ---- marshalling helpers -------------------------------------------------------------------------
+def _i64(a):
+    return np.ascontiguousarray(a, dtype=np.int64)
+
+
+def _ptrs(arrs):
+    out = (C.c_void_p * max(len(arrs), 1))()
+    for i, a in enumerate(arrs):
+        out[i] = a.ctypes.data
+    return out
+
+
+def _blocks_dtype(*blocklists):
+    dt = None
+    for bl in blocklists:
+        for b in bl:
+            d = np.asarray(b).dtype
+            dt = d if dt is None else np.promote_types(dt, d)
+    if dt is None:
+        dt = np.dtype(np.float64)
+    if dt not in _DT:
+        dt = np.promote_types(dt, np.float32) if dt.kind in "iub" else dt
+    if np.dtype(dt) not in _DT:
+        raise TypeError(f"unsupported block element type {dt}")
+    return np.dtype(dt)
+
+
+def _fblocks(blocks, dt):
+    out = []
+    for b in blocks:
+        a = np.asarray(b)
+        if a.ndim != 2:
+            raise ValueError("every block must be a 2-D array")
+        out.append(np.asfortranarray(a, dtype=dt))
+    return out
+
+
+def _options(scheduler, device, accumulate, own=None):
+    o = L.BsmOptions()
+    L.lib().bsm_options_default(C.byref(o))
+    o.scheduler = L.BSM_SCHED_SERIAL if isserial(scheduler) else L.BSM_SCHED_DYNAMIC
+    o.device = device
+    o.accumulate = {"auto": L.BSM_ACC_AUTO, "atomic": L.BSM_ACC_ATOMIC,
+                    "colored": L.BSM_ACC_COLORED}[accumulate]
+    if own is not None:
+        o.own_lo, o.own_hi = int(own[0]), int(own[1])
+    return o
+
+
+def _default_device():
+    """Current torch CUDA device when a GPU is visible, else analysis-only."""
+    if torch is not None and torch.cuda.is_available():
+        return torch.cuda.current_device()
+    return L.BSM_DEVICE_NONE
+
+
+def _scalar_buf(v, dt):
+    return np.asarray([v], dtype=dt)
+
+
+def _classes(flat):
+    out, p = [], 1
+    for _ in range(int(flat[0])):
+        n = int(flat[p])
+        out.append([int(v) for v in flat[p + 1:p + 1 + n]])
+        p += 1 + n
+    return out
+
+
+class _Handle:
+    """Owns a bsm_matrix_t; freed with the Python object (Julia side: a finalizer)."""
+
+    def __init__(self, ptr):
+        self.ptr = ptr
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                L.lib().bsm_destroy(self.ptr)
+                self.ptr = None
+        except Exception:
+            pass
+
+
+# ---- LinearMaps-style base ---------------------------------------------------------------------------
+class _LinearMap:
+    """The slice of LinearMaps.LinearMap the reference relies on (`*`, mul!, adjoint, transpose)."""
+
+    @property
+    def shape(self):
+        return size(self)
+
+    def __matmul__(self, x):
+        return _apply(self, x)
+
+    def __mul__(self, x):
+        return _apply(self, x)
+
+    @property
+    def T(self):
+        return transpose(self)
+
+    @property
+    def H(self):
+        return adjoint(self)
+
+    def __getitem__(self, key):
+        """A[:, :] -- LinearMaps materialises through products with unit vectors."""
+        if key != (slice(None), slice(None)):
+            raise IndexError("only A[:, :] is supported")
+        m, n = size(self)
+        dt = eltype(self)
+        out = np.zeros((m, n), dtype=dt, order="F")
+        e = np.zeros(n, dtype=dt)
+        y = np.zeros(m, dtype=dt)
+        for j in range(n):
+            e[j] = 1
+            mul(y, self, e)
+            out[:, j] = y
+            e[j] = 0
+        return out
+
+
+class AbstractBlockMatrix(_LinearMap):
+    """reference src/abstractblockmatrix.jl:13-62"""
+
+    def _finish(self, handle, dt, sz, sched):
+        self._h = _Handle(handle)
+        self.dtype = dt
+        self.size = (int(sz[0]), int(sz[1]))
+        self.scheduler = sched
+
+    def stats(self):
+        st = L.BsmStats()
+        L.check(L.lib().bsm_stats(self._h.ptr, C.byref(st)))
+        return {k: getattr(st, k) for k, _ in L.BsmStats._fields_ if k != "reserved"}
+
+    def _bookkeeping(self, which):
+        n = C.c_int64(0)
+        L.check(L.lib().bsm_get_bookkeeping(self._h.ptr, which, None, C.byref(n)))
+        out = np.zeros(max(n.value, 1), dtype=np.int64)
+        L.check(L.lib().bsm_get_bookkeeping(self._h.ptr, which,
+                                            out.ctypes.data_as(C.POINTER(C.c_int64)), C.byref(n)))
+        return out[:n.value]
+
+
+class TransposeMap(_LinearMap):
+    """LinearMaps.TransposeMap: lazy wrapper with field `.lmap`."""
+    _op = L.BSM_OP_T
+
+    def __init__(self, lmap):
+        self.lmap = lmap
+
+
+class AdjointMap(_LinearMap):
+    """LinearMaps.AdjointMap: lazy wrapper with field `.lmap`."""
+    _op = L.BSM_OP_C
+
+    def __init__(self, lmap):
+        self.lmap = lmap
+
+
+def transpose(A):
+    if isinstance(A, TransposeMap):
+        return A.lmap
+    if isinstance(A, AdjointMap):
+        raise NotImplementedError("transpose(A') (= conj(A)) is not wrapped")
+    return TransposeMap(A)
+
+
+def adjoint(A):
+    if isinstance(A, AdjointMap):
+        return A.lmap
+    if isinstance(A, TransposeMap):
+        raise NotImplementedError("adjoint(transpose(A)) (= conj(A)) is not wrapped")
+    return AdjointMap(A)
+
+
+def _unwrap(A):
+    if isinstance(A, (TransposeMap, AdjointMap)):
+        return A.lmap, A._op
+    return A, L.BSM_OP_N
+
+
+# ---- the three storage types ---------------------------------------------------------------------------
+class BlockSparseMatrix(AbstractBlockMatrix):
+    """reference src/blockmatrix.jl:26-109.  Fields: blocks, rowindices, colindices, size,
+    colors, transposecolors, scheduler."""
+
+    def __init__(self, blocks, rowindices, colindices, size, cols=None, *, scheduler=None,
+                 coloringalgorithm=None, device=None, accumulate="auto"):
+        if cols is not None:  # (blocks, rowindices, colindices, rows, cols) form, :81-89
+            size = (size, cols)
+        scheduler = SerialScheduler() if scheduler is None else scheduler
+        dt = _blocks_dtype(blocks)
+        self.blocks = _fblocks(blocks, dt)
+        self.rowindices = [_i64(r) for r in rowindices]
+        self.colindices = [_i64(c) for c in colindices]
+        nb = len(self.blocks)
+        if len(self.rowindices) != nb or len(self.colindices) != nb:
+            raise ValueError("blocks, rowindices and colindices must have equal lengths")
+        for b, r, c in zip(self.blocks, self.rowindices, self.colindices):
+            if b.shape != (len(r), len(c)):
+                raise ValueError("block shape does not match its index lists")
+        m = _i64([b.shape[0] for b in self.blocks])
+        n = _i64([b.shape[1] for b in self.blocks])
+        ld = _i64([max(b.shape[0], 1) for b in self.blocks])
+        dev = _default_device() if device is None else device
+        o = _options(scheduler, dev, accumulate)
+        h = C.c_void_p()
+        I = C.POINTER(C.c_int64)
+        L.check(L.lib().bsm_blocksparse_create(
+            _DT[dt], int(size[0]), int(size[1]), nb, _ptrs(self.blocks), m.ctypes.data_as(I),
+            n.ctypes.data_as(I), ld.ctypes.data_as(I), _ptrs(self.rowindices),
+            _ptrs(self.colindices), C.byref(o), C.byref(h)))
+        self._finish(h, dt, size, scheduler)
+        self.colors = _classes(self._bookkeeping(L.BSM_BK_COLORS))
+        self.transposecolors = _classes(self._bookkeeping(L.BSM_BK_TRANSPOSECOLORS))
+
+
+class SymmetricBlockMatrix(AbstractBlockMatrix):
+    """reference src/symmetricblockmatrix.jl:33-126.  The tuple-size constructor defaults to
+    DynamicScheduler() (:80)."""
+
+    def __init__(self, diagonals, diagonalindices, offdiagonals, rowindices, colindices, size,
+                 cols=None, *, scheduler=None, device=None, accumulate="auto"):
+        if cols is not None:  # rows, cols form defaults to SerialScheduler() (:102)
+            size = (size, cols)
+            scheduler = SerialScheduler() if scheduler is None else scheduler
+        scheduler = DynamicScheduler() if scheduler is None else scheduler
+        dt = _blocks_dtype(diagonals, offdiagonals)
+        self.diagonals = _fblocks(diagonals, dt)
+        self.diagonalindices = [_i64(d) for d in diagonalindices]
+        self.offdiagonals = _fblocks(offdiagonals, dt)
+        self.rowindices = [_i64(r) for r in rowindices]
+        self.colindices = [_i64(c) for c in colindices]
+        nd, no = len(self.diagonals), len(self.offdiagonals)
+        if len(self.diagonalindices) != nd or len(self.rowindices) != no or len(self.colindices) != no:
+            raise ValueError("block and index list counts differ")
+        for b, d in zip(self.diagonals, self.diagonalindices):
+            if b.shape != (len(d), len(d)):
+                raise ValueError("diagonal block shape does not match its index list")
+        for b, r, c in zip(self.offdiagonals, self.rowindices, self.colindices):
+            if b.shape != (len(r), len(c)):
+                raise ValueError("off-diagonal block shape does not match its index lists")
+        ds = _i64([b.shape[0] for b in self.diagonals])
+        dld = _i64([max(b.shape[0], 1) for b in self.diagonals])
+        m = _i64([b.shape[0] for b in self.offdiagonals])
+        n = _i64([b.shape[1] for b in self.offdiagonals])
+        ld = _i64([max(b.shape[0], 1) for b in self.offdiagonals])
+        dev = _default_device() if device is None else device
+        o = _options(scheduler, dev, accumulate)
+        h = C.c_void_p()
+        I = C.POINTER(C.c_int64)
+        L.check(L.lib().bsm_symmetric_create(
+            _DT[dt], int(size[0]), int(size[1]), nd, _ptrs(self.diagonals), ds.ctypes.data_as(I),
+            dld.ctypes.data_as(I), _ptrs(self.diagonalindices), no, _ptrs(self.offdiagonals),
+            m.ctypes.data_as(I), n.ctypes.data_as(I), ld.ctypes.data_as(I),
+            _ptrs(self.rowindices), _ptrs(self.colindices), C.byref(o), C.byref(h)))
+        self._finish(h, dt, size, scheduler)
+        self.offdiagonalcolors = _classes(self._bookkeeping(L.BSM_BK_COLORS))
+        self.transposeoffdiagonalcolors = _classes(self._bookkeeping(L.BSM_BK_TRANSPOSECOLORS))
+        self.diagonalcolors = _classes(self._bookkeeping(L.BSM_BK_DIAGONALCOLORS))
+
+
+class VariableBlockCompressedRowStorage(AbstractBlockMatrix):
+    """reference src/vbcrs.jl:36-199.  Fields: blocks (sorted), rowptr, colindices (per block),
+    rowindices (per block row), size, scheduler -- all 1-based like the reference."""
+
+    def __init__(self, matrices, rowindices=None, colindices=None, matrixsize=None, *,
+                 scheduler=None, device=None, accumulate="auto", own=None):
+        if isinstance(matrices, BlockSparseMatrix):  # src/vbcrs.jl:150-160
+            b = matrices
+            scheduler = b.scheduler if scheduler is None else scheduler
+            mats = b.blocks
+            rowindices = [int(r[0]) for r in b.rowindices]  # first(rowindices(b, i)), :203
+            colindices = [int(c[0]) for c in b.colindices]
+            matrixsize = b.size
+        elif isinstance(matrices, SymmetricBlockMatrix):  # src/vbcrs.jl:189-264
+            s = matrices
+            scheduler = s.scheduler if scheduler is None else scheduler
+            # [diagonals..., offdiagonals..., transpose(offdiagonals)...]  (:222-241)
+            mats = list(s.diagonals) + list(s.offdiagonals) + [o.T for o in s.offdiagonals]
+            rowindices = ([int(d[0]) for d in s.diagonalindices] + [int(r[0]) for r in s.rowindices]
+                          + [int(c[0]) for c in s.colindices])
+            colindices = ([int(d[0]) for d in s.diagonalindices] + [int(c[0]) for c in s.colindices]
+                          + [int(r[0]) for r in s.rowindices])
+            matrixsize = s.size
+        else:
+            mats = matrices
+        scheduler = SerialScheduler() if scheduler is None else scheduler
+        if len(mats) < 1:
+            raise IndexError("VariableBlockCompressedRowStorage needs at least one block")  # :81
+        dt = _blocks_dtype(mats)
+        fb = _fblocks(mats, dt)
+        rs, cs = _i64(rowindices), _i64(colindices)
+        if len(rs) != len(fb) or len(cs) != len(fb):
+            raise ValueError("matrices, rowindices and colindices must have equal lengths")
+        m = _i64([b.shape[0] for b in fb])
+        n = _i64([b.shape[1] for b in fb])
+        ld = _i64([max(b.shape[0], 1) for b in fb])
+        dev = _default_device() if device is None else device
+        o = _options(scheduler, dev, accumulate, own)
+        h = C.c_void_p()
+        I = C.POINTER(C.c_int64)
+        L.check(L.lib().bsm_vbcrs_create(
+            _DT[dt], int(matrixsize[0]), int(matrixsize[1]), len(fb), _ptrs(fb),
+            m.ctypes.data_as(I), n.ctypes.data_as(I), ld.ctypes.data_as(I), rs.ctypes.data_as(I),
+            cs.ctypes.data_as(I), C.byref(o), C.byref(h)))
+        self._finish(h, dt, matrixsize, scheduler)
+        self.perm = self._bookkeeping(L.BSM_BK_VBCRS_PERM).copy()
+        self.rowptr = self._bookkeeping(L.BSM_BK_VBCRS_ROWPTR).copy()
+        self.colindices = self._bookkeeping(L.BSM_BK_VBCRS_COLINDICES).copy()
+        self.rowindices = self._bookkeeping(L.BSM_BK_VBCRS_ROWINDICES).copy()
+        self.blocks = [fb[p - 1] for p in self.perm]
+
+
+# ---- mul! ------------------------------------------------------------------------------------------------
+def _vec_info(v, dt, n, name):
+    """-> (pointer, memspace, stream, keepalive)"""
+    if torch is not None and isinstance(v, torch.Tensor):
+        if v.dim() != 1 or v.numel() != n:
+            raise ValueError(f"DimensionMismatch: {name} has length {tuple(v.shape)}, expected {n}")
+        tdt = {np.dtype(np.float32): torch.float32, np.dtype(np.float64): torch.float64,
+               np.dtype(np.complex64): torch.complex64, np.dtype(np.complex128): torch.complex128}[dt]
+        if v.dtype != tdt or not v.is_contiguous():
+            raise TypeError(f"{name} must be a contiguous {tdt} tensor")
+        if v.is_cuda:
+            return v.data_ptr(), L.BSM_MEM_DEVICE, torch.cuda.current_stream(v.device).cuda_stream, v
+        a = v.numpy()
+        return a.ctypes.data, L.BSM_MEM_HOST, None, a
+    if not isinstance(v, np.ndarray):
+        raise TypeError(f"{name} must be a numpy array or a torch tensor")
+    if v.ndim != 1 or v.shape[0] != n:
+        raise ValueError(f"DimensionMismatch: {name} has shape {v.shape}, expected ({n},)")
+    if v.dtype != dt or not v.flags.c_contiguous:
+        raise TypeError(f"{name} must be a contiguous {dt} array")
+    return v.ctypes.data, L.BSM_MEM_HOST, None, v
+
+
+def mul(y, A, x, alpha=True, beta=False):
+    """LinearAlgebra.mul!(y, A, x, alpha, beta): y = alpha*A*x + beta*y, returns y.
+
+    `beta is False` (the 3-argument form, reference src/abstractblockmatrix.jl:27-34) is Julia's
+    strong zero: y is overwritten, NaN/Inf in the incoming y do not propagate.  A numeric 0.0
+    multiplies.  Dimension checks mirror LinearMaps' check_dim_mul (DimensionMismatch)."""
+    base, op = _unwrap(A)
+    if not isinstance(base, AbstractBlockMatrix):
+        raise TypeError("A must be a block matrix or its transpose/adjoint wrapper")
+    dt = base.dtype
+    nr, nc = base.size
+    ylen, xlen = (nr, nc) if op == L.BSM_OP_N else (nc, nr)
+    if dt.kind != "c" and (np.iscomplexobj(alpha) or np.iscomplexobj(beta)):
+        raise TypeError("complex alpha/beta with a real matrix is not supported on the GPU path")
+    xp, xms, xst, _kx = _vec_info(x, dt, xlen, "x")
+    yp, yms, yst, _ky = _vec_info(y, dt, ylen, "y")
+    if xms != yms:
+        raise ValueError("x and y must live in the same memory space")
+    strong = beta is False
+    a = _scalar_buf(1 if alpha is True else alpha, dt)
+    b = _scalar_buf(0 if strong else (1 if beta is True else beta), dt)
+    L.check(L.lib().bsm_mul(base._h.ptr, op, xp, yp, a.ctypes.data, b.ctypes.data,
+                            1 if strong else 0, xms, yst if yst is not None else None))
+    return y
+
+
+class MulPlan:
+    """Pre-marshalled mul!(y, A, x, alpha, beta) for device-resident x / y: `plan()` is one
+    ctypes call into bsm_mul (no per-call Python marshalling), enqueued on the CURRENT torch
+    stream -- what a Julia caller gets from `ccall` directly.  Graph-capturable."""
+
+    def __init__(self, y, A, x, alpha=True, beta=False):
+        base, op = _unwrap(A)
+        dt = base.dtype
+        nr, nc = base.size
+        ylen, xlen = (nr, nc) if op == L.BSM_OP_N else (nc, nr)
+        xp, xms, _, self._kx = _vec_info(x, dt, xlen, "x")
+        yp, yms, _, self._ky = _vec_info(y, dt, ylen, "y")
+        if xms != L.BSM_MEM_DEVICE or yms != L.BSM_MEM_DEVICE:
+            raise ValueError("MulPlan needs device-resident x and y")
+        strong = beta is False
+        self._a = _scalar_buf(1 if alpha is True else alpha, dt)
+        self._b = _scalar_buf(0 if strong else (1 if beta is True else beta), dt)
+        self._base = base
+        self._fn = L.lib().bsm_mul
+        self._dev = y.device
+        self._args = [C.c_void_p(base._h.ptr), C.c_int(op), C.c_void_p(xp), C.c_void_p(yp),
+                      C.c_void_p(self._a.ctypes.data), C.c_void_p(self._b.ctypes.data),
+                      C.c_int(1 if strong else 0), C.c_int(L.BSM_MEM_DEVICE)]
+
+    def __call__(self):
+        rc = self._fn(*self._args, C.c_void_p(torch.cuda.current_stream(self._dev).cuda_stream))
+        if rc:
+            L.check(rc)
+
+
+def _apply(A, x):
+    """A * x: allocates y like LinearMaps does (similar(x, ...), uninitialised) then mul!."""
+    m, _ = size(A)
+    if torch is not None and isinstance(x, torch.Tensor):
+        y = torch.empty(m, dtype=x.dtype, device=x.device)
+    else:
+        x = np.ascontiguousarray(x, dtype=eltype(A))
+        y = np.empty(m, dtype=x.dtype)
+    return mul(y, A, x)
+
+
+# ---- accessors (reference names) ---------------------------------------------------------------------------
+def size(A, dim=None):
+    base, op = _unwrap(A)
+    s = base.size if op == L.BSM_OP_N else (base.size[1], base.size[0])
+    return s if dim is None else s[dim - 1]
+
+
+def eltype(A):
+    return _unwrap(A)[0].dtype
+
+
+def scheduler(A):  # src/abstractblockmatrix.jl:50-62
+    return _unwrap(A)[0].scheduler
+
+
+def _wrapblock(b, op):
+    if op == L.BSM_OP_T:
+        return b.T
+    if op == L.BSM_OP_C:
+        return b.conj().T
+    return b
+
+
+def eachblockindex(A):  # src/blockmatrix.jl:124-134
+    return range(1, len(_unwrap(A)[0].blocks) + 1)
+
+
+def block(A, i):  # src/blockmatrix.jl:150-160
+    base, op = _unwrap(A)
+    return _wrapblock(base.blocks[i - 1], op)
+
+
+def rowindices(A, i):  # src/symmetricblockmatrix.jl:341-352
+    base, op = _unwrap(A)
+    return (base.rowindices if op == L.BSM_OP_N else base.colindices)[i - 1]
+
+
+def colindices(A, i):  # src/symmetricblockmatrix.jl:354-365
+    base, op = _unwrap(A)
+    return (base.colindices if op == L.BSM_OP_N else base.rowindices)[i - 1]
+
+
+def colors(A):  # src/blockmatrix.jl:177-206
+    base, op = _unwrap(A)
+    return base.colors if op == L.BSM_OP_N else base.transposecolors
+
+
+def transposecolors(A):
+    base, op = _unwrap(A)
+    return base.transposecolors if op == L.BSM_OP_N else base.colors
+
+
+def eachoffdiagonalindex(A):
+    return range(1, len(_unwrap(A)[0].offdiagonals) + 1)
+
+
+def eachdiagonalindex(A):
+    return range(1, len(_unwrap(A)[0].diagonals) + 1)
+
+
+def offdiagonal(A, i):  # src/symmetricblockmatrix.jl:199-237
+    base, op = _unwrap(A)
+    return _wrapblock(base.offdiagonals[i - 1], op)
+
+
+def diagonal(A, i):
+    base, op = _unwrap(A)
+    return _wrapblock(base.diagonals[i - 1], op)
+
+
+def diagonalindices(A, i):  # src/symmetricblockmatrix.jl:327-339
+    return _unwrap(A)[0].diagonalindices[i - 1]
+
+
+def diagonalcolors(A):
+    return _unwrap(A)[0].diagonalcolors
+
+
+def offdiagonalcolors(A):  # swaps for wrappers, src/symmetricblockmatrix.jl:307-325
+    base, op = _unwrap(A)
+    return base.offdiagonalcolors if op == L.BSM_OP_N else base.transposeoffdiagonalcolors
+
+
+def transposeoffdiagonalcolors(A):
+    base, op = _unwrap(A)
+    return base.transposeoffdiagonalcolors if op == L.BSM_OP_N else base.offdiagonalcolors
+
+
+def nnz(A):
+    """SparseArrays.nnz -- src/blockmatrix.jl:208-223, src/symmetricblockmatrix.jl:367-384
+    (off-diagonal blocks count twice), src/vbcrs.jl:290-296."""
+    return int(_unwrap(A)[0].stats()["nnz"])
+
+
+# ---- conversion used by the reference's tests as their oracle (host utility, not the hot path) ----
+def rowcolvals(A):
+    """(rows, cols, vals), 1-based -- reference src/sparse.jl:17-123."""
+    base, op = _unwrap(A)
+    rows, cols, vals = [], [], []
+
+    def push(b, ri, ci):  # _pushblocktoarrays!, src/sparse.jl:131-139 (row-major enumeration)
+        R, Cc = np.meshgrid(np.asarray(ri), np.asarray(ci), indexing="ij")
+        rows.append(R.ravel())
+        cols.append(Cc.ravel())
+        vals.append(np.asarray(b).ravel())
+
+    if isinstance(base, BlockSparseMatrix):
+        for col in colors(A):
+            for bid in col:
+                push(block(A, bid), rowindices(A, bid), colindices(A, bid))
+    elif isinstance(base, SymmetricBlockMatrix):
+        for col in offdiagonalcolors(A):
+            for bid in col:
+                push(offdiagonal(A, bid), rowindices(A, bid), colindices(A, bid))
+        for col in transposeoffdiagonalcolors(A):
+            for bid in col:
+                push(offdiagonal(A, bid).T, colindices(A, bid), rowindices(A, bid))
+        for col in diagonalcolors(A):
+            for bid in col:
+                push(diagonal(A, bid), diagonalindices(A, bid), diagonalindices(A, bid))
+    elif isinstance(base, VariableBlockCompressedRowStorage):
+        if op != L.BSM_OP_N:
+            raise NotImplementedError("rowcolvals of a wrapped VBCRS (the reference has none either)")
+        for br in range(len(base.rowptr) - 1):
+            for bi in range(base.rowptr[br], base.rowptr[br + 1]):
+                b = base.blocks[bi - 1]
+                r0, c0 = base.rowindices[br], base.colindices[bi - 1]
+                R, Cc = np.meshgrid(np.arange(r0, r0 + b.shape[0]), np.arange(c0, c0 + b.shape[1]),
+                                    indexing="ij")
+                rows.append(R.ravel(order="F"))
+                cols.append(Cc.ravel(order="F"))
+                vals.append(b.ravel(order="F"))
+    else:
+        raise TypeError("not a block matrix")
+    if not rows:
+        z = np.zeros(0, np.int64)
+        return z, z, np.zeros(0, base.dtype)
+    return np.concatenate(rows), np.concatenate(cols), np.concatenate(vals)
+
+
+def sparse(A):
+    """SparseArrays.sparse(A) -> scipy.sparse.csc_matrix (duplicates summed) -- src/sparse.jl:127-129."""
+    import scipy.sparse as sp
+    r, c, v = rowcolvals(A)
+    return sp.coo_matrix((v, (r - 1, c - 1)), shape=size(A)).tocsc()

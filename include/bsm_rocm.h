@@ -1,0 +1,172 @@
+/* bsm_rocm.h -- C ABI of libbsmrocm.so: the MI355X (gfx950) block-sparse mat-vec engine.
+ *
+ * Drop-in boundary for ONE hot path of djukic14/BlockSparseMatrices.jl: the
+ * `LinearMaps._unsafe_mul!(y, A, x[, alpha, beta])` methods of its three storage types
+ * (and their Adjoint/Transpose wrappers) plus the constructors that feed them.
+ * The reference is pure Julia and has no FFI; a Julia maintainer binds these entry
+ * points with `ccall` from methods of the same names (INTEGRATION.md shows the stub).
+ *
+ * Conventions (chosen so a Julia caller passes its data untouched):
+ *   - every index is 1-BASED int64 (Julia Int);
+ *   - a block is a column-major m x n array with leading dimension ld (a Julia Matrix);
+ *   - `blocks` is an array of nblocks pointers (pointer.(blocks) of a Vector{Matrix});
+ *   - *_create COPIES everything into library-owned device memory (repacked for
+ *     coalesced 16-byte lane loads); the caller may free its arrays afterwards;
+ *   - all functions return 0 on success, a negative bsm_status otherwise, never throw;
+ *     bsm_last_error() returns a thread-local message for the last failure;
+ *   - a handle is immutable after creation: concurrent bsm_mul calls with distinct y
+ *     (and distinct streams) are legal.
+ */
+#ifndef BSM_ROCM_H
+#define BSM_ROCM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct bsm_matrix_s *bsm_matrix_t;
+
+typedef enum {
+    BSM_OK = 0,
+    BSM_ERR_INVALID = -1,   /* bad argument (null pointer, negative size, index out of range) */
+    BSM_ERR_UNSUPPORTED = -2,
+    BSM_ERR_DEVICE = -3,    /* HIP runtime error, or no device image (analysis-only handle) */
+    BSM_ERR_ALLOC = -4
+} bsm_status;
+
+/* element type T of blocks, x, y, alpha, beta */
+typedef enum { BSM_F32 = 0, BSM_F64 = 1, BSM_C64 = 2, BSM_C128 = 3 } bsm_dtype;
+
+/* which operator of A is applied: A, transpose(A), A' -- the reference's
+ * LinearMaps.TransposeMap / AdjointMap wrappers (src/blockmatrix.jl:154-160,200-206,
+ * src/symmetricblockmatrix.jl:345-365, src/vbcrs.jl:298-354) */
+typedef enum { BSM_OP_N = 0, BSM_OP_T = 1, BSM_OP_C = 2 } bsm_op;
+
+/* where x and y live */
+typedef enum { BSM_MEM_HOST = 0, BSM_MEM_DEVICE = 1 } bsm_memspace;
+
+/* reference `scheduler=` keyword: SerialScheduler() gives the single colour
+ * [1:nblocks] (src/blockmatrix.jl:91-92), anything else colours the blocks
+ * (src/blockmatrix.jl:94-98, src/symmetricblockmatrix.jl:104-110) */
+typedef enum { BSM_SCHED_SERIAL = 0, BSM_SCHED_DYNAMIC = 1 } bsm_scheduler;
+
+/* how contributions of different blocks to the same y entries are combined on the GPU */
+typedef enum {
+    BSM_ACC_AUTO = 0,    /* exclusive direct stores when provably conflict-free, else atomics */
+    BSM_ACC_ATOMIC = 1,  /* hardware fp atomics into y, blocks ordered by colour class */
+    BSM_ACC_COLORED = 2  /* one launch per colour class, plain read-modify-write: bitwise
+                            reproducible run to run (the reference's own scheme) */
+} bsm_accumulate;
+
+#define BSM_DEVICE_CURRENT (-1)
+#define BSM_DEVICE_NONE (-2) /* analysis only: bookkeeping queries work, bsm_mul fails */
+
+typedef struct {
+    int32_t struct_size; /* = sizeof(bsm_options) */
+    int32_t device;      /* HIP ordinal, BSM_DEVICE_CURRENT or BSM_DEVICE_NONE */
+    int32_t scheduler;   /* bsm_scheduler */
+    int32_t accumulate;  /* bsm_accumulate */
+    int32_t validate;    /* 1: range-check every index at create time (default 1) */
+    int32_t reserved0;
+    /* rows of y this handle is responsible for scaling by beta (1-based, inclusive);
+     * 0,0 = all rows.  Used when block rows are partitioned over several GPUs. */
+    int64_t own_lo, own_hi;
+    int64_t reserved[4];
+} bsm_options;
+
+/* fills *o with defaults (device = current, serial scheduler, auto accumulate, validate) */
+void bsm_options_default(bsm_options *o);
+
+/* VariableBlockCompressedRowStorage(matrices, rowindices, colindices, size; scheduler)
+ * -- reference src/vbcrs.jl:78-122.  rowstart/colstart: first row/column of each block
+ * (1-based), blocks in any order; the library sorts them exactly as the reference does
+ * (stable by (rowstart, colstart)) and builds rowptr.  nblocks >= 1. */
+int bsm_vbcrs_create(int dtype, int64_t nrows, int64_t ncols, int64_t nblocks,
+                     const void *const *blocks, const int64_t *m, const int64_t *n,
+                     const int64_t *ld, const int64_t *rowstart, const int64_t *colstart,
+                     const bsm_options *opts, bsm_matrix_t *out);
+
+/* BlockSparseMatrix(blocks, rowindices, colindices, size; scheduler, coloringalgorithm)
+ * -- reference src/blockmatrix.jl:62-109.  rowidx[b] has m[b] entries, colidx[b] n[b]. */
+int bsm_blocksparse_create(int dtype, int64_t nrows, int64_t ncols, int64_t nblocks,
+                           const void *const *blocks, const int64_t *m, const int64_t *n,
+                           const int64_t *ld, const int64_t *const *rowidx,
+                           const int64_t *const *colidx, const bsm_options *opts,
+                           bsm_matrix_t *out);
+
+/* SymmetricBlockMatrix(diagonals, diagonalindices, offdiagonals, rowindices, colindices,
+ * size; scheduler) -- reference src/symmetricblockmatrix.jl:73-126.  Diagonal block d is
+ * dsize[d] x dsize[d] on index list diagidx[d]; only one triangle of the off-diagonal
+ * blocks is passed, the product applies each of them and its transpose. */
+int bsm_symmetric_create(int dtype, int64_t nrows, int64_t ncols, int64_t ndiag,
+                         const void *const *diag, const int64_t *dsize, const int64_t *dld,
+                         const int64_t *const *diagidx, int64_t noff, const void *const *off,
+                         const int64_t *m, const int64_t *n, const int64_t *ld,
+                         const int64_t *const *rowidx, const int64_t *const *colidx,
+                         const bsm_options *opts, bsm_matrix_t *out);
+
+/* y = alpha * op(A) * x + beta * y  -- LinearMaps._unsafe_mul!(y, A, x, alpha, beta):
+ * reference src/blockmatrix.jl:225-247, src/symmetricblockmatrix.jl:386-435,
+ * src/vbcrs.jl:266-288 (forward), :303-354 (adjoint/transpose).
+ *   alpha, beta : pointers to one T each (host memory); NULL = 1 resp. 0.
+ *   beta_strong_zero != 0 : beta is Julia's Bool `false` (the 3-arg form,
+ *     src/abstractblockmatrix.jl:27-34): y is OVERWRITTEN, NaN/Inf in the incoming y do
+ *     not propagate.  With beta_strong_zero == 0 a numeric beta = 0 multiplies.
+ *   memspace BSM_MEM_DEVICE: x, y are device pointers valid on the handle's device; the
+ *     call only enqueues work on `stream` (a hipStream_t, NULL = default stream) and
+ *     returns; no allocation or synchronisation happens, so it can be graph-captured.
+ *   memspace BSM_MEM_HOST: x, y are host arrays; the library stages them through device
+ *     buffers and returns when y is complete.
+ * x has size(op(A),2) entries, y size(op(A),1); they must not alias. */
+int bsm_mul(bsm_matrix_t A, int op, const void *x, void *y, const void *alpha,
+            const void *beta, int beta_strong_zero, int memspace, void *stream);
+
+/* Bookkeeping queries (bit-exact contract; every value 1-based int64 like the reference).
+ * Call with out == NULL to obtain the required length in *len. */
+typedef enum {
+    BSM_BK_VBCRS_PERM = 0,        /* sortperm of src/vbcrs.jl:84 */
+    BSM_BK_VBCRS_ROWPTR = 1,      /* src/vbcrs.jl:97-117, length nblockrows+1 */
+    BSM_BK_VBCRS_COLINDICES = 2,  /* per block, sorted order */
+    BSM_BK_VBCRS_ROWINDICES = 3,  /* per block ROW */
+    /* colour sets, flattened as [ncolors, len_1, ids_1..., len_2, ids_2..., ...] */
+    BSM_BK_COLORS = 4,            /* BlockSparseMatrix.colors / Symmetric offdiagonalcolors */
+    BSM_BK_TRANSPOSECOLORS = 5,   /* transposecolors / transposeoffdiagonalcolors */
+    BSM_BK_DIAGONALCOLORS = 6     /* Symmetric diagonalcolors */
+} bsm_bookkeeping;
+int bsm_get_bookkeeping(bsm_matrix_t A, int which, int64_t *out, int64_t *len);
+
+/* Statistics of a handle. */
+typedef struct {
+    int64_t nnz;            /* SparseArrays.nnz as the reference defines it (off-diagonal
+                               blocks of a SymmetricBlockMatrix count twice,
+                               src/symmetricblockmatrix.jl:367-384) */
+    int64_t stored_entries; /* matrix entries held on the device (each stored once) */
+    int64_t alg_bytes;      /* algorithmic bytes of one mul with beta = 0 */
+    int64_t device_bytes;   /* bytes of the packed device image (values + metadata) */
+    int64_t npanels, ntasks, nworkgroups;
+    int64_t exclusive;      /* 1: forward product needs no atomics and no pre-scale pass */
+    int64_t reserved[8];
+} bsm_stats_t;
+int bsm_stats(bsm_matrix_t A, bsm_stats_t *out);
+
+/* Debug / test hook: copies one array of the packed device image (host copy) out.
+ * which: 0 values (bytes), 1 rows (int32), 2 cols (int32), 3 pieces (32-byte records),
+ * 4 waves (64-byte records; layout in blocksparsematrices.jl_amd/csrc/bsm_layout.h).
+ * Only available on analysis-only handles (BSM_DEVICE_NONE), which keep the host copy.
+ * Call with out == NULL to obtain the size in bytes. */
+int bsm_get_image(bsm_matrix_t A, int which, void *out, int64_t *nbytes);
+
+int bsm_destroy(bsm_matrix_t A);
+
+/* thread-local message of the last failing call in this thread ("" if none) */
+const char *bsm_last_error(void);
+
+/* library / build identification, e.g. "bsmrocm 0.1 gfx950" */
+const char *bsm_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BSM_ROCM_H */

@@ -1,0 +1,237 @@
+"""Shared test helpers: fixture reader, oracle drivers, and a numpy interpreter of the packed
+device image (so the host analysis is checked on CPU, without a GPU).  Test code only."""
+import ctypes as C
+import os
+import struct
+
+import numpy as np
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+N, T, Cc = 0, 1, 2  # ops
+
+
+def read_fixture(key):
+    """tests/golden/symmetric_<key>.bin (decoded from the reference's
+    test/assets/symmetricblockexamples.jld2 by tests/golden/decode_jld2.c) ->
+    (diagonalblocks, selfindices, offblocks, testindices, trialindices), ComplexF64, 1-based."""
+    b = open(os.path.join(GOLDEN, f"symmetric_{key}.bin"), "rb").read()
+    assert b[:8] == b"BSMFIX01"
+    off = 8
+
+    def i64():
+        nonlocal off
+        v = struct.unpack_from("<q", b, off)[0]
+        off += 8
+        return v
+
+    fields = []
+    for ismat in (1, 0, 1, 0, 0):
+        items = []
+        for _ in range(i64()):
+            if ismat:
+                m, n = i64(), i64()
+                a = np.frombuffer(b, dtype="<c16", count=m * n, offset=off).reshape((m, n), order="F")
+                off += 16 * m * n
+            else:
+                ln = i64()
+                a = np.frombuffer(b, dtype="<i8", count=ln, offset=off)
+                off += 8 * ln
+            items.append(a.copy())
+        fields.append(items)
+    assert off == len(b)
+    return fields
+
+
+def fixture_problem(key, dtype=np.complex128, part="full"):
+    d, si, o, ti, tr = read_fixture(key)
+    if part == "real":
+        d, o = [x.real for x in d], [x.real for x in o]
+    elif part == "imag":
+        d, o = [x.imag for x in d], [x.imag for x in o]
+    d = [np.asfortranarray(x, dtype=dtype) for x in d]
+    o = [np.asfortranarray(x, dtype=dtype) for x in o]
+    n = max(max(int(i.max()) for i in ti), max(int(i.max()) for i in tr), max(int(i.max()) for i in si))
+    return dict(kind="symmetric", diagonals=d, diagonalindices=si, offdiagonals=o, rowindices=ti,
+                colindices=tr, size=(n, n))
+
+
+def fixture_as_blocksparse(key, dtype=np.complex128, part="full"):
+    """The fixture's off-diagonal panels as a plain BlockSparseMatrix (the missing
+    blockexamples.jld2 has the same character: unsorted, non-contiguous lists)."""
+    p = fixture_problem(key, dtype, part)
+    return dict(kind="blocksparse", blocks=p["offdiagonals"], rowindices=p["rowindices"],
+                colindices=p["colindices"], size=p["size"])
+
+
+def rand_vec(rng, n, dtype):
+    dtype = np.dtype(dtype)
+    v = rng.standard_normal(n)
+    if dtype.kind == "c":
+        v = v + 1j * rng.standard_normal(n)
+    return v.astype(dtype)
+
+
+def relerr(a, b):
+    """the reference's own norm: max|a-b| / max|b|  (test/test_vbcrs.jl:35)"""
+    if len(b) == 0:
+        return 0.0
+    den = float(np.max(np.abs(b)))
+    if den == 0:
+        den = 1.0
+    return float(np.max(np.abs(a - b)) / den)
+
+
+def single_color(n):
+    return [list(range(1, n + 1))]
+
+
+def oracle_mul(orc, problem, op, x, y0, alpha=1, beta=0, strong=True, colorsets=None):
+    """y = alpha*op(A)*x + beta*y0 through the CPU oracle (reference loop structure)."""
+    y = np.array(y0, copy=True)
+    k = problem["kind"]
+    if k == "blocksparse":
+        nb = len(problem["blocks"])
+        cs = colorsets if colorsets is not None else (single_color(nb), single_color(nb))
+        return orc.bsm_mul(op, problem["blocks"], problem["rowindices"], problem["colindices"],
+                           cs[0] if op == N else cs[1], x, y, alpha, beta, strong)
+    if k == "symmetric":
+        nd, no = len(problem["diagonals"]), len(problem["offdiagonals"])
+        cs = colorsets if colorsets is not None else (single_color(no), single_color(no), single_color(nd))
+        return orc.sym_mul(op, problem["diagonals"], problem["diagonalindices"], problem["offdiagonals"],
+                           problem["rowindices"], problem["colindices"], cs, x, y, alpha, beta, strong)
+    if k == "vbcrs":
+        perm, rowptr, colind, rowind = orc.vbcrs_build(problem["rowstart"], problem["colstart"])
+        blocks = [problem["blocks"][p - 1] for p in perm]
+        return orc.vbcrs_mul(op, blocks, rowptr, colind, rowind, x, y, alpha, beta, strong)
+    raise ValueError(k)
+
+
+def coo_of(problem):
+    """independent COO triples (1-based), the reference's test-oracle path (src/sparse.jl)."""
+    rows, cols, vals = [], [], []
+
+    def push(b, ri, ci):
+        R, K = np.meshgrid(np.asarray(ri), np.asarray(ci), indexing="ij")
+        rows.append(R.ravel())
+        cols.append(K.ravel())
+        vals.append(np.asarray(b).ravel())
+
+    k = problem["kind"]
+    if k == "blocksparse":
+        for b, r, c in zip(problem["blocks"], problem["rowindices"], problem["colindices"]):
+            push(b, r, c)
+    elif k == "symmetric":
+        for b, d in zip(problem["diagonals"], problem["diagonalindices"]):
+            push(b, d, d)
+        for b, r, c in zip(problem["offdiagonals"], problem["rowindices"], problem["colindices"]):
+            push(b, r, c)
+            push(b.T, c, r)
+    else:
+        for b, r0, c0 in zip(problem["blocks"], problem["rowstart"], problem["colstart"]):
+            push(b, np.arange(r0, r0 + b.shape[0]), np.arange(c0, c0 + b.shape[1]))
+    if not rows:
+        return np.zeros(0, np.int64), np.zeros(0, np.int64), np.zeros(0)
+    return np.concatenate(rows), np.concatenate(cols), np.concatenate(vals)
+
+
+def scipy_mul(problem, op, x, y0, alpha=1, beta=0, strong=True):
+    """scipy.sparse as an independent checker (never the oracle, never shipped)."""
+    import scipy.sparse as sp
+    r, c, v = coo_of(problem)
+    S = sp.coo_matrix((v, (r - 1, c - 1)), shape=problem["size"]).tocsr()
+    if op == T:
+        S = S.T
+    elif op == Cc:
+        S = S.conj().T
+    base = np.zeros_like(y0) if strong else beta * y0
+    return alpha * (S @ x) + base
+
+
+# ---- packed-image interpreter -------------------------------------------------------------------
+PIECE_DT = np.dtype([("val_off", "<u8"), ("xbase", "<i4"), ("col_off", "<i4"), ("nstrips", "<i4"),
+                     ("ncols", "<i4"), ("kind", "<i4"), ("pad", "<i4")])
+WAVE_DT = np.dtype([("piece_begin", "<i4"), ("npieces", "<i4"), ("row_off", "<i4"), ("rbase", "<i4"),
+                    ("m", "<u2"), ("work", "u1"), ("grp", "u1"), ("lead", "u1"), ("pad0", "u1", 3),
+                    ("pad1", "<i4", 2), ("first", PIECE_DT)])
+assert PIECE_DT.itemsize == 32 and WAVE_DT.itemsize == 64
+WORK_NOP, WORK_PANEL, WORK_SCALE = 0, 1, 2
+KIND_OFF = 2
+
+
+def get_image(A):
+    from bsm_amd import _lib as L
+    out = []
+    for which, dt in ((0, np.uint8), (1, np.int32), (2, np.int32), (3, PIECE_DT), (4, WAVE_DT)):
+        n = C.c_int64(0)
+        L.check(L.lib().bsm_get_image(A._h.ptr, which, None, C.byref(n)))
+        buf = np.zeros(max(n.value, 1), dtype=np.uint8)
+        L.check(L.lib().bsm_get_image(A._h.ptr, which, buf.ctypes.data, C.byref(n)))
+        out.append(buf[:n.value].view(dt))
+    return out
+
+
+def interpret_image(A, op, x, y0, alpha=1, beta=0, strong=True):
+    """Executes the packed image the way the HIP kernel walks it (same descriptors and index
+    arithmetic, numpy arithmetic) -- checks packing + schedule on CPU."""
+    values, rows, cols, pieces, waves = get_image(A)
+    dt = A.dtype
+    E = 16 // dt.itemsize
+    vals = values.view(dt)
+    st = A.stats()
+    opT = op != N
+    conj = op == Cc
+    direct = (not opT) and st["exclusive"] == 1
+    y = np.array(y0, copy=True)
+    if not direct:
+        y[:] = 0 if strong else beta * y
+    assert len(waves) % 4 == 0
+    pw = waves[waves["work"] == WORK_PANEL]
+    has_off = bool(np.any(pw["first"]["kind"][pw["npieces"] > 0] == KIND_OFF) or
+                   np.any((pieces["kind"] == KIND_OFF) & (pieces["nstrips"] > 0)))
+    fwd_kernel = (not opT) or has_off  # the launcher's choice of the FWD template flag
+    for wg in range(len(waves) // 4):
+        us = [None] * 4
+        for w in range(4):
+            W = waves[wg * 4 + w]
+            if W["work"] == WORK_SCALE:
+                if direct:
+                    r0, cnt = int(W["rbase"]), int(W["first"]["ncols"])
+                    y[r0:r0 + cnt] = 0 if strong else beta * y[r0:r0 + cnt]
+                continue
+            if W["work"] != WORK_PANEL:
+                continue
+            m = int(W["m"])
+            ridx = (np.arange(W["rbase"], W["rbase"] + m) if W["rbase"] >= 0
+                    else rows[W["row_off"]:W["row_off"] + m])
+            u = np.zeros(m, dtype=dt)
+            for pi in range(int(W["npieces"])):
+                P = W["first"] if pi == 0 else pieces[W["piece_begin"] + pi - 1]
+                ns, nc = int(P["nstrips"]), int(P["ncols"])
+                base = int(P["val_off"]) * 16 // dt.itemsize
+                full = vals[base:base + ns * m * E].reshape(ns, m, E).transpose(1, 0, 2).reshape(m, ns * E)
+                B = full[:, :nc]
+                assert not np.any(full[:, nc:]), "strip padding must be zero"
+                if conj:
+                    B = B.conj()
+                cidx = (np.arange(P["xbase"], P["xbase"] + nc) if P["xbase"] >= 0
+                        else cols[P["col_off"]:P["col_off"] + nc])
+                kind = int(P["kind"])
+                if (not opT) or kind == KIND_OFF:
+                    u += B @ x[cidx]
+                if opT or kind == KIND_OFF:
+                    np.add.at(y, cidx, alpha * (B.T @ x[ridx]))
+            us[w] = (u, ridx, int(W["grp"]), int(W["lead"]))
+        for w in range(4):
+            if us[w] is None or not us[w][3] or not fwd_kernel:
+                continue
+            u, ridx, grp, _ = us[w]
+            u = u.copy()
+            for k in range(1, grp):
+                assert us[w + k] is not None and not us[w + k][3]
+                assert np.array_equal(us[w + k][1], ridx)
+                u += us[w + k][0]
+            if direct:
+                y[ridx] = alpha * u if strong else beta * y[ridx] + alpha * u
+            else:
+                np.add.at(y, ridx, alpha * u)
+    return y

@@ -1,0 +1,244 @@
+"""GPU suite (-m gpu): the HIP path, called through the C ABI (libbsmrocm.so via the host
+mirror), against the CPU oracle on identical inputs.
+
+Tolerances (the reference's own norm max|y - y_ref| / max|y_ref|, test/test_vbcrs.jl:35):
+    fp64 / complex128 : 1e-12   (BASELINE.json north_star; the reference's tests use 1e-13 on
+                                 ~1e3-sized fixtures and `isapprox` rtol 1.5e-8 for products)
+    fp32 / complex64  : 2e-5
+Bookkeeping (perm / rowptr / colindices / rowindices / colour classes) is bit-exact and is
+covered in the CPU suite (tests/test_host_logic.py), which needs no GPU.
+"""
+import numpy as np
+import pytest
+
+from _common import (Cc, N, T, fixture_as_blocksparse, fixture_problem, oracle_mul, rand_vec, relerr,
+                     scipy_mul)
+
+pytestmark = pytest.mark.gpu
+TOL = {np.dtype(np.float64): 1e-12, np.dtype(np.complex128): 1e-12,
+       np.dtype(np.float32): 2e-5, np.dtype(np.complex64): 2e-5}
+OPS = [N, T, Cc]
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "GPU suite needs a GPU"
+    from bsm_amd import _lib as L
+    L.lib()  # fails loudly if the HIP extension is missing
+    return torch
+
+
+def wrap(bsm, A, op):
+    return A if op == N else (bsm.transpose(A) if op == T else bsm.adjoint(A))
+
+
+def gpu_mul(torch, bsm, A, op, x, y0, alpha, beta, strong, host=False):
+    Aop = wrap(bsm, A, op)
+    if host:  # BSM_MEM_HOST: the library stages x/y itself
+        y = np.array(y0, copy=True)
+        if strong:
+            return bsm.mul(y, Aop, x) if alpha == 1 else bsm.mul(y, Aop, x, alpha, False)
+        return bsm.mul(y, Aop, x, alpha, beta)
+    xd = torch.from_numpy(x).cuda()
+    yd = torch.from_numpy(np.array(y0, copy=True)).cuda()
+    if strong:
+        bsm.mul(yd, Aop, xd, alpha, False)
+    else:
+        bsm.mul(yd, Aop, xd, alpha, beta)
+    torch.cuda.synchronize()
+    return yd.cpu().numpy()
+
+
+def check_all(torch, bsm, oracle, problem, A, dtype, ops=OPS, seeds=(0,), host_too=True):
+    dtype = np.dtype(dtype)
+    nr, nc = problem["size"]
+    for seed in seeds:
+        rng = np.random.default_rng(seed)
+        for op in ops:
+            if op == Cc and dtype.kind != "c":
+                continue
+            xl, yl = (nc, nr) if op == N else (nr, nc)
+            x, y0 = rand_vec(rng, xl, dtype), rand_vec(rng, yl, dtype)
+            ab = [(1, 0, True), (0.75, -1.5, False)]
+            if dtype.kind == "c":
+                ab.append((1j, 2j, False))  # mul!(x, A, y, im, 2im), test_blockmatrix.jl:65
+            for alpha, beta, strong in ab:
+                ref = oracle_mul(oracle, problem, op, x, y0, alpha, beta, strong)
+                got = gpu_mul(torch, bsm, A, op, x, y0, alpha, beta, strong)
+                assert relerr(got, ref) < TOL[dtype], (op, alpha, beta, strong)
+            if host_too:
+                ref = oracle_mul(oracle, problem, op, x, y0, 1, 0, True)
+                got = gpu_mul(torch, bsm, A, op, x, y0, 1, 0, True, host=True)
+                assert relerr(got, ref) < TOL[dtype]
+
+
+# ---- the reference's fixture ------------------------------------------------------------------
+@pytest.mark.parametrize("key", ["cuboid", "sphere"])
+@pytest.mark.parametrize("dtype,part", [(np.complex128, "full"), (np.float64, "real"),
+                                        (np.float32, "imag"), (np.complex64, "full")])
+def test_symmetric_fixture(torch_cuda, bsm, oracle, key, dtype, part):
+    p = fixture_problem(key, dtype, part)
+    for sched in (bsm.SerialScheduler(), bsm.DynamicScheduler()):
+        A = bsm.SymmetricBlockMatrix(p["diagonals"], p["diagonalindices"], p["offdiagonals"],
+                                     p["rowindices"], p["colindices"], p["size"], scheduler=sched)
+        check_all(torch_cuda, bsm, oracle, p, A, dtype, seeds=(0, 1))
+    # the reference's own check: A*x ~ sparse(A)*x  (test_symmetricblockmatrix.jl:67-71)
+    rng = np.random.default_rng(5)
+    x = rand_vec(rng, p["size"][1], dtype)
+    got = gpu_mul(torch_cuda, bsm, A, N, x, np.zeros(p["size"][0], dtype), 1, 0, True)
+    assert relerr(got, scipy_mul(p, N, x, np.zeros(p["size"][0], dtype))) < TOL[np.dtype(dtype)]
+
+
+@pytest.mark.parametrize("key", ["cuboid", "sphere"])
+@pytest.mark.parametrize("acc", ["auto", "atomic"])
+def test_blocksparse_fixture(torch_cuda, bsm, oracle, key, acc):
+    p = fixture_as_blocksparse(key)
+    A = bsm.BlockSparseMatrix(p["blocks"], p["rowindices"], p["colindices"], p["size"], accumulate=acc)
+    assert A.stats()["exclusive"] == (1 if acc == "auto" else 0)
+    check_all(torch_cuda, bsm, oracle, p, A, np.complex128)
+
+
+@pytest.mark.parametrize("key", ["cuboid", "sphere"])
+def test_vbcrs_from_symmetric_matches_symmetric(torch_cuda, bsm, key):
+    # reference test/test_vbcrs.jl:52-88 (structure; the contiguous-index fixture is missing from the
+    # mount, so a contiguous synthetic symmetric operator stands in for it)
+    p = bsm.synthetic.config5(n=3000, lo=1, hi=40, halfband=3, seed=0xB5A5 + (key == "sphere"))
+    S = bsm.synthetic.build(p)
+    V = bsm.VariableBlockCompressedRowStorage(S)
+    assert bsm.nnz(S) == bsm.nnz(V)
+    rng = np.random.default_rng(2)
+    for _ in range(3):
+        x = rand_vec(rng, p["size"][1], np.float64)
+        sx = gpu_mul(torch_cuda, bsm, S, N, x, np.zeros_like(x), 1, 0, True)
+        for op in (N, T, Cc):
+            vx = gpu_mul(torch_cuda, bsm, V, op if op != Cc else T, x, np.zeros_like(x), 1, 0, True)
+            assert relerr(vx, sx) < 1e-12
+
+
+# ---- synthetic configs of BASELINE.json -----------------------------------------------------------
+def test_config1_blocksparse(torch_cuda, bsm, oracle):
+    p = bsm.synthetic.config1()
+    for sched in (bsm.SerialScheduler(), bsm.DynamicScheduler()):
+        A = bsm.synthetic.build(p, scheduler=sched)
+        check_all(torch_cuda, bsm, oracle, p, A, np.float64)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_config2_vbcrs_full_size(torch_cuda, bsm, oracle, dtype):
+    p = bsm.synthetic.config2(dtype=dtype)
+    A = bsm.synthetic.build(p)
+    st = A.stats()
+    assert st["exclusive"] == 1
+    check_all(torch_cuda, bsm, oracle, p, A, dtype, host_too=False)
+    # VBCRS vs the BlockSparseMatrix on the same blocks (test_vbcrs.jl:31-39)
+    ri = [np.arange(r, r + b.shape[0]) for r, b in zip(p["rowstart"], p["blocks"])]
+    ci = [np.arange(c, c + b.shape[1]) for c, b in zip(p["colstart"], p["blocks"])]
+    B = bsm.BlockSparseMatrix(p["blocks"], ri, ci, p["size"])
+    assert bsm.nnz(B) == bsm.nnz(A)
+    x = p["x"]
+    for op in (N, T):
+        a = gpu_mul(torch_cuda, bsm, A, op, x, np.zeros_like(x), 1, 0, True)
+        b = gpu_mul(torch_cuda, bsm, B, op, x, np.zeros_like(x), 1, 0, True)
+        assert relerr(a, b) < TOL[np.dtype(dtype)]
+
+
+def test_config3_symmetric_reduced_and_properties(torch_cuda, bsm, oracle):
+    p = bsm.synthetic.config3(nseg=200)
+    A = bsm.synthetic.build(p)
+    check_all(torch_cuda, bsm, oracle, p, A, np.float64, host_too=False)
+    # size-independent properties: S == S^T (docs/src/symmetric.md:109), linearity
+    rng = np.random.default_rng(11)
+    n = p["size"][0]
+    x, z = rand_vec(rng, n, np.float64), rand_vec(rng, n, np.float64)
+    zero = np.zeros(n)
+    sx = gpu_mul(torch_cuda, bsm, A, N, x, zero, 1, 0, True)
+    stx = gpu_mul(torch_cuda, bsm, A, T, x, zero, 1, 0, True)
+    assert relerr(stx, sx) < 1e-12
+    sz = gpu_mul(torch_cuda, bsm, A, N, z, zero, 1, 0, True)
+    sxz = gpu_mul(torch_cuda, bsm, A, N, 2 * x - 3 * z, zero, 1, 0, True)
+    assert relerr(sxz, 2 * sx - 3 * sz) < 1e-12
+    assert abs(np.dot(z, sx) - np.dot(sz, x)) < 1e-10 * abs(np.dot(z, sx))
+
+
+def test_config3_symmetric_full_size(torch_cuda, bsm, oracle):
+    p = bsm.synthetic.config3()
+    A = bsm.synthetic.build(p)
+    n = p["size"][0]
+    x = p["x"]
+    ref = oracle_mul(oracle, p, N, x, np.zeros(n))
+    got = gpu_mul(torch_cuda, bsm, A, N, x, np.zeros(n), 1, 0, True)
+    assert relerr(got, ref) < 1e-12
+    y0 = rand_vec(np.random.default_rng(1), n, np.float64)
+    ref = oracle_mul(oracle, p, N, x, y0, -0.5, 2.0, False)
+    got = gpu_mul(torch_cuda, bsm, A, N, x, y0, -0.5, 2.0, False)
+    assert relerr(got, ref) < 1e-12
+
+
+def test_config4_vbcrs_f32_one_rank_slice(torch_cuda, bsm, oracle):
+    # 1/64 of C4's block rows (the slice one GPU of eight would own is 8x this)
+    p = bsm.synthetic.config4(ngrid=15625, row_lo=0, row_hi=244)
+    A = bsm.synthetic.build(p)
+    check_all(torch_cuda, bsm, oracle, p, A, np.float32, ops=[N, T], host_too=False)
+
+
+def test_config5_symmetric_reduced(torch_cuda, bsm, oracle):
+    p = bsm.synthetic.config5(n=200_000)
+    A = bsm.synthetic.build(p)
+    check_all(torch_cuda, bsm, oracle, p, A, np.float64, host_too=False)
+
+
+# ---- edge cases the reference's semantics imply ------------------------------------------------------
+def test_strong_zero_beta_on_gpu(torch_cuda, bsm):
+    p = bsm.synthetic.config2(n=3000, nblocks=100)
+    A = bsm.synthetic.build(p)
+    x = p["x"]
+    ynan = np.full(p["size"][0], np.nan)
+    y = gpu_mul(torch_cuda, bsm, A, N, x, ynan, 1, 0, True)
+    assert np.all(np.isfinite(y))          # Bool false: overwritten (src/abstractblockmatrix.jl:27-34)
+    y = gpu_mul(torch_cuda, bsm, A, N, x, ynan, 1, 0.0, False)
+    assert np.all(np.isnan(y))             # numeric 0.0 multiplies
+    yt = gpu_mul(torch_cuda, bsm, A, T, x, ynan, 1, 0, True)
+    assert np.all(np.isfinite(yt))         # fill!(y, 0) of the 3-arg transpose form, src/vbcrs.jl:339
+
+
+def test_edge_cases_blocksparse(torch_cuda, bsm, oracle):
+    rng = np.random.default_rng(3)
+    blocks = [rng.standard_normal((1, 1)), np.zeros((0, 3)), np.zeros((2, 0)),
+              rng.standard_normal((130, 7)), rng.standard_normal((5, 9)), rng.standard_normal((5, 3)),
+              rng.standard_normal((3, 2)), rng.standard_normal((70, 300))]
+    rows = [[7], [], [1, 2], list(range(20, 150)), [1, 3, 5, 7, 9], [1, 3, 5, 7, 9], [200, 200, 201],
+            list(range(140, 210))]
+    cols = [[9], [1, 2, 3], [], [4, 3, 2, 1, 10, 11, 12], list(range(50, 59)), [2, 4, 6], [1, 1],
+            list(rng.permutation(300) + 1)]
+    p = dict(kind="blocksparse", blocks=[np.asfortranarray(b) for b in blocks], rowindices=rows,
+             colindices=cols, size=(210, 300))
+    A = bsm.synthetic.build(p)
+    check_all(torch_cuda, bsm, oracle, p, A, np.float64)
+
+
+def test_vbcrs_unequal_heights_and_overlap(torch_cuda, bsm, oracle):
+    rng = np.random.default_rng(4)
+    blocks = [rng.standard_normal((4, 4)), rng.standard_normal((6, 2)), rng.standard_normal((3, 5))]
+    p = dict(kind="vbcrs", blocks=[np.asfortranarray(b) for b in blocks],
+             rowstart=np.array([1, 1, 3]), colstart=np.array([1, 5, 2]), size=(8, 8))
+    A = bsm.synthetic.build(p)
+    check_all(torch_cuda, bsm, oracle, p, A, np.float64)
+
+
+def test_getindex_matches_sparse(torch_cuda, bsm):
+    # A[:, :] vs sparse(A)  (test_blockmatrix.jl:38-49), small operator
+    p = bsm.synthetic.config1(n=60, nblocks=6, bs=7)
+    A = bsm.synthetic.build(p)
+    assert np.max(np.abs(A[:, :] - bsm.sparse(A).toarray())) < 1e-13
+    assert np.max(np.abs(bsm.transpose(A)[:, :] - bsm.sparse(A).toarray().T)) < 1e-13
+
+
+def test_run_to_run_determinism_of_exclusive_path(torch_cuda, bsm):
+    p = bsm.synthetic.config2(n=20000, nblocks=1000)
+    A = bsm.synthetic.build(p)
+    assert A.stats()["exclusive"] == 1
+    x = p["x"]
+    a = gpu_mul(torch_cuda, bsm, A, N, x, np.zeros_like(x), 1, 0, True)
+    for _ in range(3):
+        assert np.array_equal(a, gpu_mul(torch_cuda, bsm, A, N, x, np.zeros_like(x), 1, 0, True))

@@ -1,0 +1,255 @@
+"""CPU suite, part 2: the C-ABI library loads, exports every declared symbol, and its HOST
+logic (reference bookkeeping, colouring, packing, wave schedule) is right -- no GPU needed:
+handles are created with BSM_DEVICE_NONE and the packed image is executed by a numpy
+interpreter (tests/_common.py) and compared with the oracle."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from _common import (Cc, N, T, fixture_as_blocksparse, fixture_problem, interpret_image, oracle_mul,
+                     rand_vec, relerr)
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+NODEV = -2
+OPS = [N, T, Cc]
+
+
+def test_library_exports_every_declared_symbol(bsm):
+    from bsm_amd import _lib as L
+    hdr = open(os.path.join(ROOT, "include", "bsm_rocm.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = sorted(set(re.findall(r"\b(bsm_[a-z_]+)\s*\(", hdr)))
+    assert declared, "no declarations parsed"
+    lib = L.lib()
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/bsm_rocm.h but not exported"
+    assert sorted(L.EXPORTS) == declared
+    assert b"gfx950" in lib.bsm_version()
+    assert C.sizeof(L.BsmOptions) == 72 and C.sizeof(L.BsmStats) == 128
+
+
+def test_mul_without_device_image_fails_loudly(bsm):
+    A = bsm.BlockSparseMatrix([np.eye(2)], [[1, 2]], [[1, 2]], (2, 2), device=NODEV)
+    with pytest.raises(RuntimeError, match="no device image"):
+        bsm.mul(np.zeros(2), A, np.ones(2))
+
+
+# ---- reference bookkeeping, bit-exact ----------------------------------------------------------
+def test_vbcrs_bookkeeping_kat(bsm):
+    blocks = [np.ones((2, 3)), np.ones((4, 2)), np.ones((4, 4)), np.ones((2, 1))]
+    A = bsm.VariableBlockCompressedRowStorage(blocks, [5, 1, 1, 5], [1, 7, 3, 9], (6, 9), device=NODEV)
+    assert A.perm.tolist() == [3, 2, 1, 4]
+    assert A.rowptr.tolist() == [1, 3, 5]
+    assert A.rowindices.tolist() == [1, 5]
+    assert A.colindices.tolist() == [3, 7, 1, 9]
+    assert bsm.nnz(A) == 6 + 8 + 16 + 2
+
+
+def test_vbcrs_bookkeeping_matches_oracle_random(bsm, oracle):
+    rng = np.random.default_rng(0)
+    for _ in range(20):
+        nb = int(rng.integers(1, 40))
+        rs = rng.integers(1, 8, nb) * 4 - 3
+        cs = rng.integers(1, 8, nb) * 4 - 3
+        blocks = [np.ones((4, 4))] * nb
+        A = bsm.VariableBlockCompressedRowStorage(blocks, rs, cs, (32, 32), device=NODEV)
+        perm, rowptr, colind, rowind = oracle.vbcrs_build(rs, cs)
+        assert np.array_equal(A.perm, perm) and np.array_equal(A.rowptr, rowptr)
+        assert np.array_equal(A.colindices, colind) and np.array_equal(A.rowindices, rowind)
+
+
+def test_serial_scheduler_gives_single_colour(bsm):
+    p = fixture_as_blocksparse("sphere")
+    A = bsm.BlockSparseMatrix(p["blocks"], p["rowindices"], p["colindices"], p["size"], device=NODEV)
+    nb = len(p["blocks"])
+    assert A.colors == [list(range(1, nb + 1))] and A.transposecolors == [list(range(1, nb + 1))]
+    assert bsm.colors(bsm.transpose(A)) == A.transposecolors
+
+
+@pytest.mark.parametrize("key", ["cuboid", "sphere"])
+def test_colouring_equals_oracle_spec_and_is_valid(bsm, oracle, key):
+    p = fixture_problem(key)
+    S = bsm.SymmetricBlockMatrix(p["diagonals"], p["diagonalindices"], p["offdiagonals"],
+                                 p["rowindices"], p["colindices"], p["size"], device=NODEV)
+    for got, lists in ((S.offdiagonalcolors, p["rowindices"]), (S.transposeoffdiagonalcolors, p["colindices"]),
+                       (S.diagonalcolors, p["diagonalindices"])):
+        assert oracle.color_check(lists, got)
+        assert got == oracle.color_dsatur(lists)  # deterministic DSATUR spec, bit-exact
+    assert bsm.offdiagonalcolors(bsm.adjoint(S)) == S.transposeoffdiagonalcolors  # :307-325
+    q = fixture_as_blocksparse(key)
+    B = bsm.BlockSparseMatrix(q["blocks"], q["rowindices"], q["colindices"], q["size"],
+                              scheduler=bsm.DynamicScheduler(), device=NODEV)
+    assert B.colors == oracle.color_dsatur(q["rowindices"])
+    assert B.transposecolors == oracle.color_dsatur(q["colindices"])
+
+
+def test_colouring_random_lists(bsm, oracle):
+    rng = np.random.default_rng(7)
+    for _ in range(10):
+        nb = int(rng.integers(2, 30))
+        lists = [rng.choice(40, size=int(rng.integers(1, 6)), replace=False) + 1 for _ in range(nb)]
+        blocks = [np.ones((len(l), 1)) for l in lists]
+        A = bsm.BlockSparseMatrix(blocks, lists, [[1]] * nb, (40, 40), scheduler=bsm.DynamicScheduler(),
+                                  device=NODEV)
+        assert A.colors == oracle.color_dsatur(lists)
+        assert oracle.color_check(lists, A.colors)
+
+
+# ---- nnz / size / accessors ---------------------------------------------------------------------
+def test_nnz_and_accessors(bsm):
+    p = fixture_problem("cuboid")
+    S = bsm.SymmetricBlockMatrix(p["diagonals"], p["diagonalindices"], p["offdiagonals"],
+                                 p["rowindices"], p["colindices"], p["size"], device=NODEV)
+    assert bsm.nnz(S) == 2 * 93842 + 21264 == bsm.sparse(S).nnz
+    assert bsm.nnz(bsm.adjoint(S)) == bsm.nnz(S)
+    assert bsm.size(S) == (1344, 1344) and bsm.eltype(S) == np.complex128
+    assert isinstance(bsm.scheduler(S), bsm.DynamicScheduler)  # tuple-size ctor default, :80
+    assert np.array_equal(bsm.rowindices(bsm.transpose(S), 3), p["colindices"][2])
+    assert np.array_equal(bsm.offdiagonal(bsm.adjoint(S), 1), p["offdiagonals"][0].conj().T)
+    V = bsm.VariableBlockCompressedRowStorage([np.ones((2, 2))], [1], [1], (2, 2), device=NODEV)
+    assert isinstance(bsm.scheduler(V), bsm.SerialScheduler)
+
+
+def test_error_behaviour(bsm):
+    with pytest.raises(IndexError):  # matrices[1] on an empty vector, src/vbcrs.jl:81
+        bsm.VariableBlockCompressedRowStorage([], [], [], (4, 4), device=NODEV)
+    with pytest.raises(RuntimeError, match="out of range"):
+        bsm.BlockSparseMatrix([np.ones((1, 1))], [[5]], [[1]], (4, 4), device=NODEV)
+    with pytest.raises(RuntimeError, match="outside matrix"):
+        bsm.VariableBlockCompressedRowStorage([np.ones((3, 3))], [3], [1], (4, 4), device=NODEV)
+    A = bsm.BlockSparseMatrix([np.ones((1, 1))], [[1]], [[1]], (4, 3), device=NODEV)
+    with pytest.raises(ValueError, match="DimensionMismatch"):
+        bsm.mul(np.zeros(4), A, np.zeros(4))
+    with pytest.raises(ValueError, match="DimensionMismatch"):
+        bsm.mul(np.zeros(4), bsm.transpose(A), np.zeros(4))
+
+
+# ---- packed image == oracle ----------------------------------------------------------------------
+def _check_image(bsm, oracle, problem, A, dtype, ops=OPS, tol=None):
+    rng = np.random.default_rng(42)
+    nr, nc = problem["size"]
+    tol = tol or (2e-5 if np.dtype(dtype) in (np.float32, np.complex64) else 1e-13)
+    for op in ops:
+        if op == Cc and np.dtype(dtype).kind != "c":
+            continue
+        xl, yl = (nc, nr) if op == N else (nr, nc)
+        x, y0 = rand_vec(rng, xl, dtype), rand_vec(rng, yl, dtype)
+        for alpha, beta, strong in ((1, 0, True), (0.75, -1.5, False)):
+            ref = oracle_mul(oracle, problem, op, x, y0, alpha, beta, strong)
+            got = interpret_image(A, op, x, y0, alpha, beta, strong)
+            assert relerr(got, ref) < tol, (op, alpha, beta, strong)
+
+
+@pytest.mark.parametrize("key", ["cuboid", "sphere"])
+@pytest.mark.parametrize("dtype,part", [(np.complex128, "full"), (np.float64, "real"), (np.float32, "imag")])
+def test_image_symmetric_fixture(bsm, oracle, key, dtype, part):
+    p = fixture_problem(key, dtype, part)
+    A = bsm.synthetic.build(p, device=NODEV)
+    assert A.stats()["exclusive"] == 0
+    _check_image(bsm, oracle, p, A, dtype)
+
+
+@pytest.mark.parametrize("key", ["cuboid", "sphere"])
+def test_image_blocksparse_fixture(bsm, oracle, key):
+    p = fixture_as_blocksparse(key)
+    A = bsm.synthetic.build(p, device=NODEV)
+    assert A.stats()["exclusive"] == 1  # the fixture's test lists are mutually disjoint
+    _check_image(bsm, oracle, p, A, np.complex128)
+
+
+def test_image_config1_blocksparse(bsm, oracle):
+    p = bsm.synthetic.config1()
+    A = bsm.synthetic.build(p, device=NODEV)
+    assert A.stats()["exclusive"] == 0  # random row lists overlap
+    assert bsm.nnz(A) == 50 * 32 * 32
+    _check_image(bsm, oracle, p, A, np.float64)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_image_config2_vbcrs_small(bsm, oracle, dtype):
+    p = bsm.synthetic.config2(n=4000, nblocks=400, dtype=dtype)
+    A = bsm.synthetic.build(p, device=NODEV)
+    st = A.stats()
+    assert st["exclusive"] == 1 and st["nnz"] == sum(b.size for b in p["blocks"])
+    _check_image(bsm, oracle, p, A, dtype)
+
+
+def test_image_config3_symmetric_small(bsm, oracle):
+    p = bsm.synthetic.config3(nseg=40, bs=64, halfband=8)
+    A = bsm.synthetic.build(p, device=NODEV)
+    _check_image(bsm, oracle, p, A, np.float64)
+
+
+def test_image_config4_vbcrs_small_f32(bsm, oracle):
+    p = bsm.synthetic.config4(ngrid=24, bs=128, per_row=6)
+    A = bsm.synthetic.build(p, device=NODEV)
+    assert A.stats()["exclusive"] == 1
+    _check_image(bsm, oracle, p, A, np.float32)
+
+
+def test_image_config5_symmetric_small(bsm, oracle):
+    p = bsm.synthetic.config5(n=6000, lo=16, hi=256, halfband=4)
+    A = bsm.synthetic.build(p, device=NODEV)
+    _check_image(bsm, oracle, p, A, np.float64)
+
+
+def test_image_edge_cases(bsm, oracle):
+    rng = np.random.default_rng(3)
+    # 1x1 blocks, empty blocks, m > 64 (row chunks), odd widths, duplicate index inside a list,
+    # two blocks on the same rows (grouped), rows nobody covers
+    blocks = [rng.standard_normal((1, 1)), np.zeros((0, 3)), np.zeros((2, 0)),
+              rng.standard_normal((130, 7)), rng.standard_normal((5, 9)), rng.standard_normal((5, 3)),
+              rng.standard_normal((3, 2))]
+    rows = [[7], [], [1, 2], list(range(20, 150)), [1, 3, 5, 7, 9], [1, 3, 5, 7, 9], [200, 200, 201]]
+    cols = [[9], [1, 2, 3], [], [4, 3, 2, 1, 10, 11, 12], list(range(50, 59)), [2, 4, 6], [1, 1]]
+    p = dict(kind="blocksparse", blocks=[np.asfortranarray(b) for b in blocks], rowindices=rows,
+             colindices=cols, size=(210, 60))
+    A = bsm.synthetic.build(p, device=NODEV)
+    assert A.stats()["exclusive"] == 0
+    _check_image(bsm, oracle, p, A, np.float64)
+
+
+def test_image_vbcrs_unequal_heights_and_overlap(bsm, oracle):
+    # reference semantics (src/vbcrs.jl:277-283): heights are per block, nothing is checked.
+    rng = np.random.default_rng(4)
+    blocks = [rng.standard_normal((4, 4)), rng.standard_normal((6, 2)), rng.standard_normal((3, 5))]
+    p = dict(kind="vbcrs", blocks=[np.asfortranarray(b) for b in blocks],
+             rowstart=np.array([1, 1, 3]), colstart=np.array([1, 5, 2]), size=(8, 8))
+    A = bsm.synthetic.build(p, device=NODEV)
+    assert A.stats()["exclusive"] == 0  # overlapping block rows -> atomics
+    _check_image(bsm, oracle, p, A, np.float64)
+
+
+def test_image_vbcrs_from_symmetric_and_blocksparse(bsm, oracle):
+    # converters, reference src/vbcrs.jl:150-264 (enumeration [diag..., off..., transpose(off)...])
+    p = bsm.synthetic.config3(nseg=12, bs=16, halfband=3)
+    S = bsm.synthetic.build(p, device=NODEV)
+    V = bsm.VariableBlockCompressedRowStorage(S, device=NODEV)
+    assert bsm.nnz(V) == bsm.nnz(S)
+    rng = np.random.default_rng(8)
+    n = p["size"][0]
+    x, y0 = rand_vec(rng, n, np.float64), rand_vec(rng, n, np.float64)
+    ref = oracle_mul(oracle, p, N, x, y0)
+    assert relerr(interpret_image(V, N, x, y0), ref) < 1e-13
+    assert relerr(interpret_image(V, T, x, y0), ref) < 1e-13
+    q = bsm.synthetic.config2(n=600, nblocks=60)
+    ri = [np.arange(r, r + b.shape[0]) for r, b in zip(q["rowstart"], q["blocks"])]
+    ci = [np.arange(c, c + b.shape[1]) for c, b in zip(q["colstart"], q["blocks"])]
+    B = bsm.BlockSparseMatrix(q["blocks"], ri, ci, q["size"], device=NODEV)
+    V2 = bsm.VariableBlockCompressedRowStorage(B, device=NODEV)
+    x, y0 = rand_vec(rng, 600, np.float64), rand_vec(rng, 600, np.float64)
+    assert relerr(interpret_image(V2, N, x, y0), interpret_image(B, N, x, y0)) < 1e-13
+
+
+def test_own_range_limits_scale_work(bsm):
+    p = bsm.synthetic.config2(n=2000, nblocks=40)
+    A = bsm.VariableBlockCompressedRowStorage(p["blocks"], p["rowstart"], p["colstart"], p["size"],
+                                              device=NODEV, own=(501, 1000))
+    from _common import WORK_SCALE, get_image
+    waves = get_image(A)[4]
+    sc = waves[waves["work"] == WORK_SCALE]
+    assert len(sc) > 0
+    assert sc["rbase"].min() >= 500 and (sc["rbase"] + sc["first"]["ncols"]).max() <= 1000
