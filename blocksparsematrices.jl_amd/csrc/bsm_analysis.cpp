@@ -106,35 +106,40 @@ std::vector<std::vector<int64_t>> color_dsatur(const std::vector<const int64_t *
 namespace {
 
 struct Chunk {
-    int32_t blk;      // input block
-    int32_t ra;       // first row of the block in this chunk
-    int32_t mc;       // rows (<= 64)
-    int64_t group;    // row group id
-    uint64_t val_off; // 16-byte units
-    int32_t nstrips;
+    int32_t blk;    // input block
+    int32_t ra;     // first row of the block in this chunk
+    int32_t mc;     // rows (<= 64)
+    int64_t group;  // row group id
+    int64_t woff;   // first column of this chunk inside the group's merged panel
 };
 
+// A row group = every chunk (of equal kind) living on the same y rows.  Its chunks are
+// concatenated column-wise into ONE merged panel, so a wave always streams a single piece.
 struct Group {
     int32_t mc = 0;
+    int32_t kind = 0;
     int32_t rbase = -1;    // 0-based first row when contiguous
     int32_t row_off = -1;  // rows pool offset when indexed
     std::vector<int32_t> chunks;
-    int64_t strips = 0;
+    int64_t width = 0;     // merged columns
+    int64_t strips = 0;    // ceil(width / E)
+    int64_t col_off = 0;   // cols pool offset of the merged column list
+    uint64_t val_off = 0;  // 16-byte units
 };
 
 struct Item {
     int64_t group;
-    int64_t s_begin, s_end;  // over the group's concatenated strips
+    int64_t s_begin, s_end;  // strips of the group's merged panel
     int64_t bytes;
     int nw;
 };
 
 template <typename U>
-void pack_chunk(const U *src, int64_t ld, int ra, int mc, int64_t n, int E, U *dst) {
-    // dst[(s*mc + i)*E + e] = src[(ra+i) + (s*E+e)*ld]
+void pack_chunk(const U *src, int64_t ld, int ra, int mc, int64_t n, int64_t woff, int E, U *dst) {
+    // dst[(s*mc + i)*E + e] = src[(ra+i) + w*ld],  s*E + e = woff + w
     for (int64_t w = 0; w < n; w++) {
-        const int64_t s = w / E;
-        const int e = (int)(w % E);
+        const int64_t s = (woff + w) / E;
+        const int e = (int)((woff + w) % E);
         const U *col = src + ra + w * ld;
         U *d = dst + (s * mc) * E + e;
         for (int i = 0; i < mc; i++) d[(int64_t)i * E] = col[i];
@@ -221,28 +226,9 @@ std::string Analysis::build(int mtype_, int dtype_, int64_t nrows_, int64_t ncol
     std::vector<const int64_t *> glist;  // representative index list of indexed groups
     rows.clear();
     cols.clear();
-    std::vector<int32_t> blk_xbase(nb, -1), blk_coloff(nb, -1);
-    uint64_t val_units = 0;
     for (int64_t b = 0; b < nb; b++) {
         const BlockIn &B = blocks[b];
         if (B.m == 0 || B.n == 0) continue;
-        // column identity of the block
-        bool ccontig = true;
-        if (B.cidx)
-            for (int64_t k = 1; k < B.n; k++)
-                if (B.cidx[k] != B.cidx[0] + k) {
-                    ccontig = false;
-                    break;
-                }
-        if (ccontig) {
-            blk_xbase[b] = (int32_t)((B.cidx ? B.cidx[0] : B.c0) - 1);
-        } else {
-            if ((int64_t)cols.size() + B.n + 8 > INT32_MAX) return "column index pool exceeds int32";
-            blk_coloff[b] = (int32_t)cols.size();
-            for (int64_t k = 0; k < B.n; k++) cols.push_back((int32_t)(B.cidx[k] - 1));
-        }
-        const int64_t nstrips = (B.n + E - 1) / E;
-        if (nstrips > INT32_MAX / 2) return "block too wide";
         for (int64_t ra = 0; ra < B.m; ra += kMaxRowsPerChunk) {
             const int mc = (int)std::min<int64_t>(kMaxRowsPerChunk, B.m - ra);
             bool rcontig = true;
@@ -258,11 +244,12 @@ std::string Analysis::build(int mtype_, int dtype_, int64_t nrows_, int64_t ncol
                 h = ((uint64_t)rbase * 0x9E3779B97F4A7C15ull) ^ ((uint64_t)mc << 56) ^ 0x51ull;
             else
                 h = hash_list(B.ridx + ra, mc);
+            h ^= (uint64_t)B.kind * 0xD6E8FEB86659FD93ull;
             int64_t gid = -1;
             auto &cand = gmap[h];
             for (int64_t g : cand) {
                 const Group &G = groups[g];
-                if (G.mc != mc) continue;
+                if (G.mc != mc || G.kind != B.kind) continue;
                 if (rcontig) {
                     if (G.rbase == rbase) gid = g;
                 } else if (G.rbase < 0 &&
@@ -275,6 +262,7 @@ std::string Analysis::build(int mtype_, int dtype_, int64_t nrows_, int64_t ncol
                 gid = (int64_t)groups.size();
                 Group G;
                 G.mc = mc;
+                G.kind = B.kind;
                 G.rbase = (int32_t)rbase;
                 if (!rcontig) {
                     if ((int64_t)rows.size() + mc + 8 > INT32_MAX) return "row index pool exceeds int32";
@@ -290,15 +278,33 @@ std::string Analysis::build(int mtype_, int dtype_, int64_t nrows_, int64_t ncol
             c.ra = (int32_t)ra;
             c.mc = mc;
             c.group = gid;
-            c.val_off = val_units;
-            c.nstrips = (int32_t)nstrips;
-            val_units += (uint64_t)mc * (uint64_t)nstrips;
+            c.woff = groups[gid].width;
+            groups[gid].width += B.n;
             groups[gid].chunks.push_back((int32_t)chunks.size());
-            groups[gid].strips += nstrips;
             chunks.push_back(c);
         }
     }
     ngroups = (int64_t)groups.size();
+    // merged column lists + value offsets
+    uint64_t val_units = 0;
+    {
+        int64_t total_cols = 0;
+        for (const Group &G : groups) total_cols += G.width + E;
+        if (total_cols + 8 > INT32_MAX) return "column index pool exceeds int32";
+        cols.reserve((size_t)total_cols);
+    }
+    for (Group &G : groups) {
+        G.strips = (G.width + E - 1) / E;
+        if (G.strips * (int64_t)G.mc * 16 >= ((int64_t)1 << 31)) return "row group panel exceeds 2 GiB";
+        G.col_off = (int64_t)cols.size();
+        for (int32_t ci : G.chunks) {
+            const BlockIn &B = blocks[chunks[ci].blk];
+            for (int64_t k = 0; k < B.n; k++)
+                cols.push_back((int32_t)((B.cidx ? B.cidx[k] : B.c0 + k) - 1));
+        }
+        G.val_off = val_units;
+        val_units += (uint64_t)G.mc * (uint64_t)G.strips;
+    }
 
     // ---- forward exclusivity + coverage ------------------------------------------------
     const int64_t own_lo = (opt.own_lo > 0) ? opt.own_lo - 1 : 0;
@@ -328,13 +334,13 @@ std::string Analysis::build(int mtype_, int dtype_, int64_t nrows_, int64_t ncol
             for (size_t ci = t; ci < chunks.size(); ci += nt) {
                 const Chunk &c = chunks[ci];
                 const BlockIn &B = blocks[c.blk];
-                char *dst = values.data() + (size_t)c.val_off * 16;
+                char *dst = values.data() + (size_t)groups[c.group].val_off * 16;
                 if (es == 4)
-                    pack_chunk<uint32_t>((const uint32_t *)B.data, B.ld, c.ra, c.mc, B.n, E, (uint32_t *)dst);
+                    pack_chunk<uint32_t>((const uint32_t *)B.data, B.ld, c.ra, c.mc, B.n, c.woff, E, (uint32_t *)dst);
                 else if (es == 8)
-                    pack_chunk<uint64_t>((const uint64_t *)B.data, B.ld, c.ra, c.mc, B.n, E, (uint64_t *)dst);
+                    pack_chunk<uint64_t>((const uint64_t *)B.data, B.ld, c.ra, c.mc, B.n, c.woff, E, (uint64_t *)dst);
                 else
-                    pack_chunk<U16>((const U16 *)B.data, B.ld, c.ra, c.mc, B.n, E, (U16 *)dst);
+                    pack_chunk<U16>((const U16 *)B.data, B.ld, c.ra, c.mc, B.n, c.woff, E, (U16 *)dst);
             }
         };
         std::vector<std::thread> th;
@@ -369,9 +375,8 @@ std::string Analysis::build(int mtype_, int dtype_, int64_t nrows_, int64_t ncol
         return a.bytes > b.bytes;
     });
 
-    // ---- waves ---------------------------------------------------------------------------
+    // ---- waves: every wave streams ONE piece (a strip range of a merged panel) -----------
     waves.clear();
-    pieces.clear();
     auto emit_nop = [&]() {
         WaveWork w;
         std::memset(&w, 0, sizeof w);
@@ -397,31 +402,24 @@ std::string Analysis::build(int mtype_, int dtype_, int64_t nrows_, int64_t ncol
             W.lead = (w == 0) ? 1 : 0;
             W.rbase = G.rbase;
             W.row_off = G.row_off;
-            W.piece_begin = (int32_t)pieces.size();
             W.npieces = 0;
-            // walk the group's chunks and cut [wa, wb)
-            int64_t pos = 0;
-            for (int32_t ci : G.chunks) {
-                const Chunk &c = chunks[ci];
-                const int64_t ca = pos, cb = pos + c.nstrips;
-                pos = cb;
-                const int64_t a = std::max(ca, wa), bnd = std::min(cb, wb);
-                if (a >= bnd) continue;
-                const BlockIn &B = blocks[c.blk];
-                Piece P;
-                std::memset(&P, 0, sizeof P);
-                const int64_t sa = a - ca;  // first strip inside the chunk
-                P.val_off = c.val_off + (uint64_t)sa * (uint64_t)c.mc;
-                P.nstrips = (int32_t)(bnd - a);
-                P.ncols = (int32_t)std::min<int64_t>(B.n - sa * E, (bnd - a) * E);
-                P.xbase = blk_xbase[c.blk] >= 0 ? (int32_t)(blk_xbase[c.blk] + sa * E) : -1;
-                P.col_off = blk_coloff[c.blk] >= 0 ? (int32_t)(blk_coloff[c.blk] + sa * E) : 0;
-                P.kind = B.kind;
-                if (W.npieces == 0)
-                    W.first = P;
-                else
-                    pieces.push_back(P);
-                W.npieces++;
+            if (wb > wa) {
+                Piece &P = W.first;
+                const int64_t c0 = wa * E;
+                const int64_t c1 = std::min<int64_t>(G.width, wb * E);
+                P.val_off = G.val_off + (uint64_t)wa * (uint64_t)G.mc;
+                P.nstrips = (int32_t)(wb - wa);
+                P.ncols = (int32_t)(c1 - c0);
+                P.col_off = (int32_t)(G.col_off + c0);
+                P.kind = G.kind;
+                bool contig = true;
+                for (int64_t k = c0 + 1; k < c1; k++)
+                    if (cols[G.col_off + k] != cols[G.col_off + k - 1] + 1) {
+                        contig = false;
+                        break;
+                    }
+                P.xbase = contig ? cols[G.col_off + c0] : -1;
+                W.npieces = 1;
             }
             waves.push_back(W);
         }
@@ -451,11 +449,6 @@ std::string Analysis::build(int mtype_, int dtype_, int64_t nrows_, int64_t ncol
         while (waves.size() % kWavesPerWg) emit_nop();
     }
     nwg_total = (int64_t)waves.size() / kWavesPerWg;
-    if (pieces.empty()) {  // keep the device array non-empty
-        Piece P;
-        std::memset(&P, 0, sizeof P);
-        pieces.push_back(P);
-    }
     if (rows.empty()) rows.push_back(0);
     if (cols.empty()) cols.push_back(0);
     if (values.empty()) values.assign(16, 0);

@@ -58,7 +58,6 @@ class Analysis {
     // ---- device image (host copy) ----
     std::vector<char> values;
     std::vector<int32_t> rows, cols;
-    std::vector<Piece> pieces;
     std::vector<WaveWork> waves;
     int64_t nwg_main = 0;   // workgroups holding panel work
     int64_t nwg_total = 0;  // + workgroups of scale work (exclusive forward launch only)

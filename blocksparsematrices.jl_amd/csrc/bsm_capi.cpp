@@ -91,7 +91,7 @@ template <typename V> hipError_t upload(const V &v, void **dptr, long long &tota
 }
 
 void free_image(DeviceImage &img) {
-    for (void **p : {&img.d_values, &img.d_rows, &img.d_cols, &img.d_pieces, &img.d_waves}) {
+    for (void **p : {&img.d_values, &img.d_rows, &img.d_cols, &img.d_waves}) {
         if (*p) (void)hipFree(*p);
         *p = nullptr;
     }
@@ -111,8 +111,6 @@ int finish_create(bsm_matrix_s *A, const bsm_options &o, bsm_matrix_t *out) {
     img.has_off = false;
     for (const WaveWork &w : an.waves)
         if (w.work == WORK_PANEL && w.npieces > 0 && w.first.kind == KIND_OFF) img.has_off = true;
-    for (const Piece &p : an.pieces)
-        if (p.kind == KIND_OFF && p.nstrips > 0) img.has_off = true;
     if (!img.exclusive_fwd) img.nwg_total = img.nwg_main;
 
     if (o.device != BSM_DEVICE_NONE) {
@@ -136,7 +134,6 @@ int finish_create(bsm_matrix_s *A, const bsm_options &o, bsm_matrix_t *out) {
         e = upload(an.values, &img.d_values, total);
         if (e == hipSuccess) e = upload(an.rows, &img.d_rows, total);
         if (e == hipSuccess) e = upload(an.cols, &img.d_cols, total);
-        if (e == hipSuccess) e = upload(an.pieces, &img.d_pieces, total);
         if (e == hipSuccess) e = upload(an.waves, &img.d_waves, total);
         if (e != hipSuccess) {
             free_image(img);
@@ -149,7 +146,7 @@ int finish_create(bsm_matrix_s *A, const bsm_options &o, bsm_matrix_t *out) {
         std::vector<char>().swap(an.values);
     } else {
         img.device_bytes = (long long)(an.values.size() + an.rows.size() * 4 + an.cols.size() * 4 +
-                                       an.pieces.size() * sizeof(Piece) + an.waves.size() * sizeof(WaveWork));
+                                       an.waves.size() * sizeof(WaveWork));
     }
     *out = A;
     return BSM_OK;
@@ -386,8 +383,7 @@ extern "C" int bsm_get_image(bsm_matrix_t A, int which, void *out, int64_t *nbyt
         case 0: src = an.values.data(); bytes = an.values.size(); break;
         case 1: src = an.rows.data(); bytes = an.rows.size() * 4; break;
         case 2: src = an.cols.data(); bytes = an.cols.size() * 4; break;
-        case 3: src = an.pieces.data(); bytes = an.pieces.size() * sizeof(Piece); break;
-        case 4: src = an.waves.data(); bytes = an.waves.size() * sizeof(WaveWork); break;
+        case 3: src = an.waves.data(); bytes = an.waves.size() * sizeof(WaveWork); break;
         default: return fail(BSM_ERR_INVALID, "unknown image array");
     }
     if (out) {

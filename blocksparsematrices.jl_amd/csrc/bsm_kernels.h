@@ -12,7 +12,7 @@ struct DeviceImage {
     long long nrows = 0, ncols = 0;
     long long own_lo = 0, own_hi = 0;  // 0-based [lo, hi) rows of y scaled by this handle
     void *d_values = nullptr, *d_rows = nullptr, *d_cols = nullptr;
-    void *d_pieces = nullptr, *d_waves = nullptr;
+    void *d_waves = nullptr;
     long long nwg_main = 0, nwg_total = 0;
     bool exclusive_fwd = false;
     bool has_off = false;  // SymmetricBlockMatrix off-diagonal pieces present

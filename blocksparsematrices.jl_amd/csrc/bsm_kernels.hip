@@ -12,6 +12,8 @@
 // >= 8 KB per wave in flight with perfectly coalesced 16-byte loads.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "bsm_kernels.h"
 #include "bsm_layout.h"
 
@@ -143,12 +145,50 @@ constexpr int FLAG_CONJ = 4;
 constexpr int FLAG_OPT = 8;
 
 // ----------------------------------------------------------------------------------------
+// descriptors: fetched as whole 16-byte words through a wave-uniform address (scalar loads),
+// so a wave reaches its matrix bytes after ONE dependent memory round trip.
+// ----------------------------------------------------------------------------------------
+struct PieceD {
+    uint32_t val_lo, val_hi;
+    int xbase, col_off, nstrips, ncols, kind;
+};
+struct WaveD {
+    int npieces, row_off, rbase, m, work, grp, lead;
+    PieceD first;
+};
+
+__device__ __forceinline__ PieceD decode_piece(const uint4 a, const uint4 b) {
+    PieceD p;
+    p.val_lo = a.x;
+    p.val_hi = a.y;
+    p.xbase = (int)a.z;
+    p.col_off = (int)a.w;
+    p.nstrips = (int)b.x;
+    p.ncols = (int)b.y;
+    p.kind = (int)b.z;
+    return p;
+}
+
+__device__ __forceinline__ WaveD load_wave(const WaveWork *__restrict__ wp) {
+    const uint4 *__restrict__ q = reinterpret_cast<const uint4 *>(wp);
+    const uint4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+    WaveD w;
+    w.npieces = (int)q0.y;
+    w.row_off = (int)q0.z;
+    w.rbase = (int)q0.w;
+    w.m = (int)(q1.x & 0xffffu);
+    w.work = (int)((q1.x >> 16) & 0xffu);
+    w.grp = (int)(q1.x >> 24);
+    w.lead = (int)(q1.y & 0xffu);
+    w.first = decode_piece(q2, q3);
+    return w;
+}
+
+// ----------------------------------------------------------------------------------------
 // one wave streams its pieces; returns the forward partial sum of row (lane % P)
 // ----------------------------------------------------------------------------------------
 template <typename T, int L, int P, bool FWD, bool TRN>
-__device__ __forceinline__ T run_panel(const WaveWork *__restrict__ wp,
-                                       const Piece *__restrict__ pieces,
-                                       const uint4 *__restrict__ values,
+__device__ __forceinline__ T run_panel(const WaveD &wd, const uint4 *__restrict__ values,
                                        const int *__restrict__ rows, const int *__restrict__ cols,
                                        const T *__restrict__ x, T *__restrict__ y, T alpha,
                                        int flags, int lane, T *xs, T *vs) {
@@ -158,11 +198,7 @@ __device__ __forceinline__ T run_panel(const WaveWork *__restrict__ wp,
     constexpr int NC = G * L * E;  // columns covered per iteration
     const bool opT = (flags & FLAG_OPT) != 0;
     const bool cjf = (flags & FLAG_CONJ) != 0;
-    const int m = wp->m;
-    const int npieces = wp->npieces;
-    const int rbase = wp->rbase;
-    const int row_off = wp->row_off;
-    const int piece_begin = wp->piece_begin;
+    const int m = wd.m;
     const int i = lane & (P - 1);
     const int g = lane / P;
     const bool row_ok = i < m;
@@ -170,21 +206,20 @@ __device__ __forceinline__ T run_panel(const WaveWork *__restrict__ wp,
     T acc = zero_of(T{});
     T xr = zero_of(T{});
     if (TRN && row_ok) {
-        const int ri = (rbase >= 0) ? rbase + i : rows[row_off + i];
+        const int ri = (wd.rbase >= 0) ? wd.rbase + i : rows[wd.row_off + i];
         xr = x[ri];
     }
 
-    for (int pi = 0; pi < npieces; ++pi) {
-        const Piece *pp = (pi == 0) ? &wp->first : (pieces + piece_begin + pi - 1);
-        const uint64_t val_off = pp->val_off;
-        const int xbase = pp->xbase;
-        const int col_off = pp->col_off;
-        const int nstrips = pp->nstrips;
-        const int ncols = pp->ncols;
-        const int kind = pp->kind;
-        const bool fwd_en = FWD && (!opT || kind == KIND_OFF);
-        const bool trn_en = TRN && (opT || kind == KIND_OFF);
-        const Vec16<T> *vb = reinterpret_cast<const Vec16<T> *>(values + val_off);
+    const PieceD pc = wd.first;
+    if (wd.npieces > 0) {
+        const int xbase = pc.xbase;
+        const int col_off = pc.col_off;
+        const int nstrips = pc.nstrips;
+        const int ncols = pc.ncols;
+        const bool fwd_en = FWD && (!opT || pc.kind == KIND_OFF);
+        const bool trn_en = TRN && (opT || pc.kind == KIND_OFF);
+        const Vec16<T> *__restrict__ vb = reinterpret_cast<const Vec16<T> *>(
+            values + (((uint64_t)pc.val_hi << 32) | pc.val_lo));
 
         for (int s0 = 0; s0 < nstrips; s0 += G * L) {
             Vec16<T> b[L];
@@ -192,13 +227,15 @@ __device__ __forceinline__ T run_panel(const WaveWork *__restrict__ wp,
             for (int l = 0; l < L; ++l) {
                 const int s = s0 + l * G + g;
                 if (row_ok && s < nstrips) {
-                    b[l] = vb[(size_t)s * m + i];
+                    b[l] = vb[(uint32_t)(s * m + i)];
                 } else {
 #pragma unroll
                     for (int e = 0; e < E; ++e) b[l].v[e] = zero_of(T{});
                 }
             }
             if (fwd_en) {
+                // x slice of this iteration: gathered once per wave into LDS (contiguous range
+                // or through the merged column list), then read back as 16-byte broadcasts
 #pragma unroll
                 for (int c = lane; c < NC; c += 64) {
                     const int w = s0 * E + c;
@@ -253,8 +290,7 @@ __device__ __forceinline__ T run_panel(const WaveWork *__restrict__ wp,
 
 template <typename T, int L, bool FWD, bool TRN>
 __global__ void __launch_bounds__(256)
-    panel_kernel(const WaveWork *__restrict__ waves, const Piece *__restrict__ pieces,
-                 const uint4 *__restrict__ values, const int *__restrict__ rows,
+    panel_kernel(const WaveWork *__restrict__ waves, const uint4 *__restrict__ values, const int *__restrict__ rows,
                  const int *__restrict__ cols, const T *__restrict__ x, T *__restrict__ y, T alpha,
                  T beta, int flags) {
     constexpr int E = TT<T>::E;
@@ -265,32 +301,30 @@ __global__ void __launch_bounds__(256)
 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    const WaveWork *wp = waves + ((size_t)blockIdx.x * kWavesPerWg + wave);
-    const int work = wp->work;
-    const int m = wp->m;
+    const WaveD wd = load_wave(waves + ((size_t)blockIdx.x * kWavesPerWg + wave));
+    const int work = wd.work;
+    const int m = wd.m;
 
     T u = zero_of(T{});
     if (work == WORK_PANEL) {
         if (m <= 8)
-            u = run_panel<T, L, 8, FWD, TRN>(wp, pieces, values, rows, cols, x, y, alpha, flags, lane, xs[wave], vs[wave]);
+            u = run_panel<T, L, 8, FWD, TRN>(wd, values, rows, cols, x, y, alpha, flags, lane, xs[wave], vs[wave]);
         else if (m <= 16)
-            u = run_panel<T, L, 16, FWD, TRN>(wp, pieces, values, rows, cols, x, y, alpha, flags, lane, xs[wave], vs[wave]);
+            u = run_panel<T, L, 16, FWD, TRN>(wd, values, rows, cols, x, y, alpha, flags, lane, xs[wave], vs[wave]);
         else if (m <= 32)
-            u = run_panel<T, L, 32, FWD, TRN>(wp, pieces, values, rows, cols, x, y, alpha, flags, lane, xs[wave], vs[wave]);
+            u = run_panel<T, L, 32, FWD, TRN>(wd, values, rows, cols, x, y, alpha, flags, lane, xs[wave], vs[wave]);
         else
-            u = run_panel<T, L, 64, FWD, TRN>(wp, pieces, values, rows, cols, x, y, alpha, flags, lane, xs[wave], vs[wave]);
+            u = run_panel<T, L, 64, FWD, TRN>(wd, values, rows, cols, x, y, alpha, flags, lane, xs[wave], vs[wave]);
     }
     const bool direct = (flags & FLAG_DIRECT) != 0;
     const bool sz = (flags & FLAG_STRONG_ZERO) != 0;
     if (FWD) {
-        const int grp = wp->grp;
         red[wave][lane] = u;
         __syncthreads();
-        if (work == WORK_PANEL && wp->lead) {
-            for (int k = 1; k < grp; ++k) u = add(u, red[wave + k][lane]);
+        if (work == WORK_PANEL && wd.lead) {
+            for (int k = 1; k < wd.grp; ++k) u = add(u, red[wave + k][lane]);
             if (lane < m) {
-                const int rbase = wp->rbase;
-                const int yi = (rbase >= 0) ? rbase + lane : rows[wp->row_off + lane];
+                const int yi = (wd.rbase >= 0) ? wd.rbase + lane : rows[wd.row_off + lane];
                 const T val = mul(alpha, u);
                 if (direct) {
                     y[yi] = sz ? val : madd(val, beta, y[yi]);
@@ -301,9 +335,9 @@ __global__ void __launch_bounds__(256)
         }
     }
     if (work == WORK_SCALE && direct) {
-        const int rbase = wp->rbase;
-        const int cnt = wp->first.ncols;
-        for (int r = lane; r < cnt; r += 64) y[rbase + r] = sz ? zero_of(T{}) : mul(beta, y[rbase + r]);
+        const int cnt = wd.first.ncols;
+        for (int r = lane; r < cnt; r += 64)
+            y[wd.rbase + r] = sz ? zero_of(T{}) : mul(beta, y[wd.rbase + r]);
     }
 }
 
@@ -336,11 +370,10 @@ template <> bool is_one(double v) { return v == 1.0; }
 template <> bool is_one(c64 v) { return v.re == 1.f && v.im == 0.f; }
 template <> bool is_one(c128 v) { return v.re == 1.0 && v.im == 0.0; }
 
-template <typename T>
+template <typename T, int L>
 static hipError_t launch_typed(const DeviceImage &img, int op, const void *x, void *y,
                                const void *alpha_p, const void *beta_p, int strong_zero,
                                hipStream_t stream) {
-    constexpr int L = 8;
     const T alpha = load_scalar<T>(alpha_p, 1.0);
     const T beta = load_scalar<T>(beta_p, 0.0);
     const bool opT = (op != 0);
@@ -349,7 +382,6 @@ static hipError_t launch_typed(const DeviceImage &img, int op, const void *x, vo
     if (op == 2) flags |= FLAG_CONJ;
     if (opT) flags |= FLAG_OPT;
     const WaveWork *waves = (const WaveWork *)img.d_waves;
-    const Piece *pieces = (const Piece *)img.d_pieces;
     const uint4 *values = (const uint4 *)img.d_values;
     const int *rows = (const int *)img.d_rows;
     const int *cols = (const int *)img.d_cols;
@@ -363,7 +395,7 @@ static hipError_t launch_typed(const DeviceImage &img, int op, const void *x, vo
         flags |= FLAG_DIRECT;
         if (img.nwg_total > 0)
             hipLaunchKernelGGL((panel_kernel<T, L, true, false>), dim3((unsigned)img.nwg_total), block, 0,
-                               stream, waves, pieces, values, rows, cols, xd, yd, alpha, beta, flags);
+                               stream, waves, values, rows, cols, xd, yd, alpha, beta, flags);
         return hipGetLastError();
     }
     // accumulate mode: y .*= beta over the owned range, then hardware atomics
@@ -383,17 +415,17 @@ static hipError_t launch_typed(const DeviceImage &img, int op, const void *x, vo
         const dim3 grid((unsigned)img.nwg_main);
         if (!opT) {
             if (img.has_off)
-                hipLaunchKernelGGL((panel_kernel<T, L, true, true>), grid, block, 0, stream, waves, pieces,
+                hipLaunchKernelGGL((panel_kernel<T, L, true, true>), grid, block, 0, stream, waves,
                                    values, rows, cols, xd, yd, alpha, beta, flags);
             else
-                hipLaunchKernelGGL((panel_kernel<T, L, true, false>), grid, block, 0, stream, waves, pieces,
+                hipLaunchKernelGGL((panel_kernel<T, L, true, false>), grid, block, 0, stream, waves,
                                    values, rows, cols, xd, yd, alpha, beta, flags);
         } else {
             if (img.has_off)
-                hipLaunchKernelGGL((panel_kernel<T, L, true, true>), grid, block, 0, stream, waves, pieces,
+                hipLaunchKernelGGL((panel_kernel<T, L, true, true>), grid, block, 0, stream, waves,
                                    values, rows, cols, xd, yd, alpha, beta, flags);
             else
-                hipLaunchKernelGGL((panel_kernel<T, L, false, true>), grid, block, 0, stream, waves, pieces,
+                hipLaunchKernelGGL((panel_kernel<T, L, false, true>), grid, block, 0, stream, waves,
                                    values, rows, cols, xd, yd, alpha, beta, flags);
         }
     }
@@ -402,11 +434,23 @@ static hipError_t launch_typed(const DeviceImage &img, int op, const void *x, vo
 
 hipError_t launch_mul(const DeviceImage &img, int op, const void *x, void *y, const void *alpha,
                       const void *beta, int strong_zero, hipStream_t stream) {
+    static const int Lsel = [] {
+        const char *s = std::getenv("BSM_L");
+        return (s && std::atoi(s) == 16) ? 16 : 8;
+    }();
+    if (Lsel == 16) {
+        switch (img.dtype) {
+            case 0: return launch_typed<float, 16>(img, op, x, y, alpha, beta, strong_zero, stream);
+            case 1: return launch_typed<double, 16>(img, op, x, y, alpha, beta, strong_zero, stream);
+            case 2: return launch_typed<c64, 16>(img, op, x, y, alpha, beta, strong_zero, stream);
+            case 3: return launch_typed<c128, 16>(img, op, x, y, alpha, beta, strong_zero, stream);
+        }
+    }
     switch (img.dtype) {
-        case 0: return launch_typed<float>(img, op, x, y, alpha, beta, strong_zero, stream);
-        case 1: return launch_typed<double>(img, op, x, y, alpha, beta, strong_zero, stream);
-        case 2: return launch_typed<c64>(img, op, x, y, alpha, beta, strong_zero, stream);
-        case 3: return launch_typed<c128>(img, op, x, y, alpha, beta, strong_zero, stream);
+        case 0: return launch_typed<float, 8>(img, op, x, y, alpha, beta, strong_zero, stream);
+        case 1: return launch_typed<double, 8>(img, op, x, y, alpha, beta, strong_zero, stream);
+        case 2: return launch_typed<c64, 8>(img, op, x, y, alpha, beta, strong_zero, stream);
+        case 3: return launch_typed<c128, 8>(img, op, x, y, alpha, beta, strong_zero, stream);
     }
     return hipErrorInvalidValue;
 }

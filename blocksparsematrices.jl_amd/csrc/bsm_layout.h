@@ -1,19 +1,20 @@
 // bsm_layout.h -- device image layout shared by the host analysis and the HIP kernels.
 //
 // HBM layout (one allocation each, all owned by the handle):
-//   values : every stored matrix entry exactly once, in STRIP order.  A *piece* is a
-//            dense mc x n sub-block (mc <= 64 rows).  Its entries are stored as
-//            [strip s][row i][e], E = 16 / sizeof(T) columns per strip, so that one lane
-//            load is 16 bytes = E consecutive columns of one row, and one wave-instruction
-//            reads G = 64/P consecutive strips = G*mc*16 contiguous bytes
-//            (P = lanes per strip = max(8, nextpow2(mc))).  The last strip of a piece is
-//            zero-padded to E columns.
+//   values : every stored matrix entry exactly once, in STRIP order.  All blocks (of one
+//            kind) that live on the same <= 64 y rows form a ROW GROUP; they are
+//            concatenated column-wise into one merged mc x W panel (a VBCRS block row is one
+//            such panel).  Its entries are stored as [strip s][row i][e], E = 16 / sizeof(T)
+//            columns per strip, so that one lane load is 16 bytes = E consecutive columns of
+//            one row, and one wave-instruction reads G = 64/P consecutive strips =
+//            G*mc*16 contiguous bytes (P = lanes per strip = max(8, nextpow2(mc))).  The
+//            last strip of a panel is zero-padded to E columns.
 //   rows   : int32 0-based y/x index lists of row groups whose rows are not a contiguous
 //            range.
-//   cols   : int32 0-based index lists of pieces whose columns are not a contiguous range.
-//   pieces : Piece descriptors (32 B) -- second and later pieces of a wave's work list.
-//   waves  : WaveWork descriptors (64 B), 4 per workgroup, the first piece inline so a
-//            wave reaches its matrix bytes after ONE dependent load.
+//   cols   : int32 0-based merged column list of every row group (x index per panel column).
+//   waves  : WaveWork descriptors (64 B), 4 per workgroup.  A wave streams ONE piece = a
+//            strip range of one merged panel, described inline, so it reaches its matrix
+//            bytes after ONE dependent (scalar) load.
 #pragma once
 #include <cstdint>
 
@@ -34,7 +35,7 @@ enum : uint8_t {
 struct Piece {
     uint64_t val_off;  // offset into values, in 16-byte units
     int32_t xbase;     // >= 0: columns are the contiguous range starting here (0-based); -1: indexed
-    int32_t col_off;   // offset into cols pool of the first column (indexed pieces)
+    int32_t col_off;   // offset into cols pool of the first column
     int32_t nstrips;   // strips in this piece
     int32_t ncols;     // valid columns (<= nstrips * E)
     int32_t kind;      // KIND_*
@@ -43,8 +44,8 @@ struct Piece {
 static_assert(sizeof(Piece) == 32, "Piece must be 32 bytes");
 
 struct WaveWork {
-    int32_t piece_begin;  // pieces[piece_begin .. piece_begin + npieces - 1) follow the inline one
-    int32_t npieces;      // total pieces of this wave, inline one included
+    int32_t reserved0;
+    int32_t npieces;      // 0 (nothing to stream) or 1
     int32_t row_off;      // rows pool offset (indexed row groups)
     int32_t rbase;        // >= 0: rows are the contiguous range starting here (0-based); -1: indexed
     uint16_t m;           // rows of the group (1..64)

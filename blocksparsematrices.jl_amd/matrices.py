@@ -443,7 +443,7 @@ class MulPlan:
         self._base = base
         self._fn = L.lib().bsm_mul
         self._dev = y.device
-        self._args = [C.c_void_p(base._h.ptr), C.c_int(op), C.c_void_p(xp), C.c_void_p(yp),
+        self._args = [base._h.ptr, C.c_int(op), C.c_void_p(xp), C.c_void_p(yp),
                       C.c_void_p(self._a.ctypes.data), C.c_void_p(self._b.ctypes.data),
                       C.c_int(1 if strong else 0), C.c_int(L.BSM_MEM_DEVICE)]
 

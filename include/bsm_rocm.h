@@ -152,8 +152,8 @@ typedef struct {
 int bsm_stats(bsm_matrix_t A, bsm_stats_t *out);
 
 /* Debug / test hook: copies one array of the packed device image (host copy) out.
- * which: 0 values (bytes), 1 rows (int32), 2 cols (int32), 3 pieces (32-byte records),
- * 4 waves (64-byte records; layout in blocksparsematrices.jl_amd/csrc/bsm_layout.h).
+ * which: 0 values (bytes), 1 rows (int32), 2 cols (int32), 3 waves (64-byte records;
+ * layout in blocksparsematrices.jl_amd/csrc/bsm_layout.h).
  * Only available on analysis-only handles (BSM_DEVICE_NONE), which keep the host copy.
  * Call with out == NULL to obtain the size in bytes. */
 int bsm_get_image(bsm_matrix_t A, int which, void *out, int64_t *nbytes);

@@ -150,7 +150,7 @@ def scipy_mul(problem, op, x, y0, alpha=1, beta=0, strong=True):
 # ---- packed-image interpreter -------------------------------------------------------------------
 PIECE_DT = np.dtype([("val_off", "<u8"), ("xbase", "<i4"), ("col_off", "<i4"), ("nstrips", "<i4"),
                      ("ncols", "<i4"), ("kind", "<i4"), ("pad", "<i4")])
-WAVE_DT = np.dtype([("piece_begin", "<i4"), ("npieces", "<i4"), ("row_off", "<i4"), ("rbase", "<i4"),
+WAVE_DT = np.dtype([("reserved0", "<i4"), ("npieces", "<i4"), ("row_off", "<i4"), ("rbase", "<i4"),
                     ("m", "<u2"), ("work", "u1"), ("grp", "u1"), ("lead", "u1"), ("pad0", "u1", 3),
                     ("pad1", "<i4", 2), ("first", PIECE_DT)])
 assert PIECE_DT.itemsize == 32 and WAVE_DT.itemsize == 64
@@ -161,7 +161,7 @@ KIND_OFF = 2
 def get_image(A):
     from bsm_amd import _lib as L
     out = []
-    for which, dt in ((0, np.uint8), (1, np.int32), (2, np.int32), (3, PIECE_DT), (4, WAVE_DT)):
+    for which, dt in ((0, np.uint8), (1, np.int32), (2, np.int32), (3, WAVE_DT)):
         n = C.c_int64(0)
         L.check(L.lib().bsm_get_image(A._h.ptr, which, None, C.byref(n)))
         buf = np.zeros(max(n.value, 1), dtype=np.uint8)
@@ -173,7 +173,7 @@ def get_image(A):
 def interpret_image(A, op, x, y0, alpha=1, beta=0, strong=True):
     """Executes the packed image the way the HIP kernel walks it (same descriptors and index
     arithmetic, numpy arithmetic) -- checks packing + schedule on CPU."""
-    values, rows, cols, pieces, waves = get_image(A)
+    values, rows, cols, waves = get_image(A)
     dt = A.dtype
     E = 16 // dt.itemsize
     vals = values.view(dt)
@@ -186,8 +186,7 @@ def interpret_image(A, op, x, y0, alpha=1, beta=0, strong=True):
         y[:] = 0 if strong else beta * y
     assert len(waves) % 4 == 0
     pw = waves[waves["work"] == WORK_PANEL]
-    has_off = bool(np.any(pw["first"]["kind"][pw["npieces"] > 0] == KIND_OFF) or
-                   np.any((pieces["kind"] == KIND_OFF) & (pieces["nstrips"] > 0)))
+    has_off = bool(np.any(pw["first"]["kind"][pw["npieces"] > 0] == KIND_OFF))
     fwd_kernel = (not opT) or has_off  # the launcher's choice of the FWD template flag
     for wg in range(len(waves) // 4):
         us = [None] * 4
@@ -204,8 +203,9 @@ def interpret_image(A, op, x, y0, alpha=1, beta=0, strong=True):
             ridx = (np.arange(W["rbase"], W["rbase"] + m) if W["rbase"] >= 0
                     else rows[W["row_off"]:W["row_off"] + m])
             u = np.zeros(m, dtype=dt)
+            assert int(W["npieces"]) in (0, 1)
             for pi in range(int(W["npieces"])):
-                P = W["first"] if pi == 0 else pieces[W["piece_begin"] + pi - 1]
+                P = W["first"]
                 ns, nc = int(P["nstrips"]), int(P["ncols"])
                 base = int(P["val_off"]) * 16 // dt.itemsize
                 full = vals[base:base + ns * m * E].reshape(ns, m, E).transpose(1, 0, 2).reshape(m, ns * E)

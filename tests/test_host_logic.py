@@ -249,7 +249,7 @@ def test_own_range_limits_scale_work(bsm):
     A = bsm.VariableBlockCompressedRowStorage(p["blocks"], p["rowstart"], p["colstart"], p["size"],
                                               device=NODEV, own=(501, 1000))
     from _common import WORK_SCALE, get_image
-    waves = get_image(A)[4]
+    waves = get_image(A)[3]
     sc = waves[waves["work"] == WORK_SCALE]
     assert len(sc) > 0
     assert sc["rbase"].min() >= 500 and (sc["rbase"] + sc["first"]["ncols"]).max() <= 1000

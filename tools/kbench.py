@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Kernel micro-benchmark (developer tool): times warm/cold mul! launches of one config under the
+current BSM_* environment knobs.  usage: kbench.py [c2|c3|c3s|c4s|c5s] [reps] [T]"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+import bsm_amd as bsm
+
+which = sys.argv[1] if len(sys.argv) > 1 else "c2"
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 300
+S = bsm.synthetic
+prob = {"c2": lambda: S.config2(), "c3": lambda: S.config3(), "c3s": lambda: S.config3(nseg=800),
+        "c4s": lambda: S.config4(row_lo=0, row_hi=1953),
+        "c2t": lambda: S.config2(n=6000, lo=1, hi=1, nblocks=14000),
+        "c2u": lambda: S.config2(n=100000, lo=36, hi=36, nblocks=5000),
+        "c2p": lambda: S.config2(n=100000, lo=32, hi=32, nblocks=6400),
+        "c2w": lambda: S.config2(n=100000, lo=64, hi=64, nblocks=1650), "c5s": lambda: S.config5(n=600_000)}[which]()
+A = S.build(prob)
+st = A.stats()
+x = torch.from_numpy(prob["x"]).cuda()
+ops = [("N", A)]
+if len(sys.argv) > 3 and sys.argv[3] == "T":
+    ops.append(("T", bsm.transpose(A)))
+for name, Aop in ops:
+    y = torch.zeros(bsm.size(Aop)[0], dtype=x.dtype, device="cuda")
+    plan = bsm.MulPlan(y, Aop, x)
+    for _ in range(20):
+        plan()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        plan()
+    b.record()
+    torch.cuda.synchronize()
+    warm = a.elapsed_time(b) * 1e-3 / reps
+    flush = torch.empty(512 << 20, dtype=torch.uint8, device="cuda")
+    cold = []
+    for _ in range(15):
+        flush.fill_(1)
+        a.record()
+        plan()
+        b.record()
+        torch.cuda.synchronize()
+        cold.append(a.elapsed_time(b) * 1e-3)
+    cold.sort()
+    del flush
+    knobs = {k: v for k, v in os.environ.items() if k.startswith("BSM_")}
+    print(f"{which} op={name} {knobs} wgs={st['nworkgroups']} tasks={st['ntasks']} excl={st['exclusive']} "
+          f"warm={warm * 1e6:.2f}us ({st['alg_bytes'] / warm / 1e9:.0f} GB/s) "
+          f"cold={cold[len(cold) // 2] * 1e6:.2f}us ({st['alg_bytes'] / cold[len(cold) // 2] / 1e9:.0f} GB/s)",
+          flush=True)
