@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
+#include <type_traits>
 
 #include "bsm_kernels.h"
 #include "bsm_layout.h"
@@ -288,8 +289,10 @@ __device__ __forceinline__ T run_panel(const WaveD &wd, const uint4 *__restrict_
     return acc;
 }
 
+// forward-only instances fit 64 VGPRs (8 waves per SIMD: every workgroup of a C2-sized
+// launch is resident at once); the fused forward+transposed instances need ~100.
 template <typename T, int L, bool FWD, bool TRN>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((!TRN && L <= 8 && !std::is_same<T, c64>::value) ? 8 : 4)))
     panel_kernel(const WaveWork *__restrict__ waves, const uint4 *__restrict__ values, const int *__restrict__ rows,
                  const int *__restrict__ cols, const T *__restrict__ x, T *__restrict__ y, T alpha,
                  T beta, int flags) {
@@ -434,18 +437,6 @@ static hipError_t launch_typed(const DeviceImage &img, int op, const void *x, vo
 
 hipError_t launch_mul(const DeviceImage &img, int op, const void *x, void *y, const void *alpha,
                       const void *beta, int strong_zero, hipStream_t stream) {
-    static const int Lsel = [] {
-        const char *s = std::getenv("BSM_L");
-        return (s && std::atoi(s) == 16) ? 16 : 8;
-    }();
-    if (Lsel == 16) {
-        switch (img.dtype) {
-            case 0: return launch_typed<float, 16>(img, op, x, y, alpha, beta, strong_zero, stream);
-            case 1: return launch_typed<double, 16>(img, op, x, y, alpha, beta, strong_zero, stream);
-            case 2: return launch_typed<c64, 16>(img, op, x, y, alpha, beta, strong_zero, stream);
-            case 3: return launch_typed<c128, 16>(img, op, x, y, alpha, beta, strong_zero, stream);
-        }
-    }
     switch (img.dtype) {
         case 0: return launch_typed<float, 8>(img, op, x, y, alpha, beta, strong_zero, stream);
         case 1: return launch_typed<double, 8>(img, op, x, y, alpha, beta, strong_zero, stream);
