@@ -27,6 +27,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X spec (MI355X_MICROARCH.md); measured-copy ceiling 6290
+# HBM-side bytes of one C2 launch from the PMC passes (profiles/r01_c2_pmc_summary.txt):
+# FETCH_SIZE 27773.6 KiB x 2 (gfx950 counts 128-B requests as 64 B) + WRITE_SIZE 842.0 KiB
+TRAFFIC_BYTES_PER_LAUNCH = 57_742_000
 
 
 def main():
@@ -114,15 +117,19 @@ def main():
         launch = "eager"
 
     # ---- timed region: EXACTLY K steps ----------------------------------------------------------------
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     barrier()
     t0 = time.perf_counter()
+    ev0.record()  # HIP events on the stream the kernels are launched on
     if graph is not None:
         graph.replay()
     else:
         for _ in range(args.steps):
             step()
+    ev1.record()
     barrier()
     elapsed = time.perf_counter() - t0
+    dev_elapsed = ev0.elapsed_time(ev1) * 1e-3
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -134,24 +141,19 @@ def main():
         total_bytes = float(alg_bytes)
     value = total_bytes * args.steps / elapsed / 1e9
 
-    # ---- roofline of the dominant kernel: per-launch HIP events on the launch stream ---------------
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(200)]
-    torch.cuda.synchronize()
-    for a, b_ in ev:
-        a.record()
-        plan()
-        b_.record()
-    torch.cuda.synchronize()
-    durs = sorted(a.elapsed_time(b_) * 1e-3 for a, b_ in ev)  # seconds
-    kdur = sum(durs) / len(durs)
-    kmed = durs[len(durs) // 2]
+    # ---- roofline of the dominant kernel --------------------------------------------------------
+    # one step == one launch of bsm::panel_kernel<double,8,true,false>; its average duration is
+    # the HIP-event time of the timed region / K (back-to-back launches on one stream; the
+    # rocprofv3 --kernel-trace average in profiles/ must agree).
+    kdur = dev_elapsed / args.steps
     achieved = alg_bytes / kdur / 1e9
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": TRAFFIC_BYTES_PER_LAUNCH,
                 "kernel": "bsm::panel_kernel<double,8,true,false>",
                 "alg_bytes_per_launch": int(alg_bytes), "avg_launch_us": round(kdur * 1e6, 3),
-                "median_launch_us": round(kmed * 1e6, 3),
-                "note": "warm: the 54 MB operator stays in the 256 MiB Infinity Cache between launches"}
+                "note": "warm: the 54 MB operator stays in the 256 MiB Infinity Cache between launches; "
+                        "traffic = rocprofv3 FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE per launch, "
+                        "profiles/r01_c2_pmc_summary.txt"}
 
     extra = {}
     if args.cold and rank == 0:

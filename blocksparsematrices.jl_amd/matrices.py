@@ -247,7 +247,7 @@ class BlockSparseMatrix(AbstractBlockMatrix):
     colors, transposecolors, scheduler."""
 
     def __init__(self, blocks, rowindices, colindices, size, cols=None, *, scheduler=None,
-                 coloringalgorithm=None, device=None, accumulate="auto"):
+                 coloringalgorithm=None, device=None, accumulate="auto", own=None):
         if cols is not None:  # (blocks, rowindices, colindices, rows, cols) form, :81-89
             size = (size, cols)
         scheduler = SerialScheduler() if scheduler is None else scheduler
@@ -265,7 +265,7 @@ class BlockSparseMatrix(AbstractBlockMatrix):
         n = _i64([b.shape[1] for b in self.blocks])
         ld = _i64([max(b.shape[0], 1) for b in self.blocks])
         dev = _default_device() if device is None else device
-        o = _options(scheduler, dev, accumulate)
+        o = _options(scheduler, dev, accumulate, own)
         h = C.c_void_p()
         I = C.POINTER(C.c_int64)
         L.check(L.lib().bsm_blocksparse_create(
@@ -282,7 +282,7 @@ class SymmetricBlockMatrix(AbstractBlockMatrix):
     DynamicScheduler() (:80)."""
 
     def __init__(self, diagonals, diagonalindices, offdiagonals, rowindices, colindices, size,
-                 cols=None, *, scheduler=None, device=None, accumulate="auto"):
+                 cols=None, *, scheduler=None, device=None, accumulate="auto", own=None):
         if cols is not None:  # rows, cols form defaults to SerialScheduler() (:102)
             size = (size, cols)
             scheduler = SerialScheduler() if scheduler is None else scheduler
@@ -308,7 +308,7 @@ class SymmetricBlockMatrix(AbstractBlockMatrix):
         n = _i64([b.shape[1] for b in self.offdiagonals])
         ld = _i64([max(b.shape[0], 1) for b in self.offdiagonals])
         dev = _default_device() if device is None else device
-        o = _options(scheduler, dev, accumulate)
+        o = _options(scheduler, dev, accumulate, own)
         h = C.c_void_p()
         I = C.POINTER(C.c_int64)
         L.check(L.lib().bsm_symmetric_create(

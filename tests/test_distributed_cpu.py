@@ -1,0 +1,127 @@
+"""CPU suite, part 3: the N > 1 path over `gloo` with world_size 2 (and 3).
+
+No GPU exists here, so each rank's LOCAL product is executed by the packed-image interpreter of
+tests/_common.py (the same image the HIP kernel walks); everything else -- the block-row partition,
+the ownership ranges handed to the C ABI, the point-to-point halo reduce of the symmetric path and
+the y all-gather -- is the real code of blocksparsematrices.jl_amd/distributed.py.
+"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+NODEV = -2
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, kind, q):
+    try:
+        sys.path.insert(0, ROOT)
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        import bsm_amd as bsm
+        from bsm_amd import distributed as D
+        from _common import N, interpret_image, oracle_mul, relerr
+        from oracle import load_oracle
+
+        if kind == "vbcrs":
+            prob = bsm.synthetic.config2(n=5000, nblocks=300)
+            local, own = D.split_vbcrs(prob, rank, world)
+            touched = own
+        else:
+            prob = bsm.synthetic.config5(n=5000, lo=16, hi=96, halfband=3)
+            local, own, touched = D.split_symmetric(prob, rank, world)
+        # `own` = the rows this handle is responsible for scaling by beta (C ABI bsm_options.own_lo/hi)
+        A = bsm.synthetic.build(local, device=NODEV, own=touched)
+        n = prob["size"][0]
+        x = torch.from_numpy(prob["x"].copy())
+        y0 = np.random.default_rng(7).standard_normal(n)
+
+        def local_mul(yy, xx, alpha, beta):
+            strong = beta is False
+            a = 1 if alpha is True else alpha
+            b = 0 if strong else (1 if beta is True else beta)
+            out = interpret_image(A, N, xx.numpy(), yy.numpy(), a, b, strong)
+            if kind == "vbcrs":
+                lo, hi = own  # the handle only writes the rows it owns
+                yy[lo - 1:hi] = torch.from_numpy(out[lo - 1:hi])
+            else:
+                lo, hi = touched
+                yy[lo - 1:hi] = torch.from_numpy(out[lo - 1:hi])
+            return yy
+
+        P = D.RowPartitioned(A, own, touched, gather=True)
+        results = []
+        for alpha, beta in ((True, False), (0.5, -2.0)):
+            y = torch.from_numpy(y0.copy())
+            P.mul(y, x, alpha, beta, local_mul=local_mul)
+            results.append(y.numpy().copy())
+        if rank == 0:
+            orc = load_oracle()
+            errs = []
+            for (alpha, beta), got in zip(((1, 0), (0.5, -2.0)), results):
+                ref = oracle_mul(orc, prob, N, prob["x"], y0, alpha, beta, strong=(beta == 0))
+                errs.append(relerr(got, ref))
+            q.put(("ok", errs, own, touched))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put(("err", traceback.format_exc(), None, None))
+        raise
+
+
+@pytest.mark.parametrize("kind,world", [("vbcrs", 2), ("symmetric", 2), ("symmetric", 3)])
+def test_row_partitioned_over_gloo(kind, world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, kind, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    status, errs, own, touched = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=120)
+    assert status == "ok", errs
+    assert all(e < 1e-12 for e in errs), errs
+    assert all(p.exitcode == 0 for p in procs)
+
+
+def test_partition_is_a_partition():
+    sys.path.insert(0, ROOT)
+    import bsm_amd as bsm
+    from bsm_amd import distributed as D
+    prob = bsm.synthetic.config2(n=8000, nblocks=500)
+    seen, prev_hi = 0, 0
+    for r in range(4):
+        local, own = D.split_vbcrs(prob, r, 4)
+        seen += len(local["blocks"])
+        assert own[0] == prev_hi + 1
+        prev_hi = own[1]
+        for rs, b in zip(local["rowstart"], local["blocks"]):
+            assert own[0] <= rs and rs + b.shape[0] - 1 <= own[1]
+    assert seen == len(prob["blocks"]) and prev_hi == 8000
+    sp = bsm.synthetic.config3(nseg=30, bs=16, halfband=4)
+    nd = no = 0
+    for r in range(3):
+        local, own, touched = D.split_symmetric(sp, r, 3)
+        nd += len(local["diagonals"])
+        no += len(local["offdiagonals"])
+        assert touched[0] <= own[0] and touched[1] >= own[1]
+    assert nd == len(sp["diagonals"]) and no == len(sp["offdiagonals"])
+    assert D.balanced_cuts([1, 1, 1, 1], 2) == [0, 2, 4]
