@@ -132,6 +132,7 @@ struct Item {
     int64_t s_begin, s_end;  // strips of the group's merged panel
     int64_t bytes;
     int nw;
+    int32_t color;
 };
 
 template <typename U>
@@ -325,6 +326,46 @@ std::string Analysis::build(int mtype_, int dtype_, int64_t nrows_, int64_t ncol
         if (any_off) excl = false;
     }
     exclusive_fwd = excl;
+    const bool colored = (opt.accumulate == 2);
+    std::vector<int32_t> group_color(groups.size(), 0);
+    int32_t ncolors_fused = 1;
+    if (colored) {
+        exclusive_fwd = false;
+        // fused conflict lists: a row group writes its rows (forward) and its columns (transposed)
+        std::vector<std::vector<int64_t>> lists(groups.size());
+        std::vector<const int64_t *> lp(groups.size());
+        std::vector<int64_t> ln(groups.size());
+        for (size_t g = 0; g < groups.size(); g++) {
+            const Group &G = groups[g];
+            auto &l = lists[g];
+            for (int i = 0; i < G.mc; i++)
+                l.push_back(1 + ((G.rbase >= 0) ? (int64_t)G.rbase + i : rows[G.row_off + i]));
+            const size_t nrow = l.size();
+            {
+                std::vector<int64_t> r(l.begin(), l.end());
+                std::sort(r.begin(), r.end());
+                if (std::adjacent_find(r.begin(), r.end()) != r.end())
+                    return "coloured accumulation: a block repeats a row index (use atomic mode)";
+            }
+            std::vector<int64_t> c;
+            for (int64_t k = 0; k < G.width; k++) c.push_back(1 + (int64_t)cols[G.col_off + k]);
+            std::sort(c.begin(), c.end());
+            if (std::adjacent_find(c.begin(), c.end()) != c.end())
+                return "coloured accumulation: blocks sharing rows repeat a column index (use atomic mode)";
+            // columns live in x-space for op N and in y-space for op T; rows the other way round.
+            // One colouring must serve every op, so rows and columns share one index space only
+            // when the matrix is square-indexed (symmetric); otherwise offset the columns.
+            const int64_t off = sym ? 0 : std::max(nrows, ncols) + 1;
+            for (int64_t v : c) l.push_back(v + off);
+            (void)nrow;
+            lp[g] = l.data();
+            ln[g] = (int64_t)l.size();
+        }
+        auto classes = color_dsatur(lp, ln);
+        ncolors_fused = (int32_t)classes.size();
+        for (size_t c = 0; c < classes.size(); c++)
+            for (int64_t id : classes[c]) group_color[id - 1] = (int32_t)c;
+    }
 
     // ---- pack values ---------------------------------------------------------------------
     values.assign((size_t)val_units * 16, 0);
@@ -355,7 +396,7 @@ std::string Analysis::build(int mtype_, int dtype_, int64_t nrows_, int64_t ncol
         const Group &G = groups[g];
         const int64_t strip_bytes = (int64_t)G.mc * 16;
         int64_t per_item = G.strips;
-        if (!exclusive_fwd) {
+        if (!exclusive_fwd && !colored) {
             int64_t maxs = std::max<int64_t>(1, tun.wgitem_max_bytes / strip_bytes);
             int64_t nitem = (G.strips + maxs - 1) / maxs;
             per_item = (G.strips + nitem - 1) / nitem;
@@ -367,10 +408,12 @@ std::string Analysis::build(int mtype_, int dtype_, int64_t nrows_, int64_t ncol
             it.s_end = std::min(G.strips, s + per_item);
             it.bytes = (it.s_end - it.s_begin) * strip_bytes;
             it.nw = it.bytes >= tun.split4_bytes ? 4 : (it.bytes >= tun.split2_bytes ? 2 : 1);
+            it.color = group_color[g];
             items.push_back(it);
         }
     }
     std::stable_sort(items.begin(), items.end(), [](const Item &a, const Item &b) {
+        if (a.color != b.color) return a.color < b.color;
         if (a.nw != b.nw) return a.nw > b.nw;
         return a.bytes > b.bytes;
     });
@@ -385,7 +428,15 @@ std::string Analysis::build(int mtype_, int dtype_, int64_t nrows_, int64_t ncol
         w.rbase = -1;
         waves.push_back(w);
     };
+    color_wg_ptr.clear();
+    int32_t cur_color = -1;
     for (const Item &it : items) {
+        if (colored && it.color != cur_color) {  // a colour class starts on a workgroup boundary
+            while (waves.size() % kWavesPerWg) emit_nop();
+            while ((int32_t)color_wg_ptr.size() <= it.color)
+                color_wg_ptr.push_back((int64_t)waves.size() / kWavesPerWg);
+            cur_color = it.color;
+        }
         // align the start of a multi-wave item to its group size inside the workgroup
         while ((int)(waves.size() % kWavesPerWg) % it.nw != 0) emit_nop();
         const Group &G = groups[it.group];
@@ -426,6 +477,9 @@ std::string Analysis::build(int mtype_, int dtype_, int64_t nrows_, int64_t ncol
     }
     while (waves.size() % kWavesPerWg) emit_nop();
     nwg_main = (int64_t)waves.size() / kWavesPerWg;
+    if (colored) {
+        while ((int32_t)color_wg_ptr.size() <= ncolors_fused) color_wg_ptr.push_back(nwg_main);
+    }
 
     // ---- scale work for rows no group covers (exclusive forward launch) -------------------
     if (exclusive_fwd) {

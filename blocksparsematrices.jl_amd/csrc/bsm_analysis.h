@@ -32,6 +32,7 @@ struct Tunables {
 struct AnalysisOptions {
     int scheduler = 0;   // 0 serial, 1 dynamic (colour like the reference)
     int validate = 1;
+    int accumulate = 0;  // 0 auto, 1 atomic, 2 coloured launches (bitwise reproducible)
     int64_t own_lo = 0, own_hi = 0;  // 1-based inclusive, 0,0 = all rows
 };
 
@@ -63,6 +64,9 @@ class Analysis {
     int64_t nwg_total = 0;  // + workgroups of scale work (exclusive forward launch only)
     int64_t ngroups = 0;
     bool exclusive_fwd = false;  // every y row is produced by at most one row group
+    // coloured mode: workgroups [color_wg_ptr[c], color_wg_ptr[c+1]) form launch c; the row groups
+    // of one launch touch pairwise disjoint y entries (rows and columns), for every op
+    std::vector<int64_t> color_wg_ptr;
 
     // Builds everything.  Returns "" on success, else an error message.
     std::string build(int mtype, int dtype, int64_t nrows, int64_t ncols,

@@ -72,9 +72,7 @@ int read_options(const bsm_options *opts, bsm_options &o) {
             return fail(BSM_ERR_INVALID, "bsm_options.struct_size mismatch (call bsm_options_default)");
         o = *opts;
     }
-    if (o.accumulate == BSM_ACC_COLORED)
-        return fail(BSM_ERR_UNSUPPORTED, "BSM_ACC_COLORED is not implemented yet");
-    if (o.accumulate != BSM_ACC_AUTO && o.accumulate != BSM_ACC_ATOMIC)
+    if (o.accumulate != BSM_ACC_AUTO && o.accumulate != BSM_ACC_ATOMIC && o.accumulate != BSM_ACC_COLORED)
         return fail(BSM_ERR_INVALID, "unknown accumulate mode");
     if (o.own_lo < 0 || o.own_hi < 0 || (o.own_hi > 0 && o.own_hi < o.own_lo))
         return fail(BSM_ERR_INVALID, "bad own_lo/own_hi");
@@ -112,6 +110,7 @@ int finish_create(bsm_matrix_s *A, const bsm_options &o, bsm_matrix_t *out) {
     for (const WaveWork &w : an.waves)
         if (w.work == WORK_PANEL && w.npieces > 0 && w.first.kind == KIND_OFF) img.has_off = true;
     if (!img.exclusive_fwd) img.nwg_total = img.nwg_main;
+    img.color_wg_ptr.assign(an.color_wg_ptr.begin(), an.color_wg_ptr.end());
 
     if (o.device != BSM_DEVICE_NONE) {
         int dev = o.device;
@@ -156,6 +155,7 @@ AnalysisOptions to_aopt(const bsm_options &o) {
     AnalysisOptions a;
     a.scheduler = o.scheduler;
     a.validate = 1;  // indices are always range-checked: a bad index must never reach a kernel
+    a.accumulate = o.accumulate;
     a.own_lo = o.own_lo;
     a.own_hi = o.own_hi;
     return a;

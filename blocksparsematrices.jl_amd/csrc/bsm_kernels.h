@@ -3,6 +3,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <cstdint>
+#include <vector>
 
 namespace bsm {
 
@@ -17,6 +18,7 @@ struct DeviceImage {
     bool exclusive_fwd = false;
     bool has_off = false;  // SymmetricBlockMatrix off-diagonal pieces present
     long long device_bytes = 0;
+    std::vector<long long> color_wg_ptr;  // non-empty: coloured launches, plain read-modify-write
 };
 
 // Enqueues y = alpha*op(A)*x + beta*y on `stream`.  x, y device pointers.  No allocation,

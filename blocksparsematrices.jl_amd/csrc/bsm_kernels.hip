@@ -144,6 +144,7 @@ constexpr int FLAG_STRONG_ZERO = 1;
 constexpr int FLAG_DIRECT = 2;
 constexpr int FLAG_CONJ = 4;
 constexpr int FLAG_OPT = 8;
+constexpr int FLAG_RMW = 16;  // coloured launch: conflict-free by construction, plain read-modify-write
 
 // ----------------------------------------------------------------------------------------
 // descriptors: fetched as whole 16-byte words through a wave-uniform address (scalar loads),
@@ -276,7 +277,11 @@ __device__ __forceinline__ T run_panel(const WaveD &wd, const uint4 *__restrict_
                     const int w = s0 * E + c;
                     if (w < ncols) {
                         const int yi = (xbase >= 0) ? xbase + w : cols[col_off + w];
-                        atomic_acc(&y[yi], mul(alpha, vs[c]));
+                        const T val = mul(alpha, vs[c]);
+                        if (flags & FLAG_RMW)
+                            y[yi] = add(y[yi], val);
+                        else
+                            atomic_acc(&y[yi], val);
                     }
                 }
             }
@@ -295,7 +300,7 @@ template <typename T, int L, bool FWD, bool TRN>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((!TRN && L <= 8 && !std::is_same<T, c64>::value) ? 8 : 4)))
     panel_kernel(const WaveWork *__restrict__ waves, const uint4 *__restrict__ values, const int *__restrict__ rows,
                  const int *__restrict__ cols, const T *__restrict__ x, T *__restrict__ y, T alpha,
-                 T beta, int flags) {
+                 T beta, int flags, unsigned wg_base) {
     constexpr int E = TT<T>::E;
     constexpr int XS = 8 * L * E;
     __shared__ __attribute__((aligned(16))) T xs[kWavesPerWg][XS];
@@ -304,7 +309,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((!TRN 
 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    const WaveD wd = load_wave(waves + ((size_t)blockIdx.x * kWavesPerWg + wave));
+    const WaveD wd = load_wave(waves + ((size_t)(blockIdx.x + wg_base) * kWavesPerWg + wave));
     const int work = wd.work;
     const int m = wd.m;
 
@@ -331,6 +336,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((!TRN 
                 const T val = mul(alpha, u);
                 if (direct) {
                     y[yi] = sz ? val : madd(val, beta, y[yi]);
+                } else if (flags & FLAG_RMW) {
+                    y[yi] = add(y[yi], val);
                 } else {
                     atomic_acc(&y[yi], val);
                 }
@@ -398,7 +405,7 @@ static hipError_t launch_typed(const DeviceImage &img, int op, const void *x, vo
         flags |= FLAG_DIRECT;
         if (img.nwg_total > 0)
             hipLaunchKernelGGL((panel_kernel<T, L, true, false>), dim3((unsigned)img.nwg_total), block, 0,
-                               stream, waves, values, rows, cols, xd, yd, alpha, beta, flags);
+                               stream, waves, values, rows, cols, xd, yd, alpha, beta, flags, 0u);
         return hipGetLastError();
     }
     // accumulate mode: y .*= beta over the owned range, then hardware atomics
@@ -414,22 +421,31 @@ static hipError_t launch_typed(const DeviceImage &img, int op, const void *x, vo
         hipLaunchKernelGGL((scale_kernel<T>), dim3((unsigned)nblk), block, 0, stream, yd, lo, hi, beta,
                            strong_zero);
     }
-    if (img.nwg_main > 0) {
-        const dim3 grid((unsigned)img.nwg_main);
+    // one launch over every workgroup (atomics), or one launch per colour class (plain RMW:
+    // the classes touch pairwise disjoint y entries, so the result is bitwise reproducible)
+    const bool colored = !img.color_wg_ptr.empty();
+    if (colored) flags |= FLAG_RMW;
+    const size_t nlaunch = colored ? img.color_wg_ptr.size() - 1 : 1;
+    for (size_t c = 0; c < nlaunch; ++c) {
+        const long long wg0 = colored ? img.color_wg_ptr[c] : 0;
+        const long long wg1 = colored ? img.color_wg_ptr[c + 1] : img.nwg_main;
+        if (wg1 <= wg0) continue;
+        const dim3 grid((unsigned)(wg1 - wg0));
+        const unsigned wg_base = (unsigned)wg0;
         if (!opT) {
             if (img.has_off)
                 hipLaunchKernelGGL((panel_kernel<T, L, true, true>), grid, block, 0, stream, waves,
-                                   values, rows, cols, xd, yd, alpha, beta, flags);
+                                   values, rows, cols, xd, yd, alpha, beta, flags, wg_base);
             else
                 hipLaunchKernelGGL((panel_kernel<T, L, true, false>), grid, block, 0, stream, waves,
-                                   values, rows, cols, xd, yd, alpha, beta, flags);
+                                   values, rows, cols, xd, yd, alpha, beta, flags, wg_base);
         } else {
             if (img.has_off)
                 hipLaunchKernelGGL((panel_kernel<T, L, true, true>), grid, block, 0, stream, waves,
-                                   values, rows, cols, xd, yd, alpha, beta, flags);
+                                   values, rows, cols, xd, yd, alpha, beta, flags, wg_base);
             else
                 hipLaunchKernelGGL((panel_kernel<T, L, false, true>), grid, block, 0, stream, waves,
-                                   values, rows, cols, xd, yd, alpha, beta, flags);
+                                   values, rows, cols, xd, yd, alpha, beta, flags, wg_base);
         }
     }
     return hipGetLastError();

@@ -242,3 +242,27 @@ def test_run_to_run_determinism_of_exclusive_path(torch_cuda, bsm):
     a = gpu_mul(torch_cuda, bsm, A, N, x, np.zeros_like(x), 1, 0, True)
     for _ in range(3):
         assert np.array_equal(a, gpu_mul(torch_cuda, bsm, A, N, x, np.zeros_like(x), 1, 0, True))
+
+
+# ---- coloured accumulation: one launch per colour class, plain RMW, bitwise reproducible --------------
+@pytest.mark.parametrize("key", ["cuboid", "sphere"])
+def test_coloured_mode_parity_and_determinism(torch_cuda, bsm, oracle, key):
+    p = fixture_problem(key)
+    A = bsm.synthetic.build(p, accumulate="colored")
+    check_all(torch_cuda, bsm, oracle, p, A, np.complex128, host_too=False)
+    rng = np.random.default_rng(17)
+    n = p["size"][0]
+    x, y0 = rand_vec(rng, n, np.complex128), rand_vec(rng, n, np.complex128)
+    for op in OPS:
+        first = gpu_mul(torch_cuda, bsm, A, op, x, y0, 0.5, 2.0, False)
+        for _ in range(3):
+            assert np.array_equal(first, gpu_mul(torch_cuda, bsm, A, op, x, y0, 0.5, 2.0, False))
+
+
+def test_coloured_mode_config3_reduced(torch_cuda, bsm, oracle):
+    p = bsm.synthetic.config3(nseg=120)
+    A = bsm.synthetic.build(p, accumulate="colored")
+    check_all(torch_cuda, bsm, oracle, p, A, np.float64, host_too=False)
+    q = bsm.synthetic.config1()
+    B = bsm.synthetic.build(q, accumulate="colored")
+    check_all(torch_cuda, bsm, oracle, q, B, np.float64, host_too=False)

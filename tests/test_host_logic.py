@@ -253,3 +253,22 @@ def test_own_range_limits_scale_work(bsm):
     sc = waves[waves["work"] == WORK_SCALE]
     assert len(sc) > 0
     assert sc["rbase"].min() >= 500 and (sc["rbase"] + sc["first"]["ncols"]).max() <= 1000
+
+
+# ---- coloured accumulation (BSM_ACC_COLORED): launches of pairwise conflict-free row groups ----
+@pytest.mark.parametrize("key", ["cuboid", "sphere"])
+def test_coloured_mode_image_matches_oracle(bsm, oracle, key):
+    p = fixture_problem(key)
+    A = bsm.synthetic.build(p, device=NODEV, accumulate="colored")
+    assert A.stats()["exclusive"] == 0
+    _check_image(bsm, oracle, p, A, np.complex128)
+    q = bsm.synthetic.config1()
+    B = bsm.synthetic.build(q, device=NODEV, accumulate="colored")
+    _check_image(bsm, oracle, q, B, np.float64)
+
+
+def test_coloured_mode_rejects_repeated_indices(bsm):
+    with pytest.raises(RuntimeError, match="repeats a row index"):
+        bsm.BlockSparseMatrix([np.ones((2, 1))], [[3, 3]], [[1]], (4, 4), device=NODEV, accumulate="colored")
+    with pytest.raises(RuntimeError, match="repeat a column index"):
+        bsm.BlockSparseMatrix([np.ones((1, 2))], [[1]], [[2, 2]], (4, 4), device=NODEV, accumulate="colored")
