@@ -503,6 +503,11 @@ std::string Analysis::build(int mtype_, int dtype_, int64_t nrows_, int64_t ncol
         while (waves.size() % kWavesPerWg) emit_nop();
     }
     nwg_total = (int64_t)waves.size() / kWavesPerWg;
+    for (size_t wg = 0; wg + kWavesPerWg <= waves.size(); wg += kWavesPerWg) {
+        uint8_t sync = 0;
+        for (int w = 0; w < kWavesPerWg; w++) sync |= (waves[wg + w].work == WORK_PANEL && waves[wg + w].grp > 1);
+        for (int w = 0; w < kWavesPerWg; w++) waves[wg + w].wg_sync = sync;
+    }
     if (rows.empty()) rows.push_back(0);
     if (cols.empty()) cols.push_back(0);
     if (values.empty()) values.assign(16, 0);

@@ -155,7 +155,7 @@ struct PieceD {
     int xbase, col_off, nstrips, ncols, kind;
 };
 struct WaveD {
-    int npieces, row_off, rbase, m, work, grp, lead;
+    int npieces, row_off, rbase, m, work, grp, lead, wg_sync;
     PieceD first;
 };
 
@@ -182,6 +182,7 @@ __device__ __forceinline__ WaveD load_wave(const WaveWork *__restrict__ wp) {
     w.work = (int)((q1.x >> 16) & 0xffu);
     w.grp = (int)(q1.x >> 24);
     w.lead = (int)(q1.y & 0xffu);
+    w.wg_sync = (int)((q1.y >> 8) & 0xffu);
     w.first = decode_piece(q2, q3);
     return w;
 }
@@ -189,6 +190,9 @@ __device__ __forceinline__ WaveD load_wave(const WaveWork *__restrict__ wp) {
 // ----------------------------------------------------------------------------------------
 // one wave streams its pieces; returns the forward partial sum of row (lane % P)
 // ----------------------------------------------------------------------------------------
+// x slice staged per wave in LDS: 512 columns (256 for complex128), i.e. <= 4 KB
+template <typename T> constexpr int x_chunk_cols() { return sizeof(T) >= 16 ? 256 : 512; }
+
 template <typename T, int L, int P, bool FWD, bool TRN>
 __device__ __forceinline__ T run_panel(const WaveD &wd, const uint4 *__restrict__ values,
                                        const int *__restrict__ rows, const int *__restrict__ cols,
@@ -197,7 +201,9 @@ __device__ __forceinline__ T run_panel(const WaveD &wd, const uint4 *__restrict_
     constexpr int E = TT<T>::E;
     constexpr int G = 64 / P;
     constexpr int V = L * E;
-    constexpr int NC = G * L * E;  // columns covered per iteration
+    constexpr int NC = G * L * E;                        // columns covered per iteration
+    constexpr int XCH = x_chunk_cols<T>();                 // columns staged per x chunk
+    static_assert(XCH % NC == 0, "x chunk must hold whole iterations");
     const bool opT = (flags & FLAG_OPT) != 0;
     const bool cjf = (flags & FLAG_CONJ) != 0;
     const int m = wd.m;
@@ -205,7 +211,9 @@ __device__ __forceinline__ T run_panel(const WaveD &wd, const uint4 *__restrict_
     const int g = lane / P;
     const bool row_ok = i < m;
 
-    T acc = zero_of(T{});
+    T acc[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) acc[e] = zero_of(T{});
     T xr = zero_of(T{});
     if (TRN && row_ok) {
         const int ri = (wd.rbase >= 0) ? wd.rbase + i : rows[wd.row_off + i];
@@ -223,88 +231,106 @@ __device__ __forceinline__ T run_panel(const WaveD &wd, const uint4 *__restrict_
         const Vec16<T> *__restrict__ vb = reinterpret_cast<const Vec16<T> *>(
             values + (((uint64_t)pc.val_hi << 32) | pc.val_lo));
 
-        for (int s0 = 0; s0 < nstrips; s0 += G * L) {
-            Vec16<T> b[L];
+        for (int c0 = 0; c0 < ncols; c0 += XCH) {
+            if (fwd_en) {
+                // x slice of this chunk: gathered ONCE per wave into LDS (contiguous range or
+                // through the merged column list) while the first matrix loads are in flight,
+                // then read back as 16-byte broadcasts by every iteration of the chunk
 #pragma unroll
-            for (int l = 0; l < L; ++l) {
-                const int s = s0 + l * G + g;
-                if (row_ok && s < nstrips) {
-                    b[l] = vb[(uint32_t)(s * m + i)];
-                } else {
-#pragma unroll
-                    for (int e = 0; e < E; ++e) b[l].v[e] = zero_of(T{});
+                for (int k = 0; k < XCH / 64; ++k) {
+                    const int c = k * 64 + lane;
+                    const int w = c0 + c;
+                    if (w < ncols + NC) {  // zero the tail one iteration past the last column
+                        T xv = zero_of(T{});
+                        if (w < ncols) {
+                            const int xi = (xbase >= 0) ? xbase + w : cols[col_off + w];
+                            xv = x[xi];
+                        }
+                        xs[c] = xv;
+                    }
                 }
             }
-            if (fwd_en) {
-                // x slice of this iteration: gathered once per wave into LDS (contiguous range
-                // or through the merged column list), then read back as 16-byte broadcasts
-#pragma unroll
-                for (int c = lane; c < NC; c += 64) {
-                    const int w = s0 * E + c;
-                    T xv = zero_of(T{});
-                    if (w < ncols) {
-                        const int xi = (xbase >= 0) ? xbase + w : cols[col_off + w];
-                        xv = x[xi];
-                    }
-                    xs[c] = xv;
-                }
+            const int s_end = min(nstrips, (c0 + XCH) / E);
+            for (int s0 = c0 / E; s0 < s_end; s0 += G * L) {
+                // L independent 16-byte loads per lane: 8 KB per wave in flight.  (A software-
+                // pipelined variant with the next iteration's loads already in flight was measured
+                // and did not help: occupancy already provides the memory-level parallelism.)
+                Vec16<T> b[L];
 #pragma unroll
                 for (int l = 0; l < L; ++l) {
-                    const Vec16<T> xv = *reinterpret_cast<const Vec16<T> *>(&xs[(l * G + g) * E]);
+                    const int s = s0 + l * G + g;
+                    if (row_ok && s < nstrips) {
+                        b[l] = vb[(uint32_t)(s * m + i)];
+                    } else {
 #pragma unroll
-                    for (int e = 0; e < E; ++e) acc = madd(acc, cj(b[l].v[e], cjf), xv.v[e]);
-                }
-            }
-            if (trn_en) {
-                T vals[V];
-#pragma unroll
-                for (int l = 0; l < L; ++l)
-#pragma unroll
-                    for (int e = 0; e < E; ++e) vals[l * E + e] = mul(cj(b[l].v[e], cjf), xr);
-                int pos = 0, dup = 0;
-                Butterfly<T, V, 1, P>::run(vals, i, pos, dup);
-                constexpr int CF = (V / P) > 1 ? (V / P) : 1;
-                if ((i & dup) == 0) {
-#pragma unroll
-                    for (int j = 0; j < CF; ++j) {
-                        const int q = pos + j;  // original value index l*E + e
-                        const int l = q / E, e = q % E;
-                        vs[(l * G + g) * E + e] = vals[j];
+                        for (int e = 0; e < E; ++e) b[l].v[e] = zero_of(T{});
                     }
                 }
+                if (fwd_en) {
+                    const int cb = (s0 - c0 / E) * E;  // first column of this iteration inside the chunk
 #pragma unroll
-                for (int c = lane; c < NC; c += 64) {
-                    const int w = s0 * E + c;
-                    if (w < ncols) {
-                        const int yi = (xbase >= 0) ? xbase + w : cols[col_off + w];
-                        const T val = mul(alpha, vs[c]);
-                        if (flags & FLAG_RMW)
-                            y[yi] = add(y[yi], val);
-                        else
-                            atomic_acc(&y[yi], val);
+                    for (int l = 0; l < L; ++l) {
+                        const Vec16<T> xv = *reinterpret_cast<const Vec16<T> *>(&xs[cb + (l * G + g) * E]);
+#pragma unroll
+                        for (int e = 0; e < E; ++e) acc[e] = madd(acc[e], cj(b[l].v[e], cjf), xv.v[e]);
+                    }
+                }
+                if (trn_en) {
+                    T vals[V];
+#pragma unroll
+                    for (int l = 0; l < L; ++l)
+#pragma unroll
+                        for (int e = 0; e < E; ++e) vals[l * E + e] = mul(cj(b[l].v[e], cjf), xr);
+                    int pos = 0, dup = 0;
+                    Butterfly<T, V, 1, P>::run(vals, i, pos, dup);
+                    constexpr int CF = (V / P) > 1 ? (V / P) : 1;
+                    if ((i & dup) == 0) {
+#pragma unroll
+                        for (int j = 0; j < CF; ++j) {
+                            const int q = pos + j;  // original value index l*E + e
+                            const int l = q / E, e = q % E;
+                            vs[(l * G + g) * E + e] = vals[j];
+                        }
+                    }
+#pragma unroll
+                    for (int k = 0; k < (NC + 63) / 64; ++k) {
+                        const int c = k * 64 + lane;
+                        const int w = s0 * E + c;
+                        if (c < NC && w < ncols) {
+                            const int yi = (xbase >= 0) ? xbase + w : cols[col_off + w];
+                            const T val = mul(alpha, vs[c]);
+                            if (flags & FLAG_RMW)
+                                y[yi] = add(y[yi], val);
+                            else
+                                atomic_acc(&y[yi], val);
+                        }
                     }
                 }
             }
         }
     }
+    T a = acc[0];
     if (FWD) {
 #pragma unroll
-        for (int d = P; d < 64; d <<= 1) acc = add(acc, shx(acc, d));
+        for (int e = 1; e < E; ++e) a = add(a, acc[e]);
+#pragma unroll
+        for (int d = P; d < 64; d <<= 1) a = add(a, shx(a, d));
     }
-    return acc;
+    return a;
 }
 
-// forward-only instances fit 64 VGPRs (8 waves per SIMD: every workgroup of a C2-sized
-// launch is resident at once); the fused forward+transposed instances need ~100.
+// forward-only instances are held to 80 VGPRs (6 waves per SIMD = 1536 resident workgroups:
+// every workgroup of a C2-sized launch is resident at once); the fused instances need ~100.
 template <typename T, int L, bool FWD, bool TRN>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((!TRN && L <= 8 && !std::is_same<T, c64>::value) ? 8 : 4)))
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((!TRN && sizeof(T) == 8) ? 6 : 4)))
     panel_kernel(const WaveWork *__restrict__ waves, const uint4 *__restrict__ values, const int *__restrict__ rows,
                  const int *__restrict__ cols, const T *__restrict__ x, T *__restrict__ y, T alpha,
                  T beta, int flags, unsigned wg_base) {
     constexpr int E = TT<T>::E;
-    constexpr int XS = 8 * L * E;
-    __shared__ __attribute__((aligned(16))) T xs[kWavesPerWg][XS];
-    __shared__ __attribute__((aligned(16))) T vs[kWavesPerWg][TRN ? XS : 1];
+    constexpr int XS = x_chunk_cols<T>();              // staged x slice per wave
+    constexpr int VS = 8 * L * E;                      // transposed sums of one iteration
+    __shared__ __attribute__((aligned(16))) T xs[kWavesPerWg][FWD ? XS : 1];
+    __shared__ __attribute__((aligned(16))) T vs[kWavesPerWg][TRN ? VS : 1];
     __shared__ T red[kWavesPerWg][64];
 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -327,8 +353,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((!TRN 
     const bool direct = (flags & FLAG_DIRECT) != 0;
     const bool sz = (flags & FLAG_STRONG_ZERO) != 0;
     if (FWD) {
-        red[wave][lane] = u;
-        __syncthreads();
+        if (wd.wg_sync) {  // workgroup-uniform: only groups split over several waves meet in LDS
+            red[wave][lane] = u;
+            __syncthreads();
+        }
         if (work == WORK_PANEL && wd.lead) {
             for (int k = 1; k < wd.grp; ++k) u = add(u, red[wave + k][lane]);
             if (lane < m) {

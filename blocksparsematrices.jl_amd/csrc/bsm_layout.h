@@ -52,7 +52,8 @@ struct WaveWork {
     uint8_t work;         // WORK_*
     uint8_t grp;          // waves of this workgroup sharing the row group (1, 2 or 4)
     uint8_t lead;         // 1: this wave combines the group's partial sums and writes y
-    uint8_t pad0[3];
+    uint8_t wg_sync;      // 1: some wave of this workgroup has grp > 1 (all 4 waves carry the same value)
+    uint8_t pad0[2];
     int32_t pad1[2];
     Piece first;
 };
