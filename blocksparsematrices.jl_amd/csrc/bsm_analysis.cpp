@@ -23,6 +23,7 @@ Tunables Tunables::from_env() {
     t.split4_bytes = geti("BSM_SPLIT4_BYTES", t.split4_bytes);
     t.wgitem_max_bytes = geti("BSM_WGITEM_MAX_BYTES", t.wgitem_max_bytes);
     t.pack_threads = (int)geti("BSM_PACK_THREADS", t.pack_threads);
+    t.wg_order = (int)geti("BSM_ORDER", t.wg_order);
     if (t.pack_threads < 1) t.pack_threads = 1;
     return t;
 }
@@ -463,13 +464,28 @@ std::string Analysis::build(int mtype_, int dtype_, int64_t nrows_, int64_t ncol
                 P.ncols = (int32_t)(c1 - c0);
                 P.col_off = (int32_t)(G.col_off + c0);
                 P.kind = G.kind;
-                bool contig = true;
-                for (int64_t k = c0 + 1; k < c1; k++)
+                // contiguous runs of x inside [c0, c1): up to three are described inline
+                int nseg = 1;
+                int32_t segw[3] = {0, P.ncols, P.ncols};
+                int32_t segx[3] = {cols[G.col_off + c0], 0, 0};
+                for (int64_t k = c0 + 1; k < c1 && nseg <= 3; k++)
                     if (cols[G.col_off + k] != cols[G.col_off + k - 1] + 1) {
-                        contig = false;
-                        break;
+                        if (nseg < 3) {
+                            segw[nseg] = (int32_t)(k - c0);
+                            segx[nseg] = cols[G.col_off + k];
+                        }
+                        nseg++;
                     }
-                P.xbase = contig ? cols[G.col_off + c0] : -1;
+                if (nseg <= 3) {
+                    P.xbase = segx[0];
+                    W.seg1_w = segw[1];
+                    W.seg1_x = segx[1];
+                    W.seg2_w = segw[2];
+                    P.seg2_x = segx[2];
+                } else {
+                    P.xbase = -1;
+                    W.seg1_w = W.seg2_w = P.ncols;
+                }
                 W.npieces = 1;
             }
             waves.push_back(W);
@@ -477,6 +493,25 @@ std::string Analysis::build(int mtype_, int dtype_, int64_t nrows_, int64_t ncol
     }
     while (waves.size() % kWavesPerWg) emit_nop();
     nwg_main = (int64_t)waves.size() / kWavesPerWg;
+    if (!colored && tun.wg_order != 0 && nwg_main > 2) {
+        // experimental dispatch orders (default 0 = largest first)
+        std::vector<WaveWork> re(waves.size());
+        std::vector<int64_t> ord;
+        if (tun.wg_order == 1) {  // big, small, big, small ...
+            for (int64_t a = 0, b = nwg_main - 1; a <= b; a++, b--) {
+                ord.push_back(a);
+                if (b != a) ord.push_back(b);
+            }
+        } else if (tun.wg_order == 2) {  // smallest first
+            for (int64_t a = nwg_main - 1; a >= 0; a--) ord.push_back(a);
+        } else {  // 3: stride 8 (one XCD sees a size-sorted eighth)
+            for (int64_t r = 0; r < 8; r++)
+                for (int64_t a = r; a < nwg_main; a += 8) ord.push_back(a);
+        }
+        for (int64_t k = 0; k < nwg_main; k++)
+            for (int w = 0; w < kWavesPerWg; w++) re[k * kWavesPerWg + w] = waves[ord[k] * kWavesPerWg + w];
+        waves.swap(re);
+    }
     if (colored) {
         while ((int32_t)color_wg_ptr.size() <= ncolors_fused) color_wg_ptr.push_back(nwg_main);
     }

@@ -152,10 +152,10 @@ constexpr int FLAG_RMW = 16;  // coloured launch: conflict-free by construction,
 // ----------------------------------------------------------------------------------------
 struct PieceD {
     uint32_t val_lo, val_hi;
-    int xbase, col_off, nstrips, ncols, kind;
+    int xbase, col_off, nstrips, ncols, kind, seg2_x;
 };
 struct WaveD {
-    int npieces, row_off, rbase, m, work, grp, lead, wg_sync;
+    int npieces, row_off, rbase, m, work, grp, lead, wg_sync, seg1_w, seg1_x, seg2_w;
     PieceD first;
 };
 
@@ -168,6 +168,7 @@ __device__ __forceinline__ PieceD decode_piece(const uint4 a, const uint4 b) {
     p.nstrips = (int)b.x;
     p.ncols = (int)b.y;
     p.kind = (int)b.z;
+    p.seg2_x = (int)b.w;
     return p;
 }
 
@@ -175,6 +176,7 @@ __device__ __forceinline__ WaveD load_wave(const WaveWork *__restrict__ wp) {
     const uint4 *__restrict__ q = reinterpret_cast<const uint4 *>(wp);
     const uint4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
     WaveD w;
+    w.seg1_w = (int)q0.x;
     w.npieces = (int)q0.y;
     w.row_off = (int)q0.z;
     w.rbase = (int)q0.w;
@@ -183,6 +185,8 @@ __device__ __forceinline__ WaveD load_wave(const WaveWork *__restrict__ wp) {
     w.grp = (int)(q1.x >> 24);
     w.lead = (int)(q1.y & 0xffu);
     w.wg_sync = (int)((q1.y >> 8) & 0xffu);
+    w.seg1_x = (int)q1.z;
+    w.seg2_w = (int)q1.w;
     w.first = decode_piece(q2, q3);
     return w;
 }
@@ -230,6 +234,13 @@ __device__ __forceinline__ T run_panel(const WaveD &wd, const uint4 *__restrict_
         const bool trn_en = TRN && (opT || pc.kind == KIND_OFF);
         const Vec16<T> *__restrict__ vb = reinterpret_cast<const Vec16<T> *>(
             values + (((uint64_t)pc.val_hi << 32) | pc.val_lo));
+        // piece column -> x / y index: up to three inline contiguous runs, else the cols pool
+        const int s1w = wd.seg1_w, s1x = wd.seg1_x - wd.seg1_w;
+        const int s2w = wd.seg2_w, s2x = pc.seg2_x - wd.seg2_w;
+        auto col_index = [&](int w) -> int {
+            if (xbase < 0) return cols[col_off + w];
+            return w + (w < s1w ? xbase : (w < s2w ? s1x : s2x));
+        };
 
         for (int c0 = 0; c0 < ncols; c0 += XCH) {
             if (fwd_en) {
@@ -242,10 +253,7 @@ __device__ __forceinline__ T run_panel(const WaveD &wd, const uint4 *__restrict_
                     const int w = c0 + c;
                     if (w < ncols + NC) {  // zero the tail one iteration past the last column
                         T xv = zero_of(T{});
-                        if (w < ncols) {
-                            const int xi = (xbase >= 0) ? xbase + w : cols[col_off + w];
-                            xv = x[xi];
-                        }
+                        if (w < ncols) xv = x[col_index(w)];
                         xs[c] = xv;
                     }
                 }
@@ -297,7 +305,7 @@ __device__ __forceinline__ T run_panel(const WaveD &wd, const uint4 *__restrict_
                         const int c = k * 64 + lane;
                         const int w = s0 * E + c;
                         if (c < NC && w < ncols) {
-                            const int yi = (xbase >= 0) ? xbase + w : cols[col_off + w];
+                            const int yi = col_index(w);
                             const T val = mul(alpha, vs[c]);
                             if (flags & FLAG_RMW)
                                 y[yi] = add(y[yi], val);

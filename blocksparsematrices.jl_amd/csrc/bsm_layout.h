@@ -34,17 +34,21 @@ enum : uint8_t {
 
 struct Piece {
     uint64_t val_off;  // offset into values, in 16-byte units
-    int32_t xbase;     // >= 0: columns are the contiguous range starting here (0-based); -1: indexed
+    int32_t xbase;     // first x index of column segment 0 (0-based); -1: use the cols pool
     int32_t col_off;   // offset into cols pool of the first column
     int32_t nstrips;   // strips in this piece
     int32_t ncols;     // valid columns (<= nstrips * E)
     int32_t kind;      // KIND_*
-    int32_t pad;
+    int32_t seg2_x;    // first x index of column segment 2
 };
 static_assert(sizeof(Piece) == 32, "Piece must be 32 bytes");
 
+// The columns of a piece are usually a few contiguous runs of x (one per block of a VBCRS block
+// row).  Up to three runs are described inline -- segment k covers piece columns
+// [seg_k_w, seg_{k+1}_w) and maps column w to x index seg_k_x + (w - seg_k_w), seg_0_w = 0 --
+// so the wave computes its x addresses without a dependent load of the cols pool.
 struct WaveWork {
-    int32_t reserved0;
+    int32_t seg1_w;       // first piece column of segment 1 (>= ncols when unused)
     int32_t npieces;      // 0 (nothing to stream) or 1
     int32_t row_off;      // rows pool offset (indexed row groups)
     int32_t rbase;        // >= 0: rows are the contiguous range starting here (0-based); -1: indexed
@@ -54,7 +58,8 @@ struct WaveWork {
     uint8_t lead;         // 1: this wave combines the group's partial sums and writes y
     uint8_t wg_sync;      // 1: some wave of this workgroup has grp > 1 (all 4 waves carry the same value)
     uint8_t pad0[2];
-    int32_t pad1[2];
+    int32_t seg1_x;       // first x index of segment 1
+    int32_t seg2_w;       // first piece column of segment 2 (>= ncols when unused)
     Piece first;
 };
 static_assert(sizeof(WaveWork) == 64, "WaveWork must be 64 bytes");

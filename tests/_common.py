@@ -149,10 +149,10 @@ def scipy_mul(problem, op, x, y0, alpha=1, beta=0, strong=True):
 
 # ---- packed-image interpreter -------------------------------------------------------------------
 PIECE_DT = np.dtype([("val_off", "<u8"), ("xbase", "<i4"), ("col_off", "<i4"), ("nstrips", "<i4"),
-                     ("ncols", "<i4"), ("kind", "<i4"), ("pad", "<i4")])
-WAVE_DT = np.dtype([("reserved0", "<i4"), ("npieces", "<i4"), ("row_off", "<i4"), ("rbase", "<i4"),
+                     ("ncols", "<i4"), ("kind", "<i4"), ("seg2_x", "<i4")])
+WAVE_DT = np.dtype([("seg1_w", "<i4"), ("npieces", "<i4"), ("row_off", "<i4"), ("rbase", "<i4"),
                     ("m", "<u2"), ("work", "u1"), ("grp", "u1"), ("lead", "u1"), ("wg_sync", "u1"), ("pad0", "u1", 2),
-                    ("pad1", "<i4", 2), ("first", PIECE_DT)])
+                    ("seg1_x", "<i4"), ("seg2_w", "<i4"), ("first", PIECE_DT)])
 assert PIECE_DT.itemsize == 32 and WAVE_DT.itemsize == 64
 WORK_NOP, WORK_PANEL, WORK_SCALE = 0, 1, 2
 KIND_OFF = 2
@@ -213,8 +213,14 @@ def interpret_image(A, op, x, y0, alpha=1, beta=0, strong=True):
                 assert not np.any(full[:, nc:]), "strip padding must be zero"
                 if conj:
                     B = B.conj()
-                cidx = (np.arange(P["xbase"], P["xbase"] + nc) if P["xbase"] >= 0
-                        else cols[P["col_off"]:P["col_off"] + nc])
+                if P["xbase"] >= 0:  # up to three inline contiguous runs
+                    wv = np.arange(nc)
+                    s1w, s2w = int(W["seg1_w"]), int(W["seg2_w"])
+                    cidx = np.where(wv < s1w, int(P["xbase"]) + wv,
+                                    np.where(wv < s2w, int(W["seg1_x"]) + wv - s1w, int(P["seg2_x"]) + wv - s2w))
+                    assert np.array_equal(cidx, cols[P["col_off"]:P["col_off"] + nc])
+                else:
+                    cidx = cols[P["col_off"]:P["col_off"] + nc]
                 kind = int(P["kind"])
                 if (not opT) or kind == KIND_OFF:
                     u += B @ x[cidx]
