@@ -28,8 +28,8 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X spec (MI355X_MICROARCH.md); measured-copy ceiling 6290
 # HBM-side bytes of one C2 launch from the PMC passes (profiles/r01_c2_pmc_summary.txt):
-# FETCH_SIZE 27773.6 KiB x 2 (gfx950 counts 128-B requests as 64 B) + WRITE_SIZE 842.0 KiB
-TRAFFIC_BYTES_PER_LAUNCH = 57_742_000
+# FETCH_SIZE 27442.3 KiB x 2 (gfx950 counts 128-B requests as 64 B) + WRITE_SIZE 838.8 KiB
+TRAFFIC_BYTES_PER_LAUNCH = 57_060_000
 
 
 def main():
