@@ -189,6 +189,24 @@ def main():
             dt = time.perf_counter() - t0
             if dt > 10.0 or reps >= 2000:
                 break
+        # all host cores: one OpenMP task per block row == the reference's `@tasks for browidx`
+        # with DynamicScheduler() (src/vbcrs.jl:275-276); reported beside, not as the baseline
+        try:
+            ncores = len(os.sched_getaffinity(0))
+            yp = np.zeros(n)
+            orc.vbcrs_mul(0, blocks, rowptr, colind, rowind, xh, yp, parallel=True)
+            preps, tp0 = 0, time.perf_counter()
+            while True:
+                orc.vbcrs_mul(0, blocks, rowptr, colind, rowind, xh, yp, parallel=True)
+                preps += 1
+                dtp = time.perf_counter() - tp0
+                if dtp > 5.0 or preps >= 2000:
+                    break
+            extra["cpu_allcores"] = {"value": round(st["alg_bytes"] * preps / dtp / 1e9, 3), "unit": "GB/s",
+                                     "cores": ncores, "kind": "port (OpenMP over block rows)",
+                                     "sample": f"{preps} C2 mul! calls in {dtp:.1f} s"}
+        except Exception as e:  # pragma: no cover
+            extra["cpu_allcores"] = {"error": str(e)}
         # parity of the measured GPU result against this same oracle run
         err = float(np.max(np.abs(y.cpu().numpy() - yh)) / np.max(np.abs(yh)))
         cpu = {"value": round(st["alg_bytes"] * reps / dt / 1e9, 3), "unit": "GB/s", "cores": 1,

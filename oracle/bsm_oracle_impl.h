@@ -160,6 +160,25 @@ void FN(orc_vbcrs_mul)(int64_t nrows_y, int64_t nblockrows, const int64_t *rowpt
         }
 }
 
+/* The same forward product with the reference's task structure made explicit: `@tasks for
+ * browidx` (src/vbcrs.jl:275-276) == one OpenMP task per block row (dynamic schedule, like
+ * DynamicScheduler()).  Used only for the all-cores CPU baseline of bench.py; built with
+ * -fopenmp (without it the pragma is ignored and this equals orc_vbcrs_mul). */
+void FN(orc_vbcrs_mul_par)(int64_t nrows_y, int64_t nblockrows, const int64_t *rowptr,
+                           const int64_t *colindices, const int64_t *rowindices,
+                           const T *const *blocks, const int64_t *m, const int64_t *n,
+                           const int64_t *ld, const T *x, T *y, T alpha, T beta,
+                           int beta_strong_zero) {
+    FN(scale_y)(nrows_y, y, beta, beta_strong_zero);
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int64_t br = 0; br < nblockrows; br++)
+        for (int64_t bi = rowptr[br]; bi < rowptr[br + 1]; bi++) {
+            int64_t b = bi - 1;
+            FN(block_gemv)(0, m[b], n[b], blocks[b], ld[b], NULL, rowindices[br], NULL,
+                           colindices[b], x, y, alpha);
+        }
+}
+
 /* VBCRS adjoint/transpose -- reference src/vbcrs.jl:303-329 (serial double loop,
  * y[col range] += a * op(block) * x[row range]); op: 1 = transpose, 2 = adjoint.
  * The 3-arg form (:331-341) zero-fills y then calls this with (true, true): the

@@ -182,7 +182,7 @@ class Oracle:
         return y
 
     def vbcrs_mul(self, op, blocks, rowptr, colindices, rowindices, x, y, alpha=1, beta=0,
-                  strong_zero=True):
+                  strong_zero=True, parallel=False):
         """blocks already in VBCRS (sorted) order; rowptr/colindices/rowindices 1-based."""
         dt = np.dtype(x.dtype)
         fb = _fblocks(blocks, dt)
@@ -198,7 +198,7 @@ class Oracle:
                 C.c_void_p(x.ctypes.data), C.c_void_p(y.ctypes.data), _scalar(dt, alpha),
                 _scalar(dt, beta), C.c_int(1 if strong_zero else 0)]
         if op == 0:
-            fn = getattr(self.lib, "orc_vbcrs_mul_" + _SFX[dt])
+            fn = getattr(self.lib, ("orc_vbcrs_mul_par_" if parallel else "orc_vbcrs_mul_") + _SFX[dt])
         else:
             fn = getattr(self.lib, "orc_vbcrs_mul_t_" + _SFX[dt])
             args = [C.c_int(op)] + args
