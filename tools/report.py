@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""Fills BASELINE.md's result table: for every BASELINE.json config (C4/C5 as the slice one GPU
+of eight owns) the CPU oracle rate (1 thread, scalar port of the reference loops), the GPU rate
+through the C ABI (warm, back-to-back launches; HIP events) and the parity error.
+usage: tools/report.py [out.md]"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import numpy as np
+import torch
+import bsm_amd as bsm
+from oracle import load_oracle
+from _common import N, T, oracle_mul, relerr
+
+S = bsm.synthetic
+orc = load_oracle()
+CONFIGS = [
+    ("C1 BlockSparseMatrix 1000^2, 50x 32x32 fp64", lambda: S.config1(), 1),
+    ("C2 VBCRS 100k^2, 5000 blocks 8-64 fp64", lambda: S.config2(), 1),
+    ("C3 Symmetric 200k^2, 64x64 fp64, half-bandwidth 8", lambda: S.config3(), 1),
+    ("C4 VBCRS 2M^2, 128x128 fp32: block rows 0..1952 (1/8)", lambda: S.config4(row_lo=0, row_hi=1953), 8),
+    ("C5 Symmetric 5M^2, sizes 16-256 fp64: first 625k rows (1/8)", lambda: S.config5(n=625_000), 8),
+]
+lines = ["| config | CPU oracle 1 thread GB/s | GPU N GB/s (% of 8 TB/s) | GPU T GB/s | rel-err N | rel-err T | alg MB |",
+         "|---|---|---|---|---|---|---|"]
+for name, make, share in CONFIGS:
+    prob = make()
+    A = S.build(prob)
+    st = A.stats()
+    dt = A.dtype
+    nr, nc = prob["size"]
+    x = prob["x"]
+    y0 = np.zeros(nr, dtype=dt)
+    # CPU oracle, bounded sample
+    ref = oracle_mul(orc, prob, N, x, y0)
+    reps, t0 = 0, time.perf_counter()
+    while True:
+        oracle_mul(orc, prob, N, x, y0)
+        reps += 1
+        el = time.perf_counter() - t0
+        if el > 4.0 or reps >= 200:
+            break
+    cpu = st["alg_bytes"] * reps / el / 1e9
+    out = {}
+    for opname, Aop, op in (("N", A, N), ("T", bsm.transpose(A), T)):
+        xd = torch.from_numpy(x).cuda()
+        yd = torch.zeros(nr, dtype=xd.dtype, device="cuda")
+        plan = bsm.MulPlan(yd, Aop, xd)
+        for _ in range(10):
+            plan()
+        torch.cuda.synchronize()
+        r = 300 if st["alg_bytes"] < 2e8 else 40
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(r):
+            plan()
+        b.record()
+        torch.cuda.synchronize()
+        tt = a.elapsed_time(b) * 1e-3 / r
+        refop = ref if op == N else oracle_mul(orc, prob, T, x, y0)
+        tol_ref = relerr(yd.cpu().numpy(), refop)
+        out[opname] = (st["alg_bytes"] / tt / 1e9, tol_ref, tt)
+    g, e, tt = out["N"]
+    gt, et, _ = out["T"]
+    lines.append(f"| {name} | {cpu:.2f} | {g:.0f} ({100 * g / 8000:.0f} %, {tt * 1e6:.1f} us) | {gt:.0f} | "
+                 f"{e:.1e} | {et:.1e} | {st['alg_bytes'] / 1e6:.1f} |")
+    print(lines[-1], flush=True)
+    del A, prob
+text = "\n".join(lines)
+if len(sys.argv) > 1:
+    open(sys.argv[1], "w").write(text + "\n")
+print(text)
