@@ -40,7 +40,8 @@ _I64P = C.POINTER(C.c_int64)
 _lib = None
 
 # every symbol include/bsm_rocm.h declares
-EXPORTS = ["bsm_options_default", "bsm_vbcrs_create", "bsm_blocksparse_create",
+EXPORTS = ["bsm_options_default", "bsm_vbcrs_create", "bsm_vbcrs_create_from_symmetric",
+           "bsm_blocksparse_create",
            "bsm_symmetric_create", "bsm_mul", "bsm_get_bookkeeping", "bsm_get_image", "bsm_stats",
            "bsm_destroy",
            "bsm_last_error", "bsm_version"]
@@ -68,15 +69,21 @@ def lib():
     L.bsm_symmetric_create.argtypes = [C.c_int, C.c_int64, C.c_int64, C.c_int64, _PP, _I64P,
                                        _I64P, _PP, C.c_int64, _PP, _I64P, _I64P, _I64P, _PP,
                                        _PP, C.POINTER(BsmOptions), C.POINTER(C.c_void_p)]
+    L.bsm_vbcrs_create_from_symmetric.argtypes = [C.c_int, C.c_int64, C.c_int64, C.c_int64, _PP, _I64P,
+                                                  _I64P, _I64P, C.c_int64, _PP, _I64P, _I64P, _I64P,
+                                                  _I64P, _I64P, C.POINTER(BsmOptions),
+                                                  C.POINTER(C.c_void_p)]
     L.bsm_mul.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                           C.c_int, C.c_int, C.c_void_p]
     L.bsm_get_bookkeeping.argtypes = [C.c_void_p, C.c_int, _I64P, _I64P]
     L.bsm_get_image.argtypes = [C.c_void_p, C.c_int, C.c_void_p, _I64P]
+    L.bsm_color.argtypes = [C.c_int64, _PP, _I64P, _I64P, _I64P]
+    L.bsm_color.restype = C.c_int
     L.bsm_stats.argtypes = [C.c_void_p, C.POINTER(BsmStats)]
     L.bsm_destroy.argtypes = [C.c_void_p]
     L.bsm_last_error.restype = C.c_char_p
     L.bsm_version.restype = C.c_char_p
-    for name in ("bsm_vbcrs_create", "bsm_blocksparse_create", "bsm_symmetric_create", "bsm_mul",
+    for name in ("bsm_vbcrs_create", "bsm_vbcrs_create_from_symmetric", "bsm_blocksparse_create", "bsm_symmetric_create", "bsm_mul",
                  "bsm_get_bookkeeping", "bsm_get_image", "bsm_stats", "bsm_destroy"):
         getattr(L, name).restype = C.c_int
     _lib = L

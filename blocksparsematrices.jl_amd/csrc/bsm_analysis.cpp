@@ -179,7 +179,8 @@ std::string Analysis::build(int mtype_, int dtype_, int64_t nrows_, int64_t ncol
     if (nrows < 0 || ncols < 0) return "negative matrix size";
     if (nrows > INT32_MAX - 64 || ncols > INT32_MAX - 64) return "matrix dimension exceeds int32 range";
     const int64_t nb = (int64_t)blocks.size();
-    const bool sym = (mtype == MT_SYMMETRIC);
+    bool sym = (mtype == MT_SYMMETRIC);
+    for (const BlockIn &B : blocks) sym |= (B.kind != KIND_PLAIN);  // symmetric view of a VBCRS
     // rows index y for op N and x for op T; for a symmetric matrix every list indexes both
     const int64_t rlim = sym ? std::min(nrows, ncols) : nrows;
     const int64_t clim = sym ? std::min(nrows, ncols) : ncols;
@@ -593,11 +594,8 @@ std::string Analysis::build(int mtype_, int dtype_, int64_t nrows_, int64_t ncol
     return "";
 }
 
-std::string Analysis::build_vbcrs(int dtype_, int64_t nrows_, int64_t ncols_, int64_t nblocks,
-                                  const void *const *blocks, const int64_t *m, const int64_t *n,
-                                  const int64_t *ld, const int64_t *rowstart,
-                                  const int64_t *colstart, const AnalysisOptions &opt_) {
-    if (nblocks < 1) return "VBCRS needs at least one block (reference src/vbcrs.jl:81)";
+std::vector<int64_t> Analysis::vbcrs_bookkeeping(int64_t nblocks, const int64_t *rowstart,
+                                                 const int64_t *colstart) {
     // perm = sortperm(1:n; by = i -> (rowindices[i], colindices[i]))   (src/vbcrs.jl:84), stable
     std::vector<int64_t> p(nblocks);
     std::iota(p.begin(), p.end(), (int64_t)0);
@@ -622,6 +620,61 @@ std::string Analysis::build_vbcrs(int dtype_, int64_t nrows_, int64_t ncols_, in
         colindices[out] = colstart[in];
     }
     rowptr.push_back(nblocks + 1);
+    return p;
+}
+
+std::string Analysis::build_vbcrs_symmetric_view(int dtype_, int64_t nrows_, int64_t ncols_, int64_t ndiag,
+                                                 const void *const *diag, const int64_t *dsize,
+                                                 const int64_t *dld, const int64_t *diagstart,
+                                                 int64_t noff, const void *const *off, const int64_t *m,
+                                                 const int64_t *n, const int64_t *ld,
+                                                 const int64_t *rowstart, const int64_t *colstart,
+                                                 const AnalysisOptions &opt_) {
+    const int64_t nv = ndiag + 2 * noff;
+    if (nv < 1) return "VBCRS needs at least one block (reference src/vbcrs.jl:81)";
+    // virtual block list of the reference's functors (src/vbcrs.jl:222-262)
+    std::vector<int64_t> rs(nv), cs(nv);
+    for (int64_t d = 0; d < ndiag; d++) rs[d] = cs[d] = diagstart[d];
+    for (int64_t b = 0; b < noff; b++) {
+        rs[ndiag + b] = rowstart[b];
+        cs[ndiag + b] = colstart[b];
+        rs[ndiag + noff + b] = colstart[b];
+        cs[ndiag + noff + b] = rowstart[b];
+    }
+    vbcrs_bookkeeping(nv, rs.data(), cs.data());
+    std::vector<BlockIn> in;
+    in.reserve((size_t)(ndiag + noff));
+    for (int64_t d = 0; d < ndiag; d++) {
+        BlockIn B;
+        B.data = (const char *)diag[d];
+        B.m = B.n = dsize[d];
+        B.ld = dld[d];
+        B.ridx = B.cidx = nullptr;
+        B.r0 = B.c0 = diagstart[d];
+        B.kind = KIND_DIAG;
+        in.push_back(B);
+    }
+    for (int64_t b = 0; b < noff; b++) {
+        BlockIn B;
+        B.data = (const char *)off[b];
+        B.m = m[b];
+        B.n = n[b];
+        B.ld = ld[b];
+        B.ridx = B.cidx = nullptr;
+        B.r0 = rowstart[b];
+        B.c0 = colstart[b];
+        B.kind = KIND_OFF;
+        in.push_back(B);
+    }
+    return build(MT_VBCRS, dtype_, nrows_, ncols_, in, opt_);
+}
+
+std::string Analysis::build_vbcrs(int dtype_, int64_t nrows_, int64_t ncols_, int64_t nblocks,
+                                  const void *const *blocks, const int64_t *m, const int64_t *n,
+                                  const int64_t *ld, const int64_t *rowstart,
+                                  const int64_t *colstart, const AnalysisOptions &opt_) {
+    if (nblocks < 1) return "VBCRS needs at least one block (reference src/vbcrs.jl:81)";
+    const std::vector<int64_t> p = vbcrs_bookkeeping(nblocks, rowstart, colstart);
     std::vector<BlockIn> in(nblocks);
     for (int64_t out = 0; out < nblocks; out++) {
         const int64_t i = p[out];

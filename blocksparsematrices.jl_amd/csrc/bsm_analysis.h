@@ -73,11 +73,26 @@ class Analysis {
     std::string build(int mtype, int dtype, int64_t nrows, int64_t ncols,
                       const std::vector<BlockIn> &blocks, const AnalysisOptions &opt);
 
+    // Fills perm / rowptr / colindices / rowindices exactly as src/vbcrs.jl:84-117 and returns the
+    // sorted order (0-based input positions).
+    std::vector<int64_t> vbcrs_bookkeeping(int64_t nblocks, const int64_t *rowstart, const int64_t *colstart);
+
     // VBCRS front end: sorts, fills perm/rowptr/..., then calls build with sorted blocks.
     std::string build_vbcrs(int dtype, int64_t nrows, int64_t ncols, int64_t nblocks,
                             const void *const *blocks, const int64_t *m, const int64_t *n,
                             const int64_t *ld, const int64_t *rowstart, const int64_t *colstart,
                             const AnalysisOptions &opt);
+
+    // VariableBlockCompressedRowStorage(sbm::SymmetricBlockMatrix) WITHOUT materialising the
+    // transposed off-diagonal blocks (reference src/vbcrs.jl:189-264 does, doubling the storage):
+    // bookkeeping is that of the expanded [diag..., off..., transpose(off)...] list, the device
+    // image is the symmetric one (every off-diagonal block stored and streamed once).
+    std::string build_vbcrs_symmetric_view(int dtype, int64_t nrows, int64_t ncols, int64_t ndiag,
+                                           const void *const *diag, const int64_t *dsize,
+                                           const int64_t *dld, const int64_t *diagstart, int64_t noff,
+                                           const void *const *off, const int64_t *m, const int64_t *n,
+                                           const int64_t *ld, const int64_t *rowstart,
+                                           const int64_t *colstart, const AnalysisOptions &opt);
 };
 
 }  // namespace bsm

@@ -191,6 +191,39 @@ extern "C" int bsm_vbcrs_create(int dtype, int64_t nrows, int64_t ncols, int64_t
     }
 }
 
+extern "C" int bsm_vbcrs_create_from_symmetric(int dtype, int64_t nrows, int64_t ncols, int64_t ndiag,
+                                               const void *const *diag, const int64_t *dsize,
+                                               const int64_t *dld, const int64_t *diagstart,
+                                               int64_t noff, const void *const *off, const int64_t *m,
+                                               const int64_t *n, const int64_t *ld,
+                                               const int64_t *rowstart, const int64_t *colstart,
+                                               const bsm_options *opts, bsm_matrix_t *out) {
+    try {
+        if (!out) return fail(BSM_ERR_INVALID, "out is null");
+        *out = nullptr;
+        if (ndiag < 0 || noff < 0 || ndiag + noff < 1) return fail(BSM_ERR_INVALID, "VBCRS needs at least one block");
+        if (ndiag > 0 && (!diag || !dsize || !dld || !diagstart)) return fail(BSM_ERR_INVALID, "null argument");
+        if (noff > 0 && (!off || !m || !n || !ld || !rowstart || !colstart))
+            return fail(BSM_ERR_INVALID, "null argument");
+        bsm_options o;
+        int rc = read_options(opts, o);
+        if (rc) return rc;
+        bsm_matrix_s *A = new bsm_matrix_s();
+        std::string err = A->an.build_vbcrs_symmetric_view(dtype, nrows, ncols, ndiag, diag, dsize, dld,
+                                                           diagstart, noff, off, m, n, ld, rowstart,
+                                                           colstart, to_aopt(o));
+        if (!err.empty()) {
+            delete A;
+            return fail(BSM_ERR_INVALID, err);
+        }
+        return finish_create(A, o, out);
+    } catch (const std::bad_alloc &) {
+        return fail(BSM_ERR_ALLOC, "out of host memory");
+    } catch (const std::exception &e) {
+        return fail(BSM_ERR_INVALID, e.what());
+    }
+}
+
 extern "C" int bsm_blocksparse_create(int dtype, int64_t nrows, int64_t ncols, int64_t nblocks,
                                       const void *const *blocks, const int64_t *m, const int64_t *n,
                                       const int64_t *ld, const int64_t *const *rowidx,
@@ -406,6 +439,30 @@ extern "C" int bsm_stats(bsm_matrix_t A, bsm_stats_t *out) {
     out->nworkgroups = A->img.nwg_total;
     out->exclusive = A->img.exclusive_fwd ? 1 : 0;
     return BSM_OK;
+}
+
+extern "C" int bsm_color(int64_t nlists, const int64_t *const *lists, const int64_t *lens,
+                         int64_t *color_out, int64_t *ncolors) {
+    try {
+        if (nlists < 0 || (nlists > 0 && (!lists || !lens || !color_out)) || !ncolors)
+            return fail(BSM_ERR_INVALID, "null argument");
+        std::vector<const int64_t *> lp((size_t)nlists);
+        std::vector<int64_t> ln((size_t)nlists);
+        for (int64_t b = 0; b < nlists; b++) {
+            if (lens[b] < 0 || (lens[b] > 0 && !lists[b])) return fail(BSM_ERR_INVALID, "bad list");
+            for (int64_t k = 0; k < lens[b]; k++)
+                if (lists[b][k] < 1) return fail(BSM_ERR_INVALID, "indices are 1-based");
+            lp[b] = lists[b];
+            ln[b] = lens[b];
+        }
+        auto classes = color_dsatur(lp, ln);
+        for (size_t c = 0; c < classes.size(); c++)
+            for (int64_t id : classes[c]) color_out[id - 1] = (int64_t)c;
+        *ncolors = (int64_t)classes.size();
+        return BSM_OK;
+    } catch (const std::bad_alloc &) {
+        return fail(BSM_ERR_ALLOC, "out of host memory");
+    }
 }
 
 extern "C" int bsm_destroy(bsm_matrix_t A) {

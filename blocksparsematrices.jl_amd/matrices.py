@@ -35,7 +35,8 @@ __all__ = [
     "transpose", "adjoint", "mul", "MulPlan", "nnz", "size", "eltype", "scheduler", "block", "eachblockindex",
     "rowindices", "colindices", "colors", "transposecolors", "diagonal", "offdiagonal",
     "eachdiagonalindex", "eachoffdiagonalindex", "diagonalindices", "diagonalcolors",
-    "offdiagonalcolors", "transposeoffdiagonalcolors", "rowcolvals", "sparse",
+    "offdiagonalcolors", "transposeoffdiagonalcolors", "rowcolvals", "sparse", "ColorInfo", "conflicts",
+    "color", "coloringalgorithm",
 ]
 
 _DT = {np.dtype(np.float32): L.BSM_F32, np.dtype(np.float64): L.BSM_F64,
@@ -241,6 +242,45 @@ def _unwrap(A):
     return A, L.BSM_OP_N
 
 
+# ---- colouring adapter (reference src/coloring.jl:15-61) ----------------------------------------------
+coloringalgorithm = "DSATUR"  # the reference's const is GraphsColoring.WorkstreamDSATUR (not in its tree)
+
+
+class ColorInfo:
+    """struct ColorInfo{R}: wraps the per-block conflict index lists (src/coloring.jl:15-17)."""
+
+    def __init__(self, conflictindices):
+        self.conflictindices = [_i64(c) for c in conflictindices]
+
+
+class ConflictFunctor:
+    def __init__(self, indices):
+        self.indices = indices
+
+    def __call__(self, i):
+        return self.indices[i - 1]
+
+
+def conflicts(blocks):
+    """(eachindex(indices), ConflictFunctor(indices), Base.OneTo(maxconflict)) -- src/coloring.jl:45-61"""
+    idx = blocks.conflictindices
+    maxconflict = max(int(np.max(l)) for l in idx)
+    return range(1, len(idx) + 1), ConflictFunctor(idx), range(1, maxconflict + 1)
+
+
+def color(info, algorithm=None):
+    """color(conflictgraph(info); algorithm).colors: classes of 1-based block ids that share no
+    index.  Runs the library's deterministic DSATUR (bsm_color)."""
+    lists = info.conflictindices
+    n = len(lists)
+    lens = _i64([len(l) for l in lists])
+    out = np.zeros(max(n, 1), dtype=np.int64)
+    nc = C.c_int64(0)
+    I = C.POINTER(C.c_int64)
+    L.check(L.lib().bsm_color(n, _ptrs(lists), lens.ctypes.data_as(I), out.ctypes.data_as(I), C.byref(nc)))
+    return [[int(b) + 1 for b in np.nonzero(out[:n] == c)[0]] for c in range(nc.value)]
+
+
 # ---- the three storage types ---------------------------------------------------------------------------
 class BlockSparseMatrix(AbstractBlockMatrix):
     """reference src/blockmatrix.jl:26-109.  Fields: blocks, rowindices, colindices, size,
@@ -327,45 +367,69 @@ class VariableBlockCompressedRowStorage(AbstractBlockMatrix):
     rowindices (per block row), size, scheduler -- all 1-based like the reference."""
 
     def __init__(self, matrices, rowindices=None, colindices=None, matrixsize=None, *,
-                 scheduler=None, device=None, accumulate="auto", own=None):
-        if isinstance(matrices, BlockSparseMatrix):  # src/vbcrs.jl:150-160
-            b = matrices
-            scheduler = b.scheduler if scheduler is None else scheduler
-            mats = b.blocks
-            rowindices = [int(r[0]) for r in b.rowindices]  # first(rowindices(b, i)), :203
-            colindices = [int(c[0]) for c in b.colindices]
-            matrixsize = b.size
-        elif isinstance(matrices, SymmetricBlockMatrix):  # src/vbcrs.jl:189-264
+                 scheduler=None, device=None, accumulate="auto", own=None, materialize=False):
+        I = C.POINTER(C.c_int64)
+        h = C.c_void_p()
+        dev = _default_device() if device is None else device
+        if isinstance(matrices, SymmetricBlockMatrix) and not materialize:  # src/vbcrs.jl:189-264
+            # Same bookkeeping as the reference's expansion [diagonals..., offdiagonals...,
+            # transpose(offdiagonals)...] (:222-241), but the transposes are NOT materialised:
+            # the device image is the symmetric one and each off-diagonal block is streamed once.
             s = matrices
             scheduler = s.scheduler if scheduler is None else scheduler
-            # [diagonals..., offdiagonals..., transpose(offdiagonals)...]  (:222-241)
-            mats = list(s.diagonals) + list(s.offdiagonals) + [o.T for o in s.offdiagonals]
-            rowindices = ([int(d[0]) for d in s.diagonalindices] + [int(r[0]) for r in s.rowindices]
-                          + [int(c[0]) for c in s.colindices])
-            colindices = ([int(d[0]) for d in s.diagonalindices] + [int(c[0]) for c in s.colindices]
-                          + [int(r[0]) for r in s.rowindices])
+            dt = s.dtype
+            mats = list(s.diagonals) + list(s.offdiagonals) + [o.T for o in s.offdiagonals]  # views
+            ds = _i64([b.shape[0] for b in s.diagonals])
+            dld = _i64([max(b.shape[0], 1) for b in s.diagonals])
+            d0 = _i64([int(d[0]) for d in s.diagonalindices])  # first(...), :231-239
+            m = _i64([b.shape[0] for b in s.offdiagonals])
+            n = _i64([b.shape[1] for b in s.offdiagonals])
+            ld = _i64([max(b.shape[0], 1) for b in s.offdiagonals])
+            r0 = _i64([int(r[0]) for r in s.rowindices])
+            c0 = _i64([int(c[0]) for c in s.colindices])
+            o = _options(scheduler, dev, accumulate, own)
+            L.check(L.lib().bsm_vbcrs_create_from_symmetric(
+                _DT[dt], int(s.size[0]), int(s.size[1]), len(s.diagonals), _ptrs(s.diagonals),
+                ds.ctypes.data_as(I), dld.ctypes.data_as(I), d0.ctypes.data_as(I), len(s.offdiagonals),
+                _ptrs(s.offdiagonals), m.ctypes.data_as(I), n.ctypes.data_as(I), ld.ctypes.data_as(I),
+                r0.ctypes.data_as(I), c0.ctypes.data_as(I), C.byref(o), C.byref(h)))
             matrixsize = s.size
+            fb = mats
         else:
-            mats = matrices
-        scheduler = SerialScheduler() if scheduler is None else scheduler
-        if len(mats) < 1:
-            raise IndexError("VariableBlockCompressedRowStorage needs at least one block")  # :81
-        dt = _blocks_dtype(mats)
-        fb = _fblocks(mats, dt)
-        rs, cs = _i64(rowindices), _i64(colindices)
-        if len(rs) != len(fb) or len(cs) != len(fb):
-            raise ValueError("matrices, rowindices and colindices must have equal lengths")
-        m = _i64([b.shape[0] for b in fb])
-        n = _i64([b.shape[1] for b in fb])
-        ld = _i64([max(b.shape[0], 1) for b in fb])
-        dev = _default_device() if device is None else device
-        o = _options(scheduler, dev, accumulate, own)
-        h = C.c_void_p()
-        I = C.POINTER(C.c_int64)
-        L.check(L.lib().bsm_vbcrs_create(
-            _DT[dt], int(matrixsize[0]), int(matrixsize[1]), len(fb), _ptrs(fb),
-            m.ctypes.data_as(I), n.ctypes.data_as(I), ld.ctypes.data_as(I), rs.ctypes.data_as(I),
-            cs.ctypes.data_as(I), C.byref(o), C.byref(h)))
+            if isinstance(matrices, BlockSparseMatrix):  # src/vbcrs.jl:150-160
+                b = matrices
+                scheduler = b.scheduler if scheduler is None else scheduler
+                mats = b.blocks
+                rowindices = [int(r[0]) for r in b.rowindices]  # first(rowindices(b, i)), :203
+                colindices = [int(c[0]) for c in b.colindices]
+                matrixsize = b.size
+            elif isinstance(matrices, SymmetricBlockMatrix):  # reference behaviour: materialise
+                s = matrices
+                scheduler = s.scheduler if scheduler is None else scheduler
+                mats = list(s.diagonals) + list(s.offdiagonals) + [o.T for o in s.offdiagonals]
+                rowindices = ([int(d[0]) for d in s.diagonalindices] + [int(r[0]) for r in s.rowindices]
+                              + [int(c[0]) for c in s.colindices])
+                colindices = ([int(d[0]) for d in s.diagonalindices] + [int(c[0]) for c in s.colindices]
+                              + [int(r[0]) for r in s.rowindices])
+                matrixsize = s.size
+            else:
+                mats = matrices
+            scheduler = SerialScheduler() if scheduler is None else scheduler
+            if len(mats) < 1:
+                raise IndexError("VariableBlockCompressedRowStorage needs at least one block")  # :81
+            dt = _blocks_dtype(mats)
+            fb = _fblocks(mats, dt)
+            rs, cs = _i64(rowindices), _i64(colindices)
+            if len(rs) != len(fb) or len(cs) != len(fb):
+                raise ValueError("matrices, rowindices and colindices must have equal lengths")
+            m = _i64([b.shape[0] for b in fb])
+            n = _i64([b.shape[1] for b in fb])
+            ld = _i64([max(b.shape[0], 1) for b in fb])
+            o = _options(scheduler, dev, accumulate, own)
+            L.check(L.lib().bsm_vbcrs_create(
+                _DT[dt], int(matrixsize[0]), int(matrixsize[1]), len(fb), _ptrs(fb),
+                m.ctypes.data_as(I), n.ctypes.data_as(I), ld.ctypes.data_as(I), rs.ctypes.data_as(I),
+                cs.ctypes.data_as(I), C.byref(o), C.byref(h)))
         self._finish(h, dt, matrixsize, scheduler)
         self.perm = self._bookkeeping(L.BSM_BK_VBCRS_PERM).copy()
         self.rowptr = self._bookkeeping(L.BSM_BK_VBCRS_ROWPTR).copy()

@@ -88,6 +88,21 @@ int bsm_vbcrs_create(int dtype, int64_t nrows, int64_t ncols, int64_t nblocks,
                      const int64_t *ld, const int64_t *rowstart, const int64_t *colstart,
                      const bsm_options *opts, bsm_matrix_t *out);
 
+/* VariableBlockCompressedRowStorage(sbm::SymmetricBlockMatrix; scheduler) -- reference
+ * src/vbcrs.jl:189-264.  The reference expands the matrix into [diagonals..., offdiagonals...,
+ * transpose(offdiagonals)...] and MATERIALISES the transposes (twice the off-diagonal storage).
+ * Here the bookkeeping (perm, rowptr, colindices, rowindices over those ndiag + 2*noff virtual
+ * blocks) is identical, but the device image keeps every off-diagonal block once and the product
+ * applies it and its transpose from one read.  Like the reference's converter only the FIRST
+ * index of every list is used (contiguous ranges are assumed, src/vbcrs.jl:183-184,230-240). */
+int bsm_vbcrs_create_from_symmetric(int dtype, int64_t nrows, int64_t ncols, int64_t ndiag,
+                                    const void *const *diag, const int64_t *dsize,
+                                    const int64_t *dld, const int64_t *diagstart, int64_t noff,
+                                    const void *const *off, const int64_t *m, const int64_t *n,
+                                    const int64_t *ld, const int64_t *rowstart,
+                                    const int64_t *colstart, const bsm_options *opts,
+                                    bsm_matrix_t *out);
+
 /* BlockSparseMatrix(blocks, rowindices, colindices, size; scheduler, coloringalgorithm)
  * -- reference src/blockmatrix.jl:62-109.  rowidx[b] has m[b] entries, colidx[b] n[b]. */
 int bsm_blocksparse_create(int dtype, int64_t nrows, int64_t ncols, int64_t nblocks,
@@ -157,6 +172,13 @@ int bsm_stats(bsm_matrix_t A, bsm_stats_t *out);
  * Only available on analysis-only handles (BSM_DEVICE_NONE), which keep the host copy.
  * Call with out == NULL to obtain the size in bytes. */
 int bsm_get_image(bsm_matrix_t A, int which, void *out, int64_t *nbytes);
+
+/* color(conflictgraph(ColorInfo(lists)); algorithm).colors -- reference src/coloring.jl:15-61 +
+ * GraphsColoring.jl (not in the reference tree).  Two lists conflict iff they share an index.
+ * Deterministic DSATUR (specification: oracle/bsm_oracle.c).  lists[b] has lens[b] 1-based
+ * entries; color_out[b] receives the 0-based colour of list b; *ncolors the number of colours. */
+int bsm_color(int64_t nlists, const int64_t *const *lists, const int64_t *lens, int64_t *color_out,
+              int64_t *ncolors);
 
 int bsm_destroy(bsm_matrix_t A);
 

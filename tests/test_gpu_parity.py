@@ -105,15 +105,17 @@ def test_vbcrs_from_symmetric_matches_symmetric(torch_cuda, bsm, key):
     # mount, so a contiguous synthetic symmetric operator stands in for it)
     p = bsm.synthetic.config5(n=3000, lo=1, hi=40, halfband=3, seed=0xB5A5 + (key == "sphere"))
     S = bsm.synthetic.build(p)
-    V = bsm.VariableBlockCompressedRowStorage(S)
-    assert bsm.nnz(S) == bsm.nnz(V)
-    rng = np.random.default_rng(2)
-    for _ in range(3):
-        x = rand_vec(rng, p["size"][1], np.float64)
-        sx = gpu_mul(torch_cuda, bsm, S, N, x, np.zeros_like(x), 1, 0, True)
-        for op in (N, T, Cc):
-            vx = gpu_mul(torch_cuda, bsm, V, op if op != Cc else T, x, np.zeros_like(x), 1, 0, True)
-            assert relerr(vx, sx) < 1e-12
+    # the view (off-diagonal blocks stored once) and the reference-style materialised conversion
+    for V in (bsm.VariableBlockCompressedRowStorage(S),
+              bsm.VariableBlockCompressedRowStorage(S, materialize=True)):
+        assert bsm.nnz(S) == bsm.nnz(V)
+        rng = np.random.default_rng(2)
+        for _ in range(3):
+            x = rand_vec(rng, p["size"][1], np.float64)
+            sx = gpu_mul(torch_cuda, bsm, S, N, x, np.zeros_like(x), 1, 0, True)
+            for op in (N, T, Cc):
+                vx = gpu_mul(torch_cuda, bsm, V, op if op != Cc else T, x, np.zeros_like(x), 1, 0, True)
+                assert relerr(vx, sx) < 1e-12
 
 
 # ---- synthetic configs of BASELINE.json -----------------------------------------------------------

@@ -86,6 +86,16 @@ def test_colouring_equals_oracle_spec_and_is_valid(bsm, oracle, key):
     assert B.transposecolors == oracle.color_dsatur(q["colindices"])
 
 
+def test_colorinfo_adapter(bsm, oracle):
+    # reference src/coloring.jl:45-61: conflicts() hands (1:n, functor, 1:maxindex) to the colouring
+    lists = [[1, 2], [2, 3], [4], [3, 9]]
+    info = bsm.ColorInfo(lists)
+    ids, functor, rng = bsm.conflicts(info)
+    assert list(ids) == [1, 2, 3, 4] and list(functor(2)) == [2, 3] and rng == range(1, 10)
+    classes = bsm.color(info)
+    assert classes == oracle.color_dsatur(lists) and oracle.color_check(lists, classes)
+
+
 def test_colouring_random_lists(bsm, oracle):
     rng = np.random.default_rng(7)
     for _ in range(10):
@@ -242,6 +252,39 @@ def test_image_vbcrs_from_symmetric_and_blocksparse(bsm, oracle):
     V2 = bsm.VariableBlockCompressedRowStorage(B, device=NODEV)
     x, y0 = rand_vec(rng, 600, np.float64), rand_vec(rng, 600, np.float64)
     assert relerr(interpret_image(V2, N, x, y0), interpret_image(B, N, x, y0)) < 1e-13
+
+
+def test_vbcrs_symmetric_view_equals_materialised_conversion(bsm, oracle):
+    # VariableBlockCompressedRowStorage(sbm): the view keeps every off-diagonal block once; the
+    # reference-style conversion materialises the transposes (src/vbcrs.jl:222-241).  Bookkeeping
+    # must be identical, products equal, nnz equal (test/test_vbcrs.jl:65-87).
+    p = bsm.synthetic.config5(n=3000, lo=1, hi=90, halfband=3)
+    S = bsm.synthetic.build(p, device=NODEV)
+    V = bsm.VariableBlockCompressedRowStorage(S, device=NODEV)
+    M = bsm.VariableBlockCompressedRowStorage(S, device=NODEV, materialize=True)
+    assert bsm.nnz(S) == bsm.nnz(V) == bsm.nnz(M)
+    assert M.stats()["stored_entries"] == bsm.nnz(S)
+    assert V.stats()["stored_entries"] == S.stats()["stored_entries"] < bsm.nnz(S)
+    for f in ("perm", "rowptr", "colindices", "rowindices"):
+        assert np.array_equal(getattr(V, f), getattr(M, f))
+    # bookkeeping against the oracle's restatement of the constructor on the expanded list
+    nd = len(p["diagonals"])
+    rs = ([int(d[0]) for d in p["diagonalindices"]] + [int(r[0]) for r in p["rowindices"]]
+          + [int(c[0]) for c in p["colindices"]])
+    cs = ([int(d[0]) for d in p["diagonalindices"]] + [int(c[0]) for c in p["colindices"]]
+          + [int(r[0]) for r in p["rowindices"]])
+    perm, rowptr, colind, rowind = oracle.vbcrs_build(rs, cs)
+    assert np.array_equal(V.perm, perm) and np.array_equal(V.rowptr, rowptr)
+    assert np.array_equal(V.colindices, colind) and np.array_equal(V.rowindices, rowind)
+    assert len(V.blocks) == nd + 2 * len(p["offdiagonals"])
+    assert abs(bsm.sparse(V) - bsm.sparse(S)).max() == 0
+    rng = np.random.default_rng(1)
+    n = p["size"][0]
+    x, y0 = rand_vec(rng, n, np.float64), rand_vec(rng, n, np.float64)
+    ref = oracle_mul(oracle, p, N, x, y0, 0.5, 2.0, False)
+    for A in (V, M):
+        for op in (N, T):
+            assert relerr(interpret_image(A, op, x, y0, 0.5, 2.0, False), ref) < 1e-13
 
 
 def test_own_range_limits_scale_work(bsm):
