@@ -43,8 +43,7 @@ _lib = None
 EXPORTS = ["bsm_options_default", "bsm_vbcrs_create", "bsm_vbcrs_create_from_symmetric",
            "bsm_blocksparse_create",
            "bsm_symmetric_create", "bsm_mul", "bsm_get_bookkeeping", "bsm_get_image", "bsm_stats",
-           "bsm_destroy",
-           "bsm_last_error", "bsm_version"]
+           "bsm_color", "bsm_destroy", "bsm_last_error", "bsm_version"]
 
 
 def lib():
