@@ -21,7 +21,7 @@ BSM_DEVICE_CURRENT, BSM_DEVICE_NONE = -1, -2
 
 class BsmOptions(C.Structure):
     _fields_ = [("struct_size", C.c_int32), ("device", C.c_int32), ("scheduler", C.c_int32),
-                ("accumulate", C.c_int32), ("validate", C.c_int32), ("reserved0", C.c_int32),
+                ("accumulate", C.c_int32), ("validate", C.c_int32), ("transpose_image", C.c_int32),
                 ("own_lo", C.c_int64), ("own_hi", C.c_int64), ("reserved", C.c_int64 * 4)]
 
 
@@ -51,6 +51,14 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
+    if not os.path.exists(LIB_PATH):
+        # compile on demand (hipcc --offload-arch=gfx950, in-tree); this is a build step, not a
+        # fallback: without the HIP library nothing below works
+        import subprocess
+        try:
+            subprocess.check_call(["make", "-s", "-C", os.path.join(_HERE, "csrc")])
+        except Exception:
+            pass
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} not found: the HIP extension has not been built. Run "

@@ -137,14 +137,21 @@ struct Item {
 };
 
 template <typename U>
-void pack_chunk(const U *src, int64_t ld, int ra, int mc, int64_t n, int64_t woff, int E, U *dst) {
-    // dst[(s*mc + i)*E + e] = src[(ra+i) + w*ld],  s*E + e = woff + w
+void pack_chunk(const U *src, int64_t ld, int ra, int mc, int64_t n, int64_t woff, int E, bool trans,
+                U *dst) {
+    // dst[(s*mc + i)*E + e] = B[ra+i, w],  s*E + e = woff + w;
+    // B[r, w] = src[r + w*ld] (stored as is) or src[w + r*ld] (logical block = transpose of storage)
     for (int64_t w = 0; w < n; w++) {
         const int64_t s = (woff + w) / E;
         const int e = (int)((woff + w) % E);
-        const U *col = src + ra + w * ld;
         U *d = dst + (s * mc) * E + e;
-        for (int i = 0; i < mc; i++) d[(int64_t)i * E] = col[i];
+        if (!trans) {
+            const U *col = src + ra + w * ld;
+            for (int i = 0; i < mc; i++) d[(int64_t)i * E] = col[i];
+        } else {
+            const U *row = src + w + (int64_t)ra * ld;
+            for (int i = 0; i < mc; i++) d[(int64_t)i * E] = row[(int64_t)i * ld];
+        }
     }
 }
 
@@ -193,7 +200,8 @@ std::string Analysis::build(int mtype_, int dtype_, int64_t nrows_, int64_t ncol
         const BlockIn &B = blocks[b];
         if (B.m < 0 || B.n < 0) return "block " + std::to_string(b + 1) + ": negative size";
         if (B.m > 0 && B.n > 0 && !B.data) return "block " + std::to_string(b + 1) + ": null data";
-        if (B.ld < std::max<int64_t>(B.m, 1)) return "block " + std::to_string(b + 1) + ": ld < m";
+        if (B.ld < std::max<int64_t>(B.trans ? B.n : B.m, 1))
+            return "block " + std::to_string(b + 1) + ": ld < m";
         if (B.m > 0 && !B.ridx && (B.r0 < 1 || B.r0 + B.m - 1 > rlim))
             return "block " + std::to_string(b + 1) + ": row range outside matrix";
         if (B.n > 0 && !B.cidx && (B.c0 < 1 || B.c0 + B.n - 1 > clim))
@@ -379,11 +387,11 @@ std::string Analysis::build(int mtype_, int dtype_, int64_t nrows_, int64_t ncol
                 const BlockIn &B = blocks[c.blk];
                 char *dst = values.data() + (size_t)groups[c.group].val_off * 16;
                 if (es == 4)
-                    pack_chunk<uint32_t>((const uint32_t *)B.data, B.ld, c.ra, c.mc, B.n, c.woff, E, (uint32_t *)dst);
+                    pack_chunk<uint32_t>((const uint32_t *)B.data, B.ld, c.ra, c.mc, B.n, c.woff, E, B.trans, (uint32_t *)dst);
                 else if (es == 8)
-                    pack_chunk<uint64_t>((const uint64_t *)B.data, B.ld, c.ra, c.mc, B.n, c.woff, E, (uint64_t *)dst);
+                    pack_chunk<uint64_t>((const uint64_t *)B.data, B.ld, c.ra, c.mc, B.n, c.woff, E, B.trans, (uint64_t *)dst);
                 else
-                    pack_chunk<U16>((const U16 *)B.data, B.ld, c.ra, c.mc, B.n, c.woff, E, (U16 *)dst);
+                    pack_chunk<U16>((const U16 *)B.data, B.ld, c.ra, c.mc, B.n, c.woff, E, B.trans, (U16 *)dst);
             }
         };
         std::vector<std::thread> th;

@@ -19,6 +19,7 @@ struct BlockIn {
     const int64_t *cidx;  // 1-based col index list (n entries) or nullptr -> contiguous at c0
     int64_t r0, c0;       // 1-based first row / column when the lists are null
     int kind;             // KIND_*
+    bool trans = false;   // the logical m x n block is the TRANSPOSE of the stored n x m array
 };
 
 struct Tunables {

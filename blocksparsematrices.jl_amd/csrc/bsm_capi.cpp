@@ -18,6 +18,11 @@ struct bsm_matrix_s {
     Analysis an;
     DeviceImage img;
     bool on_device = false;
+    // optional second ordering (bsm_options.transpose_image): the transposed operator as its own
+    // forward image
+    bool has_t = false;
+    Analysis an_t;
+    DeviceImage img_t;
 };
 
 static thread_local std::string g_err;
@@ -95,14 +100,12 @@ void free_image(DeviceImage &img) {
     }
 }
 
-int finish_create(bsm_matrix_s *A, const bsm_options &o, bsm_matrix_t *out) {
-    Analysis &an = A->an;
-    DeviceImage &img = A->img;
+void fill_image(const Analysis &an, const bsm_options &o, bool use_own, DeviceImage &img) {
     img.dtype = an.dtype;
     img.nrows = an.nrows;
     img.ncols = an.ncols;
-    img.own_lo = (o.own_lo > 0) ? o.own_lo - 1 : 0;
-    img.own_hi = (o.own_hi > 0) ? std::min<long long>(o.own_hi, an.nrows) : an.nrows;
+    img.own_lo = (use_own && o.own_lo > 0) ? o.own_lo - 1 : 0;
+    img.own_hi = (use_own && o.own_hi > 0) ? std::min<long long>(o.own_hi, an.nrows) : an.nrows;
     img.nwg_main = an.nwg_main;
     img.nwg_total = an.nwg_total;
     img.exclusive_fwd = an.exclusive_fwd && o.accumulate == BSM_ACC_AUTO;
@@ -111,7 +114,24 @@ int finish_create(bsm_matrix_s *A, const bsm_options &o, bsm_matrix_t *out) {
         if (w.work == WORK_PANEL && w.npieces > 0 && w.first.kind == KIND_OFF) img.has_off = true;
     if (!img.exclusive_fwd) img.nwg_total = img.nwg_main;
     img.color_wg_ptr.assign(an.color_wg_ptr.begin(), an.color_wg_ptr.end());
+    img.device_bytes = (long long)(an.values.size() + an.rows.size() * 4 + an.cols.size() * 4 +
+                                   an.waves.size() * sizeof(WaveWork));
+}
 
+hipError_t upload_image(Analysis &an, DeviceImage &img, int dev) {
+    img.device = dev;
+    long long total = 0;
+    hipError_t e = upload(an.values, &img.d_values, total);
+    if (e == hipSuccess) e = upload(an.rows, &img.d_rows, total);
+    if (e == hipSuccess) e = upload(an.cols, &img.d_cols, total);
+    if (e == hipSuccess) e = upload(an.waves, &img.d_waves, total);
+    if (e == hipSuccess) std::vector<char>().swap(an.values);  // packed host copy no longer needed
+    return e;
+}
+
+int finish_create(bsm_matrix_s *A, const bsm_options &o, bsm_matrix_t *out) {
+    fill_image(A->an, o, true, A->img);
+    if (A->has_t) fill_image(A->an_t, o, false, A->img_t);
     if (o.device != BSM_DEVICE_NONE) {
         int dev = o.device;
         hipError_t e;
@@ -128,27 +148,44 @@ int finish_create(bsm_matrix_s *A, const bsm_options &o, bsm_matrix_t *out) {
             delete A;
             return hip_fail(e, "hipSetDevice");
         }
-        img.device = dev;
-        long long total = 0;
-        e = upload(an.values, &img.d_values, total);
-        if (e == hipSuccess) e = upload(an.rows, &img.d_rows, total);
-        if (e == hipSuccess) e = upload(an.cols, &img.d_cols, total);
-        if (e == hipSuccess) e = upload(an.waves, &img.d_waves, total);
+        e = upload_image(A->an, A->img, dev);
+        if (e == hipSuccess && A->has_t) e = upload_image(A->an_t, A->img_t, dev);
         if (e != hipSuccess) {
-            free_image(img);
+            free_image(A->img);
+            free_image(A->img_t);
             delete A;
             return hip_fail(e, "device upload");
         }
-        img.device_bytes = total;
         A->on_device = true;
-        // the packed host copy is no longer needed
-        std::vector<char>().swap(an.values);
-    } else {
-        img.device_bytes = (long long)(an.values.size() + an.rows.size() * 4 + an.cols.size() * 4 +
-                                       an.waves.size() * sizeof(WaveWork));
     }
     *out = A;
     return BSM_OK;
+}
+
+// Second ordering: the transposed operator as a forward image (rows <-> columns, blocks read
+// transposed by the packer).  Built from the same caller arrays, before they are released.
+std::string build_transpose_image(bsm_matrix_s *A, const std::vector<BlockIn> &in, const bsm_options &o) {
+    std::vector<BlockIn> t(in.size());
+    for (size_t b = 0; b < in.size(); b++) {
+        const BlockIn &B = in[b];
+        BlockIn &Tb = t[b];
+        Tb.data = B.data;
+        Tb.m = B.n;
+        Tb.n = B.m;
+        Tb.ld = B.ld;
+        Tb.ridx = B.cidx;
+        Tb.cidx = B.ridx;
+        Tb.r0 = B.c0;
+        Tb.c0 = B.r0;
+        Tb.kind = KIND_PLAIN;
+        Tb.trans = !B.trans;
+    }
+    AnalysisOptions a;
+    a.scheduler = 0;
+    a.accumulate = o.accumulate;
+    std::string err = A->an_t.build(MT_BLOCKSPARSE, A->an.dtype, A->an.ncols, A->an.nrows, t, a);
+    if (err.empty()) A->has_t = true;
+    return err;
 }
 
 AnalysisOptions to_aopt(const bsm_options &o) {
@@ -179,6 +216,21 @@ extern "C" int bsm_vbcrs_create(int dtype, int64_t nrows, int64_t ncols, int64_t
         bsm_matrix_s *A = new bsm_matrix_s();
         std::string err = A->an.build_vbcrs(dtype, nrows, ncols, nblocks, blocks, m, n, ld, rowstart,
                                             colstart, to_aopt(o));
+        if (err.empty() && o.transpose_image) {
+            std::vector<BlockIn> in((size_t)nblocks);
+            for (int64_t b = 0; b < nblocks; b++) {
+                BlockIn &B = in[b];
+                B.data = (const char *)blocks[b];
+                B.m = m[b];
+                B.n = n[b];
+                B.ld = ld[b];
+                B.ridx = B.cidx = nullptr;
+                B.r0 = rowstart[b];
+                B.c0 = colstart[b];
+                B.kind = KIND_PLAIN;
+            }
+            err = build_transpose_image(A, in, o);
+        }
         if (!err.empty()) {
             delete A;
             return fail(BSM_ERR_INVALID, err);
@@ -254,6 +306,7 @@ extern "C" int bsm_blocksparse_create(int dtype, int64_t nrows, int64_t ncols, i
         }
         bsm_matrix_s *A = new bsm_matrix_s();
         std::string err = A->an.build(MT_BLOCKSPARSE, dtype, nrows, ncols, in, to_aopt(o));
+        if (err.empty() && o.transpose_image) err = build_transpose_image(A, in, o);
         if (!err.empty()) {
             delete A;
             return fail(BSM_ERR_INVALID, err);
@@ -332,28 +385,32 @@ extern "C" int bsm_mul(bsm_matrix_t A, int op, const void *x, void *y, const voi
     if (!x || !y) return fail(BSM_ERR_INVALID, "null vector");
     if (!A->on_device)
         return fail(BSM_ERR_DEVICE, "handle has no device image (created with BSM_DEVICE_NONE)");
-    const DeviceImage &img = A->img;
+    // transposed products run forward on the second ordering when the handle has one
+    const bool use_t = (op != BSM_OP_N) && A->has_t;
+    const DeviceImage &img = use_t ? A->img_t : A->img;
+    const bool opT = (op != BSM_OP_N) && !use_t;
+    const bool conj = (op == BSM_OP_C);
     DeviceGuard guard;
     hipError_t e = guard.enter(img.device);
     if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
     hipStream_t st = (hipStream_t)stream;
     if (memspace == BSM_MEM_DEVICE) {
-        e = launch_mul(img, op, x, y, alpha, beta, beta_strong_zero, st);
+        e = launch_mul(img, opT, conj, x, y, alpha, beta, beta_strong_zero, st);
         if (e != hipSuccess) return hip_fail(e, "kernel launch");
         return BSM_OK;
     }
     if (memspace != BSM_MEM_HOST) return fail(BSM_ERR_INVALID, "bad memspace");
     // host vectors: stage through device buffers (PCIe), synchronous
     const size_t es = (size_t)A->an.es;
-    const size_t xlen = (size_t)(op == 0 ? img.ncols : img.nrows);
-    const size_t ylen = (size_t)(op == 0 ? img.nrows : img.ncols);
+    const size_t xlen = (size_t)(op == 0 ? A->img.ncols : A->img.nrows);
+    const size_t ylen = (size_t)(op == 0 ? A->img.nrows : A->img.ncols);
     void *dx = nullptr, *dy = nullptr;
     e = hipMalloc(&dx, xlen * es + 16);
     if (e == hipSuccess) e = hipMalloc(&dy, ylen * es + 16);
     if (e == hipSuccess) e = hipMemcpyAsync(dx, x, xlen * es, hipMemcpyHostToDevice, st);
     if (e == hipSuccess && !beta_strong_zero)
         e = hipMemcpyAsync(dy, y, ylen * es, hipMemcpyHostToDevice, st);
-    if (e == hipSuccess) e = launch_mul(img, op, dx, dy, alpha, beta, beta_strong_zero, st);
+    if (e == hipSuccess) e = launch_mul(img, opT, conj, dx, dy, alpha, beta, beta_strong_zero, st);
     if (e == hipSuccess) e = hipMemcpyAsync(y, dy, ylen * es, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (dx) (void)hipFree(dx);
@@ -409,7 +466,9 @@ extern "C" int bsm_get_bookkeeping(bsm_matrix_t A, int which, int64_t *out, int6
 extern "C" int bsm_get_image(bsm_matrix_t A, int which, void *out, int64_t *nbytes) {
     if (!A || !nbytes) return fail(BSM_ERR_INVALID, "null argument");
     if (A->on_device) return fail(BSM_ERR_UNSUPPORTED, "image dump needs an analysis-only handle");
-    const Analysis &an = A->an;
+    if (which >= 16 && !A->has_t) return fail(BSM_ERR_INVALID, "handle has no transposed image");
+    const Analysis &an = (which >= 16) ? A->an_t : A->an;
+    which &= 15;
     const void *src = nullptr;
     size_t bytes = 0;
     switch (which) {
@@ -433,7 +492,7 @@ extern "C" int bsm_stats(bsm_matrix_t A, bsm_stats_t *out) {
     out->nnz = A->an.nnz;
     out->stored_entries = A->an.stored_entries;
     out->alg_bytes = A->an.alg_bytes;
-    out->device_bytes = A->img.device_bytes;
+    out->device_bytes = A->img.device_bytes + (A->has_t ? A->img_t.device_bytes : 0);
     out->npanels = A->an.ngroups;
     out->ntasks = (int64_t)A->an.waves.size();
     out->nworkgroups = A->img.nwg_total;
@@ -471,6 +530,7 @@ extern "C" int bsm_destroy(bsm_matrix_t A) {
         DeviceGuard guard;
         (void)guard.enter(A->img.device);
         free_image(A->img);
+        free_image(A->img_t);
     }
     delete A;
     return BSM_OK;

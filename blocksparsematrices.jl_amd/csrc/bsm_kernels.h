@@ -23,7 +23,8 @@ struct DeviceImage {
 
 // Enqueues y = alpha*op(A)*x + beta*y on `stream`.  x, y device pointers.  No allocation,
 // no synchronisation (graph-capturable).
-hipError_t launch_mul(const DeviceImage &img, int op, const void *x, void *y, const void *alpha,
-                      const void *beta, int strong_zero, hipStream_t stream);
+// opT: apply the transposed operator of the image; conj: conjugate every stored entry.
+hipError_t launch_mul(const DeviceImage &img, bool opT, bool conj, const void *x, void *y,
+                      const void *alpha, const void *beta, int strong_zero, hipStream_t stream);
 
 }  // namespace bsm

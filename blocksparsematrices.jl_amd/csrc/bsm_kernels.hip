@@ -417,15 +417,14 @@ template <> bool is_one(c64 v) { return v.re == 1.f && v.im == 0.f; }
 template <> bool is_one(c128 v) { return v.re == 1.0 && v.im == 0.0; }
 
 template <typename T, int L>
-static hipError_t launch_typed(const DeviceImage &img, int op, const void *x, void *y,
+static hipError_t launch_typed(const DeviceImage &img, bool opT, bool conj, const void *x, void *y,
                                const void *alpha_p, const void *beta_p, int strong_zero,
                                hipStream_t stream) {
     const T alpha = load_scalar<T>(alpha_p, 1.0);
     const T beta = load_scalar<T>(beta_p, 0.0);
-    const bool opT = (op != 0);
     int flags = 0;
     if (strong_zero) flags |= FLAG_STRONG_ZERO;
-    if (op == 2) flags |= FLAG_CONJ;
+    if (conj) flags |= FLAG_CONJ;
     if (opT) flags |= FLAG_OPT;
     const WaveWork *waves = (const WaveWork *)img.d_waves;
     const uint4 *values = (const uint4 *)img.d_values;
@@ -487,13 +486,13 @@ static hipError_t launch_typed(const DeviceImage &img, int op, const void *x, vo
     return hipGetLastError();
 }
 
-hipError_t launch_mul(const DeviceImage &img, int op, const void *x, void *y, const void *alpha,
-                      const void *beta, int strong_zero, hipStream_t stream) {
+hipError_t launch_mul(const DeviceImage &img, bool opT, bool conj, const void *x, void *y,
+                      const void *alpha, const void *beta, int strong_zero, hipStream_t stream) {
     switch (img.dtype) {
-        case 0: return launch_typed<float, 8>(img, op, x, y, alpha, beta, strong_zero, stream);
-        case 1: return launch_typed<double, 8>(img, op, x, y, alpha, beta, strong_zero, stream);
-        case 2: return launch_typed<c64, 8>(img, op, x, y, alpha, beta, strong_zero, stream);
-        case 3: return launch_typed<c128, 8>(img, op, x, y, alpha, beta, strong_zero, stream);
+        case 0: return launch_typed<float, 8>(img, opT, conj, x, y, alpha, beta, strong_zero, stream);
+        case 1: return launch_typed<double, 8>(img, opT, conj, x, y, alpha, beta, strong_zero, stream);
+        case 2: return launch_typed<c64, 8>(img, opT, conj, x, y, alpha, beta, strong_zero, stream);
+        case 3: return launch_typed<c128, 8>(img, opT, conj, x, y, alpha, beta, strong_zero, stream);
     }
     return hipErrorInvalidValue;
 }

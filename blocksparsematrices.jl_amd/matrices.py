@@ -95,7 +95,7 @@ def _fblocks(blocks, dt):
     return out
 
 
-def _options(scheduler, device, accumulate, own=None):
+def _options(scheduler, device, accumulate, own=None, transpose_image=False):
     o = L.BsmOptions()
     L.lib().bsm_options_default(C.byref(o))
     o.scheduler = L.BSM_SCHED_SERIAL if isserial(scheduler) else L.BSM_SCHED_DYNAMIC
@@ -104,6 +104,7 @@ def _options(scheduler, device, accumulate, own=None):
                     "colored": L.BSM_ACC_COLORED}[accumulate]
     if own is not None:
         o.own_lo, o.own_hi = int(own[0]), int(own[1])
+    o.transpose_image = 1 if transpose_image else 0
     return o
 
 
@@ -287,7 +288,8 @@ class BlockSparseMatrix(AbstractBlockMatrix):
     colors, transposecolors, scheduler."""
 
     def __init__(self, blocks, rowindices, colindices, size, cols=None, *, scheduler=None,
-                 coloringalgorithm=None, device=None, accumulate="auto", own=None):
+                 coloringalgorithm=None, device=None, accumulate="auto", own=None,
+                 transpose_image=False):
         if cols is not None:  # (blocks, rowindices, colindices, rows, cols) form, :81-89
             size = (size, cols)
         scheduler = SerialScheduler() if scheduler is None else scheduler
@@ -305,7 +307,7 @@ class BlockSparseMatrix(AbstractBlockMatrix):
         n = _i64([b.shape[1] for b in self.blocks])
         ld = _i64([max(b.shape[0], 1) for b in self.blocks])
         dev = _default_device() if device is None else device
-        o = _options(scheduler, dev, accumulate, own)
+        o = _options(scheduler, dev, accumulate, own, transpose_image)
         h = C.c_void_p()
         I = C.POINTER(C.c_int64)
         L.check(L.lib().bsm_blocksparse_create(
@@ -367,7 +369,8 @@ class VariableBlockCompressedRowStorage(AbstractBlockMatrix):
     rowindices (per block row), size, scheduler -- all 1-based like the reference."""
 
     def __init__(self, matrices, rowindices=None, colindices=None, matrixsize=None, *,
-                 scheduler=None, device=None, accumulate="auto", own=None, materialize=False):
+                 scheduler=None, device=None, accumulate="auto", own=None, materialize=False,
+                 transpose_image=False):
         I = C.POINTER(C.c_int64)
         h = C.c_void_p()
         dev = _default_device() if device is None else device
@@ -425,7 +428,7 @@ class VariableBlockCompressedRowStorage(AbstractBlockMatrix):
             m = _i64([b.shape[0] for b in fb])
             n = _i64([b.shape[1] for b in fb])
             ld = _i64([max(b.shape[0], 1) for b in fb])
-            o = _options(scheduler, dev, accumulate, own)
+            o = _options(scheduler, dev, accumulate, own, transpose_image)
             L.check(L.lib().bsm_vbcrs_create(
                 _DT[dt], int(matrixsize[0]), int(matrixsize[1]), len(fb), _ptrs(fb),
                 m.ctypes.data_as(I), n.ctypes.data_as(I), ld.ctypes.data_as(I), rs.ctypes.data_as(I),

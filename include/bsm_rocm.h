@@ -69,7 +69,11 @@ typedef struct {
     int32_t scheduler;   /* bsm_scheduler */
     int32_t accumulate;  /* bsm_accumulate */
     int32_t validate;    /* 1: range-check every index at create time (default 1) */
-    int32_t reserved0;
+    /* 1: VBCRS / BlockSparseMatrix handles also keep a SECOND, transposed ordering of the blocks
+     * (the reference's own TODO, src/vbcrs.jl:124): transpose(A)*x and A'*x then run as a forward
+     * product on it -- one launch, no atomics, bitwise reproducible -- at twice the device
+     * memory.  0 (default): the transposed products run on the single image with atomics. */
+    int32_t transpose_image;
     /* rows of y this handle is responsible for scaling by beta (1-based, inclusive);
      * 0,0 = all rows.  Used when block rows are partitioned over several GPUs. */
     int64_t own_lo, own_hi;
@@ -169,6 +173,7 @@ int bsm_stats(bsm_matrix_t A, bsm_stats_t *out);
 /* Debug / test hook: copies one array of the packed device image (host copy) out.
  * which: 0 values (bytes), 1 rows (int32), 2 cols (int32), 3 waves (64-byte records;
  * layout in blocksparsematrices.jl_amd/csrc/bsm_layout.h).
+ * Add 16 to `which` for the arrays of the transposed image (bsm_options.transpose_image).
  * Only available on analysis-only handles (BSM_DEVICE_NONE), which keep the host copy.
  * Call with out == NULL to obtain the size in bytes. */
 int bsm_get_image(bsm_matrix_t A, int which, void *out, int64_t *nbytes);

@@ -23,7 +23,7 @@ BlockSparseMatrices.isserial(::ROCmScheduler) = true   # no host colouring neede
 
 mutable struct BsmOptions           # mirrors bsm_options (72 bytes)
     struct_size::Int32; device::Int32; scheduler::Int32; accumulate::Int32
-    validate::Int32; reserved0::Int32; own_lo::Int64; own_hi::Int64
+    validate::Int32; transpose_image::Int32; own_lo::Int64; own_hi::Int64
     reserved::NTuple{4,Int64}
 end
 

@@ -158,10 +158,11 @@ WORK_NOP, WORK_PANEL, WORK_SCALE = 0, 1, 2
 KIND_OFF = 2
 
 
-def get_image(A):
+def get_image(A, timage=False):
     from bsm_amd import _lib as L
     out = []
     for which, dt in ((0, np.uint8), (1, np.int32), (2, np.int32), (3, WAVE_DT)):
+        which += 16 if timage else 0
         n = C.c_int64(0)
         L.check(L.lib().bsm_get_image(A._h.ptr, which, None, C.byref(n)))
         buf = np.zeros(max(n.value, 1), dtype=np.uint8)
@@ -170,17 +171,34 @@ def get_image(A):
     return out
 
 
-def interpret_image(A, op, x, y0, alpha=1, beta=0, strong=True):
+def _image_exclusive(waves, rows, ylen):
+    """every y row produced by at most one lead wave group (the library's exclusivity proof)"""
+    seen = np.zeros(ylen, dtype=np.int32)
+    for W in waves[(waves["work"] == WORK_PANEL) & (waves["lead"] == 1)]:
+        m = int(W["m"])
+        r = (np.arange(W["rbase"], W["rbase"] + m) if W["rbase"] >= 0 else rows[W["row_off"]:W["row_off"] + m])
+        np.add.at(seen, r, 1)
+    return bool(np.all(seen <= 1))
+
+
+def interpret_image(A, op, x, y0, alpha=1, beta=0, strong=True, timage=False):
     """Executes the packed image the way the HIP kernel walks it (same descriptors and index
-    arithmetic, numpy arithmetic) -- checks packing + schedule on CPU."""
-    values, rows, cols, waves = get_image(A)
+    arithmetic, numpy arithmetic) -- checks packing + schedule on CPU.
+    timage: run op T / C as a FORWARD product on the handle's second (transposed) ordering."""
+    values, rows, cols, waves = get_image(A, timage)
     dt = A.dtype
     E = 16 // dt.itemsize
     vals = values.view(dt)
     st = A.stats()
-    opT = op != N
     conj = op == Cc
-    direct = (not opT) and st["exclusive"] == 1
+    if timage:
+        assert op != N
+        opT = False
+        works = waves["work"]
+        direct = bool(np.any(works == WORK_SCALE)) or _image_exclusive(waves, rows, len(y0))
+    else:
+        opT = op != N
+        direct = (not opT) and st["exclusive"] == 1
     y = np.array(y0, copy=True)
     if not direct:
         y[:] = 0 if strong else beta * y

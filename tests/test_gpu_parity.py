@@ -268,3 +268,20 @@ def test_coloured_mode_config3_reduced(torch_cuda, bsm, oracle):
     q = bsm.synthetic.config1()
     B = bsm.synthetic.build(q, accumulate="colored")
     check_all(torch_cuda, bsm, oracle, q, B, np.float64, host_too=False)
+
+
+# ---- second ordering: transposed products as a forward launch on a transposed image -------------------
+def test_transpose_image_parity_and_determinism(torch_cuda, bsm, oracle):
+    p = bsm.synthetic.config2(n=30000, nblocks=1500)
+    A = bsm.synthetic.build(p, transpose_image=True)
+    check_all(torch_cuda, bsm, oracle, p, A, np.float64, host_too=False)
+    x = p["x"]
+    first = gpu_mul(torch_cuda, bsm, A, T, x, np.zeros_like(x), 1, 0, True)
+    for _ in range(3):  # no atomics on this path: bitwise reproducible
+        assert np.array_equal(first, gpu_mul(torch_cuda, bsm, A, T, x, np.zeros_like(x), 1, 0, True))
+    q = fixture_as_blocksparse("sphere")
+    B = bsm.synthetic.build(q, transpose_image=True)
+    check_all(torch_cuda, bsm, oracle, q, B, np.complex128, host_too=False)
+    r = bsm.synthetic.config1()
+    Cm = bsm.synthetic.build(r, transpose_image=True)
+    check_all(torch_cuda, bsm, oracle, r, Cm, np.float64, host_too=False)

@@ -287,6 +287,35 @@ def test_vbcrs_symmetric_view_equals_materialised_conversion(bsm, oracle):
             assert relerr(interpret_image(A, op, x, y0, 0.5, 2.0, False), ref) < 1e-13
 
 
+def test_second_ordering_transposed_image(bsm, oracle):
+    # bsm_options.transpose_image: op T / C run FORWARD on a second, transposed ordering
+    # (the reference author's TODO, src/vbcrs.jl:124)
+    rng = np.random.default_rng(12)
+    p = bsm.synthetic.config2(n=4000, nblocks=300)
+    A = bsm.synthetic.build(p, device=NODEV, transpose_image=True)
+    A1 = bsm.synthetic.build(p, device=NODEV)
+    assert A.stats()["device_bytes"] > 1.9 * A1.stats()["device_bytes"]
+    x, y0 = rand_vec(rng, 4000, np.float64), rand_vec(rng, 4000, np.float64)
+    for alpha, beta, strong in ((1, 0, True), (0.5, 2.0, False)):
+        ref = oracle_mul(oracle, p, T, x, y0, alpha, beta, strong)
+        assert relerr(interpret_image(A, T, x, y0, alpha, beta, strong, timage=True), ref) < 1e-13
+    q = fixture_as_blocksparse("cuboid")
+    B = bsm.synthetic.build(q, device=NODEV, transpose_image=True)
+    n = q["size"][0]
+    x, y0 = rand_vec(rng, n, np.complex128), rand_vec(rng, n, np.complex128)
+    for op in (T, Cc):
+        ref = oracle_mul(oracle, q, op, x, y0, 1j, 2j, False)
+        assert relerr(interpret_image(B, op, x, y0, 1j, 2j, False, timage=True), ref) < 1e-13
+    # rectangular, m > 64 chunks, odd sizes
+    blocks = [np.asfortranarray(rng.standard_normal((130, 7))), np.asfortranarray(rng.standard_normal((5, 9)))]
+    r = dict(kind="blocksparse", blocks=blocks, rowindices=[list(range(20, 150)), [1, 3, 5, 7, 9]],
+             colindices=[[4, 3, 2, 1, 10, 11, 12], list(range(50, 59))], size=(210, 60))
+    Cm = bsm.synthetic.build(r, device=NODEV, transpose_image=True)
+    x, y0 = rand_vec(rng, 210, np.float64), rand_vec(rng, 60, np.float64)
+    ref = oracle_mul(oracle, r, T, x, y0, 0.5, 2.0, False)
+    assert relerr(interpret_image(Cm, T, x, y0, 0.5, 2.0, False, timage=True), ref) < 1e-13
+
+
 def test_own_range_limits_scale_work(bsm):
     p = bsm.synthetic.config2(n=2000, nblocks=40)
     A = bsm.VariableBlockCompressedRowStorage(p["blocks"], p["rowstart"], p["colstart"], p["size"],

@@ -19,7 +19,10 @@ prob = {"c2": lambda: S.config2(), "c3": lambda: S.config3(), "c3s": lambda: S.c
         "c2u": lambda: S.config2(n=100000, lo=36, hi=36, nblocks=5000),
         "c2p": lambda: S.config2(n=100000, lo=32, hi=32, nblocks=6400),
         "c2w": lambda: S.config2(n=100000, lo=64, hi=64, nblocks=1650), "c5s": lambda: S.config5(n=600_000)}[which]()
-A = S.build(prob, accumulate=os.environ.get("KB_ACC", "auto"))
+kw = {"accumulate": os.environ.get("KB_ACC", "auto")}
+if os.environ.get("KB_TIMG") and prob["kind"] != "symmetric":
+    kw["transpose_image"] = True
+A = S.build(prob, **kw)
 st = A.stats()
 x = torch.from_numpy(prob["x"]).cuda()
 ops = [("N", A)]
