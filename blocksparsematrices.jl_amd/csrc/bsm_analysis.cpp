@@ -2,6 +2,8 @@
 #include "bsm_analysis.h"
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <numeric>
@@ -141,16 +143,23 @@ void pack_chunk(const U *src, int64_t ld, int ra, int mc, int64_t n, int64_t wof
                 U *dst) {
     // dst[(s*mc + i)*E + e] = B[ra+i, w],  s*E + e = woff + w;
     // B[r, w] = src[r + w*ld] (stored as is) or src[w + r*ld] (logical block = transpose of storage)
-    for (int64_t w = 0; w < n; w++) {
-        const int64_t s = (woff + w) / E;
-        const int e = (int)((woff + w) % E);
-        U *d = dst + (s * mc) * E + e;
+    // Strip-major: every 16-byte lane unit of the destination is written once, sequentially.
+    const int64_t s_first = woff / E, s_last = (woff + n - 1) / E;
+    for (int64_t s = s_first; s <= s_last; s++) {
+        const int64_t w0 = s * E - woff;  // block column of e = 0 (may be < 0 / >= n at the ends)
+        const int e_lo = (int)std::max<int64_t>(0, -w0);
+        const int e_hi = (int)std::min<int64_t>(E, n - w0);
+        U *d = dst + (s * mc) * E;
         if (!trans) {
-            const U *col = src + ra + w * ld;
-            for (int i = 0; i < mc; i++) d[(int64_t)i * E] = col[i];
+            for (int e = e_lo; e < e_hi; e++) {
+                const U *col = src + ra + (w0 + e) * ld;
+                for (int i = 0; i < mc; i++) d[(int64_t)i * E + e] = col[i];
+            }
         } else {
-            const U *row = src + w + (int64_t)ra * ld;
-            for (int i = 0; i < mc; i++) d[(int64_t)i * E] = row[(int64_t)i * ld];
+            for (int i = 0; i < mc; i++) {
+                const U *row = src + w0 + (int64_t)(ra + i) * ld;
+                for (int e = e_lo; e < e_hi; e++) d[(int64_t)i * E + e] = row[e];
+            }
         }
     }
 }
@@ -179,6 +188,15 @@ std::string Analysis::build(int mtype_, int dtype_, int64_t nrows_, int64_t ncol
     ncols = ncols_;
     opt = opt_;
     tun = Tunables::from_env();
+    const bool timing = std::getenv("BSM_TIMING") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!timing) return;
+        auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[bsm analysis] %-28s %8.1f ms\n", what,
+                     std::chrono::duration<double, std::milli>(now - t_last).count());
+        t_last = now;
+    };
     static const int kEs[4] = {4, 8, 8, 16};
     if (dtype < 0 || dtype > 3) return "unknown dtype";
     es = kEs[dtype];
@@ -230,6 +248,7 @@ std::string Analysis::build(int mtype_, int dtype_, int64_t nrows_, int64_t ncol
         alg_bytes = stored_entries * es + meta + ncols * es + nrows * es;
     }
 
+    lap("validate");
     // ---- chunks (<= 64 rows) and row groups ------------------------------------------
     std::vector<Chunk> chunks;
     std::vector<Group> groups;
@@ -317,6 +336,7 @@ std::string Analysis::build(int mtype_, int dtype_, int64_t nrows_, int64_t ncol
         val_units += (uint64_t)G.mc * (uint64_t)G.strips;
     }
 
+    lap("groups + column lists");
     // ---- forward exclusivity + coverage ------------------------------------------------
     const int64_t own_lo = (opt.own_lo > 0) ? opt.own_lo - 1 : 0;
     const int64_t own_hi = (opt.own_hi > 0) ? std::min(opt.own_hi, nrows) : nrows;  // exclusive
@@ -377,8 +397,16 @@ std::string Analysis::build(int mtype_, int dtype_, int64_t nrows_, int64_t ncol
             for (int64_t id : classes[c]) group_color[id - 1] = (int32_t)c;
     }
 
+    lap("exclusivity / fused colours");
     // ---- pack values ---------------------------------------------------------------------
-    values.assign((size_t)val_units * 16, 0);
+    values.allocate((size_t)val_units * 16);
+    for (const Group &G : groups) {  // zero the padded tail of every panel's last strip
+        const int64_t padcols = G.strips * E - G.width;
+        if (padcols > 0) {
+            char *last = values.data() + ((size_t)G.val_off + (size_t)(G.strips - 1) * G.mc) * 16;
+            std::memset(last, 0, (size_t)G.mc * 16);
+        }
+    }
     {
         const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(tun.pack_threads, (int64_t)chunks.size() / 64 + 1));
         auto worker = [&](int t) {
@@ -400,6 +428,7 @@ std::string Analysis::build(int mtype_, int dtype_, int64_t nrows_, int64_t ncol
         for (auto &x : th) x.join();
     }
 
+    lap("pack values");
     // ---- work items ----------------------------------------------------------------------
     std::vector<Item> items;
     for (int64_t g = 0; g < ngroups; g++) {
@@ -554,8 +583,12 @@ std::string Analysis::build(int mtype_, int dtype_, int64_t nrows_, int64_t ncol
     }
     if (rows.empty()) rows.push_back(0);
     if (cols.empty()) cols.push_back(0);
-    if (values.empty()) values.assign(16, 0);
+    if (values.empty()) {
+        values.allocate(16);
+        std::memset(values.data(), 0, 16);
+    }
 
+    lap("schedule");
     // ---- colouring (reference bookkeeping) ---------------------------------------------------
     for (auto &c : colors) c.clear();
     auto single = [](int64_t n) {
@@ -599,6 +632,7 @@ std::string Analysis::build(int mtype_, int dtype_, int64_t nrows_, int64_t ncol
         colors[1] = color_dsatur(cl, cn);
         colors[2] = color_dsatur(dl, dn);
     }
+    lap("reference colourings");
     return "";
 }
 

@@ -10,6 +10,35 @@
 
 namespace bsm {
 
+// byte buffer whose storage is NOT zero-filled on allocation (the packer writes every byte it
+// needs and zeroes the strip tails itself; a 16 GB memset per create would be pure waste)
+class RawBuffer {
+  public:
+    RawBuffer() = default;
+    RawBuffer(const RawBuffer &) = delete;
+    RawBuffer &operator=(const RawBuffer &) = delete;
+    ~RawBuffer() { release(); }
+    void allocate(size_t n) {
+        release();
+        p_ = n ? static_cast<char *>(::operator new(n)) : nullptr;
+        n_ = n;
+    }
+    void release() {
+        if (p_) ::operator delete(p_);
+        p_ = nullptr;
+        n_ = 0;
+    }
+    char *data() { return p_; }
+    const char *data() const { return p_; }
+    size_t size() const { return n_; }
+    bool empty() const { return n_ == 0; }
+    const char &operator[](size_t i) const { return p_[i]; }
+
+  private:
+    char *p_ = nullptr;
+    size_t n_ = 0;
+};
+
 enum MatType { MT_VBCRS = 0, MT_BLOCKSPARSE = 1, MT_SYMMETRIC = 2 };
 
 struct BlockIn {
@@ -59,7 +88,7 @@ class Analysis {
     int64_t nnz = 0, stored_entries = 0, alg_bytes = 0;
 
     // ---- device image (host copy) ----
-    std::vector<char> values;
+    RawBuffer values;
     std::vector<int32_t> rows, cols;
     std::vector<WaveWork> waves;
     int64_t nwg_main = 0;   // workgroups holding panel work

@@ -85,7 +85,7 @@ int read_options(const bsm_options *opts, bsm_options &o) {
 }
 
 template <typename V> hipError_t upload(const V &v, void **dptr, long long &total) {
-    const size_t bytes = v.size() * sizeof(v[0]);
+    const size_t bytes = v.size() * sizeof(decltype(v[0]));
     hipError_t e = hipMalloc(dptr, bytes ? bytes : 16);
     if (e != hipSuccess) return e;
     total += (long long)bytes;
@@ -125,7 +125,7 @@ hipError_t upload_image(Analysis &an, DeviceImage &img, int dev) {
     if (e == hipSuccess) e = upload(an.rows, &img.d_rows, total);
     if (e == hipSuccess) e = upload(an.cols, &img.d_cols, total);
     if (e == hipSuccess) e = upload(an.waves, &img.d_waves, total);
-    if (e == hipSuccess) std::vector<char>().swap(an.values);  // packed host copy no longer needed
+    if (e == hipSuccess) an.values.release();  // packed host copy no longer needed
     return e;
 }
 
