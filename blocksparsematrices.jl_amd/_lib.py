@@ -42,7 +42,7 @@ _lib = None
 # every symbol include/bsm_rocm.h declares
 EXPORTS = ["bsm_options_default", "bsm_vbcrs_create", "bsm_vbcrs_create_from_symmetric",
            "bsm_blocksparse_create",
-           "bsm_symmetric_create", "bsm_mul", "bsm_get_bookkeeping", "bsm_get_image", "bsm_stats",
+           "bsm_symmetric_create", "bsm_mul", "bsm_mul_multi", "bsm_get_bookkeeping", "bsm_get_image", "bsm_stats",
            "bsm_color", "bsm_destroy", "bsm_last_error", "bsm_version"]
 
 
@@ -82,6 +82,9 @@ def lib():
                                                   C.POINTER(C.c_void_p)]
     L.bsm_mul.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                           C.c_int, C.c_int, C.c_void_p]
+    L.bsm_mul_multi.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,
+                                C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    L.bsm_mul_multi.restype = C.c_int
     L.bsm_get_bookkeeping.argtypes = [C.c_void_p, C.c_int, _I64P, _I64P]
     L.bsm_get_image.argtypes = [C.c_void_p, C.c_int, C.c_void_p, _I64P]
     L.bsm_color.argtypes = [C.c_int64, _PP, _I64P, _I64P, _I64P]

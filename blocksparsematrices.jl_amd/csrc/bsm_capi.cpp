@@ -419,6 +419,56 @@ extern "C" int bsm_mul(bsm_matrix_t A, int op, const void *x, void *y, const voi
     return BSM_OK;
 }
 
+extern "C" int bsm_mul_multi(bsm_matrix_t A, int op, int64_t nrhs, const void *X, int64_t ldx, void *Y,
+                             int64_t ldy, const void *alpha, const void *beta, int beta_strong_zero,
+                             int memspace, void *stream) {
+    if (!A) return fail(BSM_ERR_INVALID, "null handle");
+    if (op < 0 || op > 2) return fail(BSM_ERR_INVALID, "bad op");
+    if (nrhs < 0) return fail(BSM_ERR_INVALID, "negative nrhs");
+    if (nrhs == 0) return BSM_OK;
+    if (!X || !Y) return fail(BSM_ERR_INVALID, "null matrix");
+    if (!A->on_device)
+        return fail(BSM_ERR_DEVICE, "handle has no device image (created with BSM_DEVICE_NONE)");
+    const long long xlen = (op == 0 ? A->img.ncols : A->img.nrows);
+    const long long ylen = (op == 0 ? A->img.nrows : A->img.ncols);
+    if (ldx < std::max<long long>(xlen, 1) || ldy < std::max<long long>(ylen, 1))
+        return fail(BSM_ERR_INVALID, "leading dimension smaller than the vector length");
+    const bool use_t = (op != BSM_OP_N) && A->has_t;
+    const DeviceImage &img = use_t ? A->img_t : A->img;
+    const bool opT = (op != BSM_OP_N) && !use_t;
+    const bool conj = (op == BSM_OP_C);
+    DeviceGuard guard;
+    hipError_t e = guard.enter(img.device);
+    if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
+    hipStream_t st = (hipStream_t)stream;
+    if (memspace == BSM_MEM_DEVICE) {
+        e = launch_mul_multi(img, opT, conj, nrhs, X, ldx, Y, ldy, alpha, beta, beta_strong_zero, st);
+        if (e != hipSuccess) return hip_fail(e, "kernel launch");
+        return BSM_OK;
+    }
+    if (memspace != BSM_MEM_HOST) return fail(BSM_ERR_INVALID, "bad memspace");
+    const size_t es = (size_t)A->an.es;
+    void *dx = nullptr, *dy = nullptr;
+    e = hipMalloc(&dx, (size_t)xlen * nrhs * es + 16);
+    if (e == hipSuccess) e = hipMalloc(&dy, (size_t)ylen * nrhs * es + 16);
+    if (e == hipSuccess)
+        e = hipMemcpy2DAsync(dx, (size_t)xlen * es, X, (size_t)ldx * es, (size_t)xlen * es, (size_t)nrhs,
+                             hipMemcpyHostToDevice, st);
+    if (e == hipSuccess && !beta_strong_zero)
+        e = hipMemcpy2DAsync(dy, (size_t)ylen * es, Y, (size_t)ldy * es, (size_t)ylen * es, (size_t)nrhs,
+                             hipMemcpyHostToDevice, st);
+    if (e == hipSuccess)
+        e = launch_mul_multi(img, opT, conj, nrhs, dx, xlen, dy, ylen, alpha, beta, beta_strong_zero, st);
+    if (e == hipSuccess)
+        e = hipMemcpy2DAsync(Y, (size_t)ldy * es, dy, (size_t)ylen * es, (size_t)ylen * es, (size_t)nrhs,
+                             hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (dx) (void)hipFree(dx);
+    if (dy) (void)hipFree(dy);
+    if (e != hipSuccess) return hip_fail(e, "host-staged multi mul");
+    return BSM_OK;
+}
+
 static int copy_out(const std::vector<int64_t> &v, int64_t *out, int64_t *len) {
     if (!len) return fail(BSM_ERR_INVALID, "len is null");
     if (out) {

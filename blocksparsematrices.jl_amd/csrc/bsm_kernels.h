@@ -27,4 +27,9 @@ struct DeviceImage {
 hipError_t launch_mul(const DeviceImage &img, bool opT, bool conj, const void *x, void *y,
                       const void *alpha, const void *beta, int strong_zero, hipStream_t stream);
 
+// nrhs right-hand sides: X (ldx) and Y (ldy) column-major; A is streamed once per batch of <= 8.
+hipError_t launch_mul_multi(const DeviceImage &img, bool opT, bool conj, long long nrhs, const void *x,
+                            long long ldx, void *y, long long ldy, const void *alpha, const void *beta,
+                            int strong_zero, hipStream_t stream);
+
 }  // namespace bsm

@@ -387,14 +387,236 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((!TRN 
     }
 }
 
+// ========================================================================================
+// multi right-hand-side variant: Y = alpha*op(A)*X + beta*Y for K columns per pass.  A is
+// streamed ONCE for the K columns (LinearMaps loops the columns through _unsafe_mul!, i.e. K
+// full sweeps of A).  Same work distribution and layout as panel_kernel; every lane keeps K
+// accumulators, the staged x slice is [column][k] in LDS.
+// ========================================================================================
+template <typename T, int K> constexpr int x_chunk_cols_multi() {
+    return (x_chunk_cols<T>() / K) > 64 * TT<T>::E ? (x_chunk_cols<T>() / K) : 64 * TT<T>::E;
+}
+
+template <typename T, int L, int P, bool FWD, bool TRN, int K>
+__device__ __forceinline__ void run_panel_multi(const WaveD &wd, const uint4 *__restrict__ values,
+                                                const int *__restrict__ rows,
+                                                const int *__restrict__ cols, const T *__restrict__ x,
+                                                long long ldx, T *__restrict__ y, long long ldy, T alpha,
+                                                int flags, int lane, T *xs, T *vs, T (&out)[K]) {
+    constexpr int E = TT<T>::E;
+    constexpr int G = 64 / P;
+    constexpr int V = L * E;
+    constexpr int NC = G * L * E;
+    constexpr int XCH = x_chunk_cols_multi<T, K>();
+    static_assert(XCH % NC == 0, "x chunk must hold whole iterations");
+    const bool opT = (flags & FLAG_OPT) != 0;
+    const bool cjf = (flags & FLAG_CONJ) != 0;
+    const int m = wd.m;
+    const int i = lane & (P - 1);
+    const int g = lane / P;
+    const bool row_ok = i < m;
+
+    T acc[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) acc[k] = zero_of(T{});
+    T xr[TRN ? K : 1];
+    if (TRN) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) xr[k] = zero_of(T{});
+        if (row_ok) {
+            const int ri = (wd.rbase >= 0) ? wd.rbase + i : rows[wd.row_off + i];
+#pragma unroll
+            for (int k = 0; k < K; ++k) xr[k] = x[ri + k * ldx];
+        }
+    }
+
+    const PieceD pc = wd.first;
+    if (wd.npieces > 0) {
+        const int xbase = pc.xbase;
+        const int col_off = pc.col_off;
+        const int nstrips = pc.nstrips;
+        const int ncols = pc.ncols;
+        const bool fwd_en = FWD && (!opT || pc.kind == KIND_OFF);
+        const bool trn_en = TRN && (opT || pc.kind == KIND_OFF);
+        const Vec16<T> *__restrict__ vb = reinterpret_cast<const Vec16<T> *>(
+            values + (((uint64_t)pc.val_hi << 32) | pc.val_lo));
+        const int s1w = wd.seg1_w, s1x = wd.seg1_x - wd.seg1_w;
+        const int s2w = wd.seg2_w, s2x = pc.seg2_x - wd.seg2_w;
+        auto col_index = [&](int w) -> int {
+            if (xbase < 0) return cols[col_off + w];
+            return w + (w < s1w ? xbase : (w < s2w ? s1x : s2x));
+        };
+
+        for (int c0 = 0; c0 < ncols; c0 += XCH) {
+            if (fwd_en) {
+#pragma unroll
+                for (int q = 0; q < XCH / 64; ++q) {
+                    const int c = q * 64 + lane;
+                    const int w = c0 + c;
+                    if (w < ncols + NC) {
+                        const bool ok = w < ncols;
+                        const int xi = ok ? col_index(w) : 0;
+#pragma unroll
+                        for (int k = 0; k < K; ++k) xs[c * K + k] = ok ? x[xi + k * ldx] : zero_of(T{});
+                    }
+                }
+            }
+            const int s_end = min(nstrips, (c0 + XCH) / E);
+            for (int s0 = c0 / E; s0 < s_end; s0 += G * L) {
+                Vec16<T> b[L];
+#pragma unroll
+                for (int l = 0; l < L; ++l) {
+                    const int s = s0 + l * G + g;
+                    if (row_ok && s < nstrips) {
+                        b[l] = vb[(uint32_t)(s * m + i)];
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < E; ++e) b[l].v[e] = zero_of(T{});
+                    }
+                }
+                if (fwd_en) {
+                    const int cb = (s0 - c0 / E) * E;
+#pragma unroll
+                    for (int l = 0; l < L; ++l) {
+                        const T *xp = &xs[(cb + (l * G + g) * E) * K];
+#pragma unroll
+                        for (int e = 0; e < E; ++e) {
+                            const T bv = cj(b[l].v[e], cjf);
+#pragma unroll
+                            for (int k = 0; k < K; ++k) acc[k] = madd(acc[k], bv, xp[e * K + k]);
+                        }
+                    }
+                }
+                if (trn_en) {
+#pragma unroll
+                    for (int k = 0; k < K; ++k) {
+                        T vals[V];
+#pragma unroll
+                        for (int l = 0; l < L; ++l)
+#pragma unroll
+                            for (int e = 0; e < E; ++e) vals[l * E + e] = mul(cj(b[l].v[e], cjf), xr[k]);
+                        int pos = 0, dup = 0;
+                        Butterfly<T, V, 1, P>::run(vals, i, pos, dup);
+                        constexpr int CF = (V / P) > 1 ? (V / P) : 1;
+                        if ((i & dup) == 0) {
+#pragma unroll
+                            for (int j = 0; j < CF; ++j) {
+                                const int q = pos + j;
+                                const int l = q / E, e = q % E;
+                                vs[(l * G + g) * E + e] = vals[j];
+                            }
+                        }
+#pragma unroll
+                        for (int q = 0; q < (NC + 63) / 64; ++q) {
+                            const int c = q * 64 + lane;
+                            const int w = s0 * E + c;
+                            if (c < NC && w < ncols) {
+                                T *yp = &y[col_index(w) + k * ldy];
+                                const T val = mul(alpha, vs[c]);
+                                if (flags & FLAG_RMW)
+                                    *yp = add(*yp, val);
+                                else
+                                    atomic_acc(yp, val);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        T a = acc[k];
+        if (FWD) {
+#pragma unroll
+            for (int d = P; d < 64; d <<= 1) a = add(a, shx(a, d));
+        }
+        out[k] = a;
+    }
+}
+
+template <typename T, int L, bool FWD, bool TRN, int K>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2)))
+    panel_kernel_multi(const WaveWork *__restrict__ waves, const uint4 *__restrict__ values,
+                       const int *__restrict__ rows, const int *__restrict__ cols,
+                       const T *__restrict__ x, long long ldx, T *__restrict__ y, long long ldy, T alpha,
+                       T beta, int flags, unsigned wg_base) {
+    constexpr int E = TT<T>::E;
+    constexpr int XS = x_chunk_cols_multi<T, K>() * K;  // >= 64*K: also holds the combine slab
+    constexpr int VS = 8 * L * E;
+    __shared__ __attribute__((aligned(16))) T xs[kWavesPerWg][FWD ? XS : 1];
+    __shared__ __attribute__((aligned(16))) T vs[kWavesPerWg][TRN ? VS : 1];
+
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const WaveD wd = load_wave(waves + ((size_t)(blockIdx.x + wg_base) * kWavesPerWg + wave));
+    const int work = wd.work;
+    const int m = wd.m;
+
+    T u[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) u[k] = zero_of(T{});
+    if (work == WORK_PANEL) {
+        if (m <= 8)
+            run_panel_multi<T, L, 8, FWD, TRN, K>(wd, values, rows, cols, x, ldx, y, ldy, alpha, flags, lane, xs[wave], vs[wave], u);
+        else if (m <= 16)
+            run_panel_multi<T, L, 16, FWD, TRN, K>(wd, values, rows, cols, x, ldx, y, ldy, alpha, flags, lane, xs[wave], vs[wave], u);
+        else if (m <= 32)
+            run_panel_multi<T, L, 32, FWD, TRN, K>(wd, values, rows, cols, x, ldx, y, ldy, alpha, flags, lane, xs[wave], vs[wave], u);
+        else
+            run_panel_multi<T, L, 64, FWD, TRN, K>(wd, values, rows, cols, x, ldx, y, ldy, alpha, flags, lane, xs[wave], vs[wave], u);
+    }
+    const bool direct = (flags & FLAG_DIRECT) != 0;
+    const bool sz = (flags & FLAG_STRONG_ZERO) != 0;
+    if (FWD) {
+        if (wd.wg_sync) {
+            // a wave's staged x slice is dead once it has left its loop: reuse it as this wave's
+            // part of the combine slab [wave][lane][k]
+#pragma unroll
+            for (int k = 0; k < K; ++k) xs[wave][lane * K + k] = u[k];
+            __syncthreads();
+        }
+        if (work == WORK_PANEL && wd.lead) {
+            for (int w2 = 1; w2 < wd.grp; ++w2)
+#pragma unroll
+                for (int k = 0; k < K; ++k) u[k] = add(u[k], xs[wave + w2][lane * K + k]);
+            if (lane < m) {
+                const int yi = (wd.rbase >= 0) ? wd.rbase + lane : rows[wd.row_off + lane];
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    T *yp = &y[yi + k * ldy];
+                    const T val = mul(alpha, u[k]);
+                    if (direct) {
+                        *yp = sz ? val : madd(val, beta, *yp);
+                    } else if (flags & FLAG_RMW) {
+                        *yp = add(*yp, val);
+                    } else {
+                        atomic_acc(yp, val);
+                    }
+                }
+            }
+        }
+    }
+    if (work == WORK_SCALE && direct) {
+        const int cnt = wd.first.ncols;
+        for (int r = lane; r < cnt; r += 64)
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                T *yp = &y[wd.rbase + r + k * ldy];
+                *yp = sz ? zero_of(T{}) : mul(beta, *yp);
+            }
+    }
+}
+
 // y[lo .. hi) = beta * y  (or 0 for the strong zero) -- `y .*= beta`,
 // reference src/blockmatrix.jl:231, src/symmetricblockmatrix.jl:392, src/vbcrs.jl:273,313
 template <typename T>
-__global__ void __launch_bounds__(256) scale_kernel(T *__restrict__ y, long long lo, long long hi,
-                                                    T beta, int strong_zero) {
+__global__ void __launch_bounds__(256) scale_kernel(T *__restrict__ y, long long ldy, long long lo,
+                                                    long long hi, T beta, int strong_zero) {
+    T *__restrict__ yc = y + (long long)blockIdx.y * ldy;  // one grid row per right-hand side
     long long i = lo + (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long stride = (long long)gridDim.x * blockDim.x;
-    for (; i < hi; i += stride) y[i] = strong_zero ? zero_of(T{}) : mul(beta, y[i]);
+    for (; i < hi; i += stride) yc[i] = strong_zero ? zero_of(T{}) : mul(beta, yc[i]);
 }
 
 // ----------------------------------------------------------------------------------------
@@ -453,7 +675,7 @@ static hipError_t launch_typed(const DeviceImage &img, bool opT, bool conj, cons
     if (hi > lo && (strong_zero || !is_one(beta))) {
         long long nblk = (hi - lo + 255) / 256;
         if (nblk > 2048) nblk = 2048;
-        hipLaunchKernelGGL((scale_kernel<T>), dim3((unsigned)nblk), block, 0, stream, yd, lo, hi, beta,
+        hipLaunchKernelGGL((scale_kernel<T>), dim3((unsigned)nblk), block, 0, stream, yd, 0LL, lo, hi, beta,
                            strong_zero);
     }
     // one launch over every workgroup (atomics), or one launch per colour class (plain RMW:
@@ -484,6 +706,100 @@ static hipError_t launch_typed(const DeviceImage &img, bool opT, bool conj, cons
         }
     }
     return hipGetLastError();
+}
+
+// K right-hand sides per pass
+template <typename T, int L, int K>
+static hipError_t launch_typed_multi(const DeviceImage &img, bool opT, bool conj, const T *xd, long long ldx,
+                                     T *yd, long long ldy, T alpha, T beta, int strong_zero,
+                                     hipStream_t stream) {
+    int flags = 0;
+    if (strong_zero) flags |= FLAG_STRONG_ZERO;
+    if (conj) flags |= FLAG_CONJ;
+    if (opT) flags |= FLAG_OPT;
+    const WaveWork *waves = (const WaveWork *)img.d_waves;
+    const uint4 *values = (const uint4 *)img.d_values;
+    const int *rows = (const int *)img.d_rows;
+    const int *cols = (const int *)img.d_cols;
+    const dim3 block(256);
+    if (!opT && img.exclusive_fwd) {
+        flags |= FLAG_DIRECT;
+        if (img.nwg_total > 0)
+            hipLaunchKernelGGL((panel_kernel_multi<T, L, true, false, K>), dim3((unsigned)img.nwg_total), block,
+                               0, stream, waves, values, rows, cols, xd, ldx, yd, ldy, alpha, beta, flags, 0u);
+        return hipGetLastError();
+    }
+    const long long ylen = opT ? img.ncols : img.nrows;
+    long long lo = 0, hi = ylen;
+    if (!opT) {
+        lo = img.own_lo;
+        hi = img.own_hi;
+    }
+    if (hi > lo && (strong_zero || !is_one(beta))) {
+        long long nblk = (hi - lo + 255) / 256;
+        if (nblk > 2048) nblk = 2048;
+        hipLaunchKernelGGL((scale_kernel<T>), dim3((unsigned)nblk, (unsigned)K), block, 0, stream, yd, ldy, lo,
+                           hi, beta, strong_zero);
+    }
+    const bool colored = !img.color_wg_ptr.empty();
+    if (colored) flags |= FLAG_RMW;
+    const size_t nlaunch = colored ? img.color_wg_ptr.size() - 1 : 1;
+    for (size_t c = 0; c < nlaunch; ++c) {
+        const long long wg0 = colored ? img.color_wg_ptr[c] : 0;
+        const long long wg1 = colored ? img.color_wg_ptr[c + 1] : img.nwg_main;
+        if (wg1 <= wg0) continue;
+        const dim3 grid((unsigned)(wg1 - wg0));
+        const unsigned wg_base = (unsigned)wg0;
+        if (!opT && !img.has_off)
+            hipLaunchKernelGGL((panel_kernel_multi<T, L, true, false, K>), grid, block, 0, stream, waves, values,
+                               rows, cols, xd, ldx, yd, ldy, alpha, beta, flags, wg_base);
+        else if (img.has_off)
+            hipLaunchKernelGGL((panel_kernel_multi<T, L, true, true, K>), grid, block, 0, stream, waves, values,
+                               rows, cols, xd, ldx, yd, ldy, alpha, beta, flags, wg_base);
+        else
+            hipLaunchKernelGGL((panel_kernel_multi<T, L, false, true, K>), grid, block, 0, stream, waves, values,
+                               rows, cols, xd, ldx, yd, ldy, alpha, beta, flags, wg_base);
+    }
+    return hipGetLastError();
+}
+
+template <typename T>
+static hipError_t launch_multi_typed(const DeviceImage &img, bool opT, bool conj, long long nrhs,
+                                     const void *x, long long ldx, void *y, long long ldy,
+                                     const void *alpha_p, const void *beta_p, int strong_zero,
+                                     hipStream_t stream) {
+    const T alpha = load_scalar<T>(alpha_p, 1.0);
+    const T beta = load_scalar<T>(beta_p, 0.0);
+    const T *xd = (const T *)x;
+    T *yd = (T *)y;
+    long long k = 0;
+    hipError_t e = hipSuccess;
+    // batches of 8, then 4, then single columns: A is streamed once per batch
+    while (e == hipSuccess && nrhs - k >= 8) {
+        e = launch_typed_multi<T, 8, 8>(img, opT, conj, xd + k * ldx, ldx, yd + k * ldy, ldy, alpha, beta,
+                                        strong_zero, stream);
+        k += 8;
+    }
+    if (e == hipSuccess && nrhs - k >= 4) {
+        e = launch_typed_multi<T, 8, 4>(img, opT, conj, xd + k * ldx, ldx, yd + k * ldy, ldy, alpha, beta,
+                                        strong_zero, stream);
+        k += 4;
+    }
+    for (; e == hipSuccess && k < nrhs; ++k)
+        e = launch_typed<T, 8>(img, opT, conj, xd + k * ldx, yd + k * ldy, alpha_p, beta_p, strong_zero, stream);
+    return e;
+}
+
+hipError_t launch_mul_multi(const DeviceImage &img, bool opT, bool conj, long long nrhs, const void *x,
+                            long long ldx, void *y, long long ldy, const void *alpha, const void *beta,
+                            int strong_zero, hipStream_t stream) {
+    switch (img.dtype) {
+        case 0: return launch_multi_typed<float>(img, opT, conj, nrhs, x, ldx, y, ldy, alpha, beta, strong_zero, stream);
+        case 1: return launch_multi_typed<double>(img, opT, conj, nrhs, x, ldx, y, ldy, alpha, beta, strong_zero, stream);
+        case 2: return launch_multi_typed<c64>(img, opT, conj, nrhs, x, ldx, y, ldy, alpha, beta, strong_zero, stream);
+        case 3: return launch_multi_typed<c128>(img, opT, conj, nrhs, x, ldx, y, ldy, alpha, beta, strong_zero, stream);
+    }
+    return hipErrorInvalidValue;
 }
 
 hipError_t launch_mul(const DeviceImage &img, bool opT, bool conj, const void *x, void *y,

@@ -464,8 +464,52 @@ def _vec_info(v, dt, n, name):
     return v.ctypes.data, L.BSM_MEM_HOST, None, v
 
 
+def _mat_info(v, dt, n, name):
+    """2-D column-major operand -> (pointer, ld, ncols, memspace, stream, keepalive)"""
+    if torch is not None and isinstance(v, torch.Tensor):
+        tdt = {np.dtype(np.float32): torch.float32, np.dtype(np.float64): torch.float64,
+               np.dtype(np.complex64): torch.complex64, np.dtype(np.complex128): torch.complex128}[dt]
+        if v.dim() != 2 or v.shape[0] != n:
+            raise ValueError(f"DimensionMismatch: {name} has shape {tuple(v.shape)}, expected ({n}, k)")
+        if v.dtype != tdt or v.stride(0) != 1 or (v.shape[1] > 1 and v.stride(1) < max(n, 1)):
+            raise TypeError(f"{name} must be a column-major {tdt} tensor (e.g. torch.empty(k, n).t())")
+        ld = v.stride(1) if v.shape[1] > 1 else max(n, 1)
+        if v.is_cuda:
+            return (v.data_ptr(), ld, v.shape[1], L.BSM_MEM_DEVICE,
+                    torch.cuda.current_stream(v.device).cuda_stream, v)
+        a = v.numpy()
+        return a.ctypes.data, ld, v.shape[1], L.BSM_MEM_HOST, None, a
+    if not isinstance(v, np.ndarray) or v.ndim != 2 or v.shape[0] != n:
+        raise ValueError(f"DimensionMismatch: {name} must be a 2-D array with {n} rows")
+    if v.dtype != dt or not v.flags.f_contiguous:
+        raise TypeError(f"{name} must be a column-major (Fortran-order) {dt} array")
+    return v.ctypes.data, max(n, 1), v.shape[1], L.BSM_MEM_HOST, None, v
+
+
+def _mul_matrix(Y, A, X, alpha, beta):
+    """mul!(Y, A, X, alpha, beta) with matrices: one bsm_mul_multi call (A streamed once per batch
+    of up to 8 columns) instead of LinearMaps' column loop over _unsafe_mul!."""
+    base, op = _unwrap(A)
+    dt = base.dtype
+    nr, nc = base.size
+    ylen, xlen = (nr, nc) if op == L.BSM_OP_N else (nc, nr)
+    xp, ldx, kx, xms, _, _kx = _mat_info(X, dt, xlen, "X")
+    yp, ldy, ky, yms, yst, _ky = _mat_info(Y, dt, ylen, "Y")
+    if kx != ky:
+        raise ValueError("DimensionMismatch: X and Y have different numbers of columns")
+    if xms != yms:
+        raise ValueError("X and Y must live in the same memory space")
+    strong = beta is False
+    a = _scalar_buf(1 if alpha is True else alpha, dt)
+    b = _scalar_buf(0 if strong else (1 if beta is True else beta), dt)
+    L.check(L.lib().bsm_mul_multi(base._h.ptr, op, kx, xp, ldx, yp, ldy, a.ctypes.data, b.ctypes.data,
+                                  1 if strong else 0, xms, yst))
+    return Y
+
+
 def mul(y, A, x, alpha=True, beta=False):
     """LinearAlgebra.mul!(y, A, x, alpha, beta): y = alpha*A*x + beta*y, returns y.
+    x / y may also be matrices (column-major): the multi right-hand-side product.
 
     `beta is False` (the 3-argument form, reference src/abstractblockmatrix.jl:27-34) is Julia's
     strong zero: y is overwritten, NaN/Inf in the incoming y do not propagate.  A numeric 0.0
@@ -476,6 +520,10 @@ def mul(y, A, x, alpha=True, beta=False):
     dt = base.dtype
     nr, nc = base.size
     ylen, xlen = (nr, nc) if op == L.BSM_OP_N else (nc, nr)
+    if getattr(x, "ndim", 1) == 2 or getattr(y, "ndim", 1) == 2:
+        if dt.kind != "c" and (np.iscomplexobj(alpha) or np.iscomplexobj(beta)):
+            raise TypeError("complex alpha/beta with a real matrix is not supported on the GPU path")
+        return _mul_matrix(y, A, x, alpha, beta)
     if dt.kind != "c" and (np.iscomplexobj(alpha) or np.iscomplexobj(beta)):
         raise TypeError("complex alpha/beta with a real matrix is not supported on the GPU path")
     xp, xms, xst, _kx = _vec_info(x, dt, xlen, "x")
@@ -524,10 +572,20 @@ def _apply(A, x):
     """A * x: allocates y like LinearMaps does (similar(x, ...), uninitialised) then mul!."""
     m, _ = size(A)
     if torch is not None and isinstance(x, torch.Tensor):
-        y = torch.empty(m, dtype=x.dtype, device=x.device)
+        if x.dim() == 2:  # A * X: column-major result
+            y = torch.empty((x.shape[1], m), dtype=x.dtype, device=x.device).t()
+            if x.stride(0) != 1:
+                x = x.t().contiguous().t()
+        else:
+            y = torch.empty(m, dtype=x.dtype, device=x.device)
     else:
-        x = np.ascontiguousarray(x, dtype=eltype(A))
-        y = np.empty(m, dtype=x.dtype)
+        x = np.asarray(x, dtype=eltype(A))
+        if x.ndim == 2:
+            x = np.asfortranarray(x)
+            y = np.empty((m, x.shape[1]), dtype=x.dtype, order="F")
+        else:
+            x = np.ascontiguousarray(x)
+            y = np.empty(m, dtype=x.dtype)
     return mul(y, A, x)
 
 

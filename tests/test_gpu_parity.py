@@ -285,3 +285,51 @@ def test_transpose_image_parity_and_determinism(torch_cuda, bsm, oracle):
     r = bsm.synthetic.config1()
     Cm = bsm.synthetic.build(r, transpose_image=True)
     check_all(torch_cuda, bsm, oracle, r, Cm, np.float64, host_too=False)
+
+
+# ---- multi right-hand-side product: A * X, mul!(Y, A, X, a, b) with matrices ---------------------------
+def _check_multi(torch, bsm, oracle, problem, A, dtype, nrhs_list=(1, 3, 4, 8, 13), ops=OPS):
+    dtype = np.dtype(dtype)
+    nr, nc = problem["size"]
+    rng = np.random.default_rng(21)
+    for op in ops:
+        if op == Cc and dtype.kind != "c":
+            continue
+        xl, yl = (nc, nr) if op == N else (nr, nc)
+        Aop = wrap(bsm, A, op)
+        for k in nrhs_list:
+            X = np.asfortranarray(np.stack([rand_vec(rng, xl, dtype) for _ in range(k)], axis=1))
+            Y0 = np.asfortranarray(np.stack([rand_vec(rng, yl, dtype) for _ in range(k)], axis=1))
+            for alpha, beta, strong in ((1, 0, True), (0.5, -2.0, False)):
+                # the reference semantics: LinearMaps applies _unsafe_mul! column by column
+                ref = np.stack([oracle_mul(oracle, problem, op, X[:, j].copy(), Y0[:, j].copy(), alpha, beta, strong)
+                                for j in range(k)], axis=1)
+                Xd = torch.from_numpy(X.T.copy()).cuda().t()       # column-major device matrices
+                Yd = torch.from_numpy(Y0.T.copy()).cuda().t()
+                bsm.mul(Yd, Aop, Xd, alpha, False if strong else beta)
+                torch.cuda.synchronize()
+                got = Yd.cpu().numpy()
+                assert relerr(got.ravel(), ref.ravel()) < TOL[dtype], (op, k, alpha, beta)
+            # host matrices (BSM_MEM_HOST) and the `A * X` form
+            ref = np.stack([oracle_mul(oracle, problem, op, X[:, j].copy(), np.zeros(yl, dtype)) for j in range(k)], axis=1)
+            got = Aop @ X
+            assert got.shape == (yl, k) and relerr(got.ravel(), ref.ravel()) < TOL[dtype]
+
+
+def test_multi_rhs_vbcrs(torch_cuda, bsm, oracle):
+    p = bsm.synthetic.config2(n=20000, nblocks=1000)
+    _check_multi(torch_cuda, bsm, oracle, p, bsm.synthetic.build(p), np.float64)
+    _check_multi(torch_cuda, bsm, oracle, p, bsm.synthetic.build(p, transpose_image=True), np.float64, nrhs_list=(5,))
+    q = bsm.synthetic.config2(n=20000, nblocks=1000, dtype=np.float32)
+    _check_multi(torch_cuda, bsm, oracle, q, bsm.synthetic.build(q), np.float32, nrhs_list=(8, 5))
+
+
+@pytest.mark.parametrize("key", ["cuboid"])
+def test_multi_rhs_symmetric_and_blocksparse_fixture(torch_cuda, bsm, oracle, key):
+    p = fixture_problem(key)
+    _check_multi(torch_cuda, bsm, oracle, p, bsm.synthetic.build(p), np.complex128, nrhs_list=(4, 9))
+    _check_multi(torch_cuda, bsm, oracle, p, bsm.synthetic.build(p, accumulate="colored"), np.complex128, nrhs_list=(8,))
+    q = fixture_as_blocksparse(key)
+    _check_multi(torch_cuda, bsm, oracle, q, bsm.synthetic.build(q), np.complex128, nrhs_list=(12,))
+    r = bsm.synthetic.config3(nseg=60)
+    _check_multi(torch_cuda, bsm, oracle, r, bsm.synthetic.build(r), np.float64, nrhs_list=(8, 6), ops=[N, T])

@@ -52,6 +52,22 @@ for name, Aop in ops:
         cold.append(a.elapsed_time(b) * 1e-3)
     cold.sort()
     del flush
+    nrhs = int(os.environ.get("KB_NRHS", "0"))
+    if nrhs > 1:
+        n_in, n_out = bsm.size(Aop)[1], bsm.size(Aop)[0]
+        X = torch.randn((nrhs, n_in), dtype=x.dtype, device="cuda").t()
+        Y = torch.zeros((nrhs, n_out), dtype=x.dtype, device="cuda").t()
+        for _ in range(5):
+            bsm.mul(Y, Aop, X)
+        torch.cuda.synchronize()
+        a.record()
+        for _ in range(max(reps // 4, 5)):
+            bsm.mul(Y, Aop, X)
+        b.record()
+        torch.cuda.synchronize()
+        tm = a.elapsed_time(b) * 1e-3 / max(reps // 4, 5)
+        print(f"   multi-RHS k={nrhs}: {tm * 1e6:.2f}us per call = {tm / nrhs * 1e6:.2f}us per column "
+              f"(single-RHS warm {warm * 1e6:.2f}us) -> {warm * nrhs / tm:.2f}x", flush=True)
     knobs = {k: v for k, v in os.environ.items() if k.startswith("BSM_")}
     print(f"{which} op={name} {knobs} wgs={st['nworkgroups']} tasks={st['ntasks']} excl={st['exclusive']} "
           f"warm={warm * 1e6:.2f}us ({st['alg_bytes'] / warm / 1e9:.0f} GB/s) "
