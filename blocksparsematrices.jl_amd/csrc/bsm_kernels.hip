@@ -207,6 +207,7 @@ __device__ __forceinline__ T run_panel(const WaveD &wd, const uint4 *__restrict_
     constexpr int V = L * E;
     constexpr int NC = G * L * E;                        // columns covered per iteration
     constexpr int XCH = x_chunk_cols<T>();                 // columns staged per x chunk
+    constexpr int BF = (NC >= 64) ? 1 : 64 / NC;           // iterations per transposed emission
     static_assert(XCH % NC == 0, "x chunk must hold whole iterations");
     const bool opT = (flags & FLAG_OPT) != 0;
     const bool cjf = (flags & FLAG_CONJ) != 0;
@@ -292,25 +293,33 @@ __device__ __forceinline__ T run_panel(const WaveD &wd, const uint4 *__restrict_
                     int pos = 0, dup = 0;
                     Butterfly<T, V, 1, P>::run(vals, i, pos, dup);
                     constexpr int CF = (V / P) > 1 ? (V / P) : 1;
+                    // the column sums of BF consecutive iterations are parked in LDS and leave the
+                    // wave together: atomics are priced per wave-instruction, so 64 busy lanes
+                    // instead of NC (16 for 64-row groups) quarter their cost
+                    const int slot = ((s0 - c0 / E) / (G * L)) % BF;
                     if ((i & dup) == 0) {
 #pragma unroll
                         for (int j = 0; j < CF; ++j) {
                             const int q = pos + j;  // original value index l*E + e
                             const int l = q / E, e = q % E;
-                            vs[(l * G + g) * E + e] = vals[j];
+                            vs[slot * NC + (l * G + g) * E + e] = vals[j];
                         }
                     }
+                    const bool last_it = (s0 + G * L >= s_end);
+                    if (slot == BF - 1 || last_it) {
+                        const int sb = s0 - slot * (G * L);  // first strip of the batch
 #pragma unroll
-                    for (int k = 0; k < (NC + 63) / 64; ++k) {
-                        const int c = k * 64 + lane;
-                        const int w = s0 * E + c;
-                        if (c < NC && w < ncols) {
-                            const int yi = col_index(w);
-                            const T val = mul(alpha, vs[c]);
-                            if (flags & FLAG_RMW)
-                                y[yi] = add(y[yi], val);
-                            else
-                                atomic_acc(&y[yi], val);
+                        for (int k = 0; k < (BF * NC + 63) / 64; ++k) {
+                            const int c = k * 64 + lane;
+                            const int w = sb * E + c;
+                            if (c < (slot + 1) * NC && w < ncols) {
+                                const int yi = col_index(w);
+                                const T val = mul(alpha, vs[c]);
+                                if (flags & FLAG_RMW)
+                                    y[yi] = add(y[yi], val);
+                                else
+                                    atomic_acc(&y[yi], val);
+                            }
                         }
                     }
                 }

@@ -18,10 +18,20 @@ prob = {"c2": lambda: S.config2(), "c3": lambda: S.config3(), "c3s": lambda: S.c
         "c2t": lambda: S.config2(n=6000, lo=1, hi=1, nblocks=14000),
         "c2u": lambda: S.config2(n=100000, lo=36, hi=36, nblocks=5000),
         "c2p": lambda: S.config2(n=100000, lo=32, hi=32, nblocks=6400),
-        "c2w": lambda: S.config2(n=100000, lo=64, hi=64, nblocks=1650), "c5s": lambda: S.config5(n=600_000)}[which]()
+        "c2w": lambda: S.config2(n=100000, lo=64, hi=64, nblocks=1650), "c5s": lambda: S.config5(n=600_000),
+        "c5u64": lambda: S.config5(n=600_000, lo=64, hi=64),
+        "c5u128": lambda: S.config5(n=600_000, lo=128, hi=128),
+        "c5u40": lambda: S.config5(n=300_000, lo=40, hi=40),
+        "c5u100": lambda: S.config5(n=600_000, lo=100, hi=100),
+        "c5m": lambda: S.config5(n=600_000, lo=65, hi=127)}[which]()
 kw = {"accumulate": os.environ.get("KB_ACC", "auto")}
 if os.environ.get("KB_TIMG") and prob["kind"] != "symmetric":
     kw["transpose_image"] = True
+if os.environ.get("KB_AS_BSM") and prob["kind"] == "symmetric":
+    # same bytes as a forward-only BlockSparseMatrix (isolates the cost of the transposed half)
+    prob = dict(kind="blocksparse", blocks=prob["diagonals"] + prob["offdiagonals"],
+                rowindices=prob["diagonalindices"] + prob["rowindices"],
+                colindices=prob["diagonalindices"] + prob["colindices"], size=prob["size"], x=prob["x"])
 A = S.build(prob, **kw)
 st = A.stats()
 x = torch.from_numpy(prob["x"]).cuda()
