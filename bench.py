@@ -42,6 +42,9 @@ def main():
     ap.add_argument("--allgather", action="store_true",
                     help="include an RCCL all-gather of the y slices in every step (N > 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to "
+                    "rehearse the N > 1 code path on a single GPU)")
+    ap.add_argument("--device", type=int, default=None, help="override LOCAL_RANK as the HIP device (rehearsal)")
     ap.add_argument("--cold", action="store_true", help="also report a cold-cache figure")
     args = ap.parse_args()
 
@@ -58,11 +61,17 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch N > 1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    torch.cuda.set_device(local_rank)
+    dev_index = local_rank if args.device is None else args.device
+    torch.cuda.set_device(dev_index)
     dist = None
+    red_dev = "cuda"  # where the scalar reductions over ranks live
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(args.backend)
+            red_dev = "cpu"
 
     # ---- workload -------------------------------------------------------------------------------
     prob = bsm.synthetic.config2(part=(rank, world) if world > 1 else None)
@@ -74,7 +83,14 @@ def main():
     # algorithmic bytes of THIS rank: its stored entries + metadata + x once + its y rows once
     own = prob.get("own", (1, n))
     own_rows = own[1] - own[0] + 1
-    alg_bytes = st["alg_bytes"] - 8 * n + 8 * own_rows if world > 1 else st["alg_bytes"]
+    if world > 1:
+        # this rank reads only the x entries its blocks reference (each once) and writes its own rows
+        touched = np.zeros(n, dtype=bool)
+        for c0, blk in zip(prob["colstart"], prob["blocks"]):
+            touched[c0 - 1:c0 - 1 + blk.shape[1]] = True
+        alg_bytes = st["alg_bytes"] - 8 * n - 8 * n + 8 * int(touched.sum()) + 8 * own_rows
+    else:
+        alg_bytes = st["alg_bytes"]
     x = torch.from_numpy(prob["x"]).cuda()
     y = torch.full((n,), float("nan"), dtype=torch.float64, device="cuda")
     plan = bsm.MulPlan(y, A, x)
@@ -131,10 +147,10 @@ def main():
     elapsed = time.perf_counter() - t0
     dev_elapsed = ev0.elapsed_time(ev1) * 1e-3
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        b = torch.tensor([float(alg_bytes)], dtype=torch.float64, device="cuda")
+        b = torch.tensor([float(alg_bytes)], dtype=torch.float64, device=red_dev)
         dist.all_reduce(b, op=dist.ReduceOp.SUM)
         total_bytes = float(b.item())
     else:
