@@ -344,3 +344,60 @@ def test_coloured_mode_rejects_repeated_indices(bsm):
         bsm.BlockSparseMatrix([np.ones((2, 1))], [[3, 3]], [[1]], (4, 4), device=NODEV, accumulate="colored")
     with pytest.raises(RuntimeError, match="repeat a column index"):
         bsm.BlockSparseMatrix([np.ones((1, 2))], [[1]], [[2, 2]], (4, 4), device=NODEV, accumulate="colored")
+
+
+# ---- C ABI argument checking: errors are status codes + bsm_last_error, never crashes --------------
+def test_c_abi_rejects_bad_arguments(bsm):
+    from bsm_amd import _lib as L
+    lib = L.lib()
+    I = C.POINTER(C.c_int64)
+    o = L.BsmOptions()
+    lib.bsm_options_default(C.byref(o))
+    o.device = NODEV
+    h = C.c_void_p()
+    blk = np.asfortranarray(np.ones((2, 2)))
+    ptrs = (C.c_void_p * 1)(blk.ctypes.data)
+    one = np.array([1], dtype=np.int64)
+    two = np.array([2], dtype=np.int64)
+
+    def p(a):
+        return a.ctypes.data_as(I)
+
+    # null handle / null out
+    assert lib.bsm_mul(None, 0, None, None, None, None, 1, 1, None) == -1
+    assert b"null handle" in lib.bsm_last_error()
+    assert lib.bsm_vbcrs_create(1, 4, 4, 1, ptrs, p(two), p(two), p(two), p(one), p(one), C.byref(o), None) == -1
+    # zero blocks, bad dtype, ld < m, range outside matrix, wrong options size
+    assert lib.bsm_vbcrs_create(1, 4, 4, 0, ptrs, p(two), p(two), p(two), p(one), p(one), C.byref(o), C.byref(h)) == -1
+    assert lib.bsm_vbcrs_create(9, 4, 4, 1, ptrs, p(two), p(two), p(two), p(one), p(one), C.byref(o), C.byref(h)) == -1
+    assert b"dtype" in lib.bsm_last_error()
+    assert lib.bsm_vbcrs_create(1, 4, 4, 1, ptrs, p(two), p(two), p(one), p(one), p(one), C.byref(o), C.byref(h)) == -1
+    assert b"ld" in lib.bsm_last_error()
+    four = np.array([4], dtype=np.int64)
+    assert lib.bsm_vbcrs_create(1, 4, 4, 1, ptrs, p(two), p(two), p(two), p(four), p(one), C.byref(o), C.byref(h)) == -1
+    bad = L.BsmOptions()
+    bad.struct_size = 8
+    assert lib.bsm_vbcrs_create(1, 4, 4, 1, ptrs, p(two), p(two), p(two), p(one), p(one), C.byref(bad), C.byref(h)) == -1
+    assert b"struct_size" in lib.bsm_last_error()
+    # a good handle: op out of range, null vectors, multi-RHS argument checks, bookkeeping misuse
+    assert lib.bsm_vbcrs_create(1, 4, 4, 1, ptrs, p(two), p(two), p(two), p(one), p(one), C.byref(o), C.byref(h)) == 0
+    x = np.zeros(4)
+    assert lib.bsm_mul(h, 7, x.ctypes.data, x.ctypes.data, None, None, 1, 0, None) == -1
+    assert lib.bsm_mul(h, 0, None, x.ctypes.data, None, None, 1, 0, None) == -1
+    assert lib.bsm_mul(h, 0, x.ctypes.data, x.ctypes.data, None, None, 1, 0, None) == -3  # no device image
+    assert lib.bsm_mul_multi(h, 0, -1, x.ctypes.data, 4, x.ctypes.data, 4, None, None, 1, 0, None) == -1
+    assert lib.bsm_mul_multi(h, 0, 0, x.ctypes.data, 4, x.ctypes.data, 4, None, None, 1, 0, None) == 0
+    n = C.c_int64(0)
+    assert lib.bsm_get_bookkeeping(h, 99, None, C.byref(n)) == -1
+    assert lib.bsm_get_bookkeeping(h, L.BSM_BK_COLORS, None, C.byref(n)) == -1  # VBCRS has no colours
+    assert lib.bsm_get_bookkeeping(h, L.BSM_BK_VBCRS_ROWPTR, None, C.byref(n)) == 0 and n.value == 2
+    small = np.zeros(1, dtype=np.int64)
+    n = C.c_int64(1)
+    assert lib.bsm_get_bookkeeping(h, L.BSM_BK_VBCRS_ROWPTR, p(small), C.byref(n)) == -1  # buffer too small
+    assert lib.bsm_destroy(h) == 0 and lib.bsm_destroy(None) == 0
+    # colouring entry: 0-based index is rejected
+    lst = np.array([0, 1], dtype=np.int64)
+    lp = (C.c_void_p * 1)(lst.ctypes.data)
+    out = np.zeros(1, dtype=np.int64)
+    nc = C.c_int64(0)
+    assert lib.bsm_color(1, lp, p(two), p(out), C.byref(nc)) == -1
