@@ -25,6 +25,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# threads of the all-cores CPU variant (OpenMP runtime reads this when the oracle is loaded): the
+# GPU box gives one GPU a 16-CPU share
+os.environ.setdefault("OMP_NUM_THREADS", str(min(len(os.sched_getaffinity(0)), 16)))
 
 HBM_PEAK_GBPS = 8000.0  # MI355X spec (MI355X_MICROARCH.md); measured-copy ceiling 6290
 # HBM-side bytes of one C2 launch from the PMC passes (profiles/r01_c2_pmc_summary.txt):
@@ -208,7 +211,7 @@ def main():
         # all host cores: one OpenMP task per block row == the reference's `@tasks for browidx`
         # with DynamicScheduler() (src/vbcrs.jl:275-276); reported beside, not as the baseline
         try:
-            ncores = len(os.sched_getaffinity(0))
+            ncores = int(os.environ.get("OMP_NUM_THREADS", "1"))
             yp = np.zeros(n)
             orc.vbcrs_mul(0, blocks, rowptr, colind, rowind, xh, yp, parallel=True)
             preps, tp0 = 0, time.perf_counter()
