@@ -356,6 +356,9 @@ std::string Analysis::build(int mtype_, int dtype_, int64_t nrows_, int64_t ncol
         if (any_off) excl = false;
     }
     exclusive_fwd = excl;
+    // forced atomics: schedule like a non-exclusive matrix (large row groups are cut into several
+    // workgroup items; their partial sums meet in y through atomics)
+    if (opt.accumulate == 1) exclusive_fwd = false;
     const bool colored = (opt.accumulate == 2);
     std::vector<int32_t> group_color(groups.size(), 0);
     int32_t ncolors_fused = 1;

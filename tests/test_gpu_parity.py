@@ -333,3 +333,56 @@ def test_multi_rhs_symmetric_and_blocksparse_fixture(torch_cuda, bsm, oracle, ke
     _check_multi(torch_cuda, bsm, oracle, q, bsm.synthetic.build(q), np.complex128, nrhs_list=(12,))
     r = bsm.synthetic.config3(nseg=60)
     _check_multi(torch_cuda, bsm, oracle, r, bsm.synthetic.build(r), np.float64, nrhs_list=(8, 6), ops=[N, T])
+
+
+# ---- BASELINE.json's big configs at the size ONE GPU of eight owns: size-independent properties ------
+def _dot(a, b):
+    return float(np.dot(a.astype(np.float64), b.astype(np.float64)))
+
+
+def test_config4_one_gpu_share_properties(torch_cuda, bsm):
+    # C4: 1/8 of the block rows (2.06 GB fp32).  The oracle check of a smaller slice is above; here:
+    # adjoint identity <A x, z> = <x, A^T z>, linearity, and the second ordering against atomics.
+    p = bsm.synthetic.config4(row_lo=0, row_hi=1953)
+    A = bsm.synthetic.build(p, transpose_image=True)
+    rng = np.random.default_rng(31)
+    n = p["size"][0]
+    x, z = rand_vec(rng, n, np.float32), rand_vec(rng, n, np.float32)
+    zero = np.zeros(n, np.float32)
+    ax = gpu_mul(torch_cuda, bsm, A, N, x, zero, 1, 0, True)
+    atz = gpu_mul(torch_cuda, bsm, A, T, z, zero, 1, 0, True)          # forward launch on the second ordering
+    assert abs(_dot(ax, z) - _dot(x, atz)) < 1e-4 * abs(_dot(ax, z))
+    az = gpu_mul(torch_cuda, bsm, A, N, z, zero, 1, 0, True)
+    both = gpu_mul(torch_cuda, bsm, A, N, (2 * x - 3 * z).astype(np.float32), zero, 1, 0, True)
+    assert relerr(both, 2 * ax - 3 * az) < 2e-5
+    del A
+    B = bsm.synthetic.build(p)                                          # single image: atomics
+    atz2 = gpu_mul(torch_cuda, bsm, B, T, z, zero, 1, 0, True)
+    assert relerr(atz2, atz) < 2e-5
+    rows_touched = np.zeros(n, bool)
+    rows_touched[:1953 * 128] = True
+    assert not np.any(ax[~rows_touched])                                # rows without blocks are exactly zero
+
+
+def test_config5_one_gpu_share_properties(torch_cuda, bsm):
+    # C5: the first 1/8 of the rows (3.6 GB fp64, sizes 16-256): symmetry S x = S^T x, <S x, z> = <x, S z>,
+    # linearity; VBCRS view of the same operator.
+    p = bsm.synthetic.config5(n=625_000)
+    S = bsm.synthetic.build(p)
+    rng = np.random.default_rng(32)
+    n = p["size"][0]
+    x, z = rand_vec(rng, n, np.float64), rand_vec(rng, n, np.float64)
+    zero = np.zeros(n)
+    sx = gpu_mul(torch_cuda, bsm, S, N, x, zero, 1, 0, True)
+    stx = gpu_mul(torch_cuda, bsm, S, T, x, zero, 1, 0, True)
+    assert relerr(stx, sx) < 1e-12
+    sz = gpu_mul(torch_cuda, bsm, S, N, z, zero, 1, 0, True)
+    assert abs(np.dot(sx, z) - np.dot(x, sz)) < 1e-11 * abs(np.dot(sx, z))
+    comb = gpu_mul(torch_cuda, bsm, S, N, 2 * x - 3 * z, zero, 1, 0, True)
+    assert relerr(comb, 2 * sx - 3 * sz) < 1e-12
+    y0 = rand_vec(rng, n, np.float64)
+    ab = gpu_mul(torch_cuda, bsm, S, N, x, y0, -0.5, 2.0, False)
+    assert relerr(ab, -0.5 * sx + 2.0 * y0) < 1e-12
+    V = bsm.VariableBlockCompressedRowStorage(S)                        # view: blocks stored once
+    assert bsm.nnz(V) == bsm.nnz(S)
+    assert relerr(gpu_mul(torch_cuda, bsm, V, N, x, zero, 1, 0, True), sx) < 1e-12
