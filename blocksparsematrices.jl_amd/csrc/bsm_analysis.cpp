@@ -545,9 +545,23 @@ std::string Analysis::build(int mtype_, int dtype_, int64_t nrows_, int64_t ncol
             }
         } else if (tun.wg_order == 2) {  // smallest first
             for (int64_t a = nwg_main - 1; a >= 0; a--) ord.push_back(a);
-        } else {  // 3: stride 8 (one XCD sees a size-sorted eighth)
+        } else if (tun.wg_order == 3) {  // sawtooth: 8 size-sorted passes
             for (int64_t r = 0; r < 8; r++)
                 for (int64_t a = r; a < nwg_main; a += 8) ord.push_back(a);
+        } else if (tun.wg_order == 4) {  // deterministic pseudo-random shuffle
+            ord.resize(nwg_main);
+            std::iota(ord.begin(), ord.end(), (int64_t)0);
+            uint64_t st = 0x9E3779B97F4A7C15ull;
+            for (int64_t a = nwg_main - 1; a > 0; a--) {
+                st ^= st << 13;
+                st ^= st >> 7;
+                st ^= st << 17;
+                std::swap(ord[a], ord[(int64_t)(st % (uint64_t)(a + 1))]);
+            }
+        } else {  // >= 5: sawtooth with wg_order passes
+            const int64_t np = tun.wg_order;
+            for (int64_t r = 0; r < np; r++)
+                for (int64_t a = r; a < nwg_main; a += np) ord.push_back(a);
         }
         for (int64_t k = 0; k < nwg_main; k++)
             for (int w = 0; w < kWavesPerWg; w++) re[k * kWavesPerWg + w] = waves[ord[k] * kWavesPerWg + w];

@@ -24,6 +24,12 @@ CONFIGS = [
     ("C4 VBCRS 2M^2, 128x128 fp32: block rows 0..1952 (1/8)", lambda: S.config4(row_lo=0, row_hi=1953), 8),
     ("C5 Symmetric 5M^2, sizes 16-256 fp64: first 625k rows (1/8)", lambda: S.config5(n=625_000), 8),
 ]
+if "--full" in sys.argv:  # the complete 8-GPU configs on ONE MI355X (16.4 GB / 28.7 GB of HBM)
+    sys.argv.remove("--full")
+    CONFIGS = [
+        ("C4 VBCRS 2M^2, 250000x 128x128 fp32, FULL on one GPU", lambda: S.config4(), 1),
+        ("C5 Symmetric 5M^2, sizes 16-256 fp64, FULL on one GPU", lambda: S.config5(), 1),
+    ]
 lines = ["| config | CPU oracle 1 thread GB/s | GPU N GB/s (% of 8 TB/s) | GPU T GB/s | rel-err N | rel-err T | alg MB |",
          "|---|---|---|---|---|---|---|"]
 for name, make, share in CONFIGS:
@@ -35,14 +41,16 @@ for name, make, share in CONFIGS:
     x = prob["x"]
     y0 = np.zeros(nr, dtype=dt)
     # CPU oracle, bounded sample
+    t0 = time.perf_counter()
     ref = oracle_mul(orc, prob, N, x, y0)
-    reps, t0 = 0, time.perf_counter()
-    while True:
+    reps, el = 1, time.perf_counter() - t0
+    t0 = time.perf_counter()
+    while el < 4.0 and reps < 200:
         oracle_mul(orc, prob, N, x, y0)
         reps += 1
         el = time.perf_counter() - t0
-        if el > 4.0 or reps >= 200:
-            break
+    if reps > 1:
+        reps -= 1
     cpu = st["alg_bytes"] * reps / el / 1e9
     out = {}
     for opname, Aop, op in (("N", A, N), ("T", bsm.transpose(A), T)):
