@@ -16,9 +16,11 @@ const libbsm = get(ENV, "BSM_ROCM_LIB", "libbsmrocm.so")
 
 "Opt-in scheduler: `BlockSparseMatrix(...; scheduler=ROCmScheduler())`."
 struct ROCmScheduler
-    device::Int32
+    device::Int32            # HIP ordinal, -1 = current device
+    accumulate::Int32        # 0 auto, 1 atomics, 2 coloured launches (bitwise reproducible)
+    transpose_image::Int32   # 1: keep a second, transposed ordering for A' / transpose(A)
 end
-ROCmScheduler() = ROCmScheduler(-1)   # BSM_DEVICE_CURRENT
+ROCmScheduler(; device=-1, accumulate=0, transpose_image=0) = ROCmScheduler(device, accumulate, transpose_image)
 BlockSparseMatrices.isserial(::ROCmScheduler) = true   # no host colouring needed for the GPU path
 
 mutable struct BsmOptions           # mirrors bsm_options (72 bytes)
@@ -43,10 +45,12 @@ end
 
 const _handles = WeakKeyDict{Any,Handle}()
 
-function _options(dev)
+function _options(s::ROCmScheduler)
     o = Ref(BsmOptions(0, 0, 0, 0, 0, 0, 0, 0, (0, 0, 0, 0)))
     ccall((:bsm_options_default, libbsm), Cvoid, (Ref{BsmOptions},), o)
-    o[].device = dev
+    o[].device = s.device
+    o[].accumulate = s.accumulate
+    o[].transpose_image = s.transpose_image
     return o
 end
 
@@ -63,7 +67,7 @@ function handle(A::VariableBlockCompressedRowStorage{T}) where {T}
             (Cint, Int64, Int64, Int64, Ptr{Ptr{Cvoid}}, Ptr{Int64}, Ptr{Int64}, Ptr{Int64},
              Ptr{Int64}, Ptr{Int64}, Ref{BsmOptions}, Ref{Ptr{Cvoid}}),
             _DTYPE[T], size(A, 1), size(A, 2), nb, ptrs, m, n, m, rowstart, colstart,
-            _options(A.scheduler.device), out))
+            _options(A.scheduler), out))
         Handle(out[])
     end
 end
@@ -79,7 +83,7 @@ function handle(A::BlockSparseMatrix{T}) where {T}
             (Cint, Int64, Int64, Int64, Ptr{Ptr{Cvoid}}, Ptr{Int64}, Ptr{Int64}, Ptr{Int64},
              Ptr{Ptr{Int64}}, Ptr{Ptr{Int64}}, Ref{BsmOptions}, Ref{Ptr{Cvoid}}),
             _DTYPE[T], size(A, 1), size(A, 2), nb, Ptr{Cvoid}[pointer(b) for b in A.blocks], m, n, m,
-            pointer.(ri), pointer.(ci), _options(A.scheduler.device), out))
+            pointer.(ri), pointer.(ci), _options(A.scheduler), out))
         Handle(out[])
     end
 end
@@ -98,7 +102,7 @@ function handle(A::SymmetricBlockMatrix{T}) where {T}
              Ptr{Ptr{Int64}}, Ref{BsmOptions}, Ref{Ptr{Cvoid}}),
             _DTYPE[T], size(A, 1), size(A, 2), length(ds), Ptr{Cvoid}[pointer(b) for b in A.diagonals],
             ds, ds, pointer.(di), length(m), Ptr{Cvoid}[pointer(b) for b in A.offdiagonals], m, n, m,
-            pointer.(ri), pointer.(ci), _options(A.scheduler.device), out))
+            pointer.(ri), pointer.(ci), _options(A.scheduler), out))
         Handle(out[])
     end
 end
@@ -126,5 +130,20 @@ function LinearMaps._unsafe_mul!(y::Vector{T}, A::Union{Z,LinearMaps.AdjointMap{
 end
 # device-resident vectors (AMDGPU.jl ROCVector): identical call with memspace = 1 and the
 # task-local HIP stream instead of C_NULL.
+
+# `A * X` / mul!(Y, A, X, α, β) with matrices: LinearMaps would loop the columns through the
+# method above (one sweep of A per column); bsm_mul_multi streams A once per 8 columns.
+function LinearMaps._unsafe_mul!(Y::Matrix{T}, A::Union{Z,LinearMaps.AdjointMap{<:Any,Z},
+        LinearMaps.TransposeMap{<:Any,Z}}, X::Matrix{T}, α::Number, β::Number) where {T,Z<:ROCmMat}
+    h = handle(_base(A))
+    a = Ref(T(α)); b = Ref(T(β === false ? 0 : β))
+    GC.@preserve X Y _check(ccall((:bsm_mul_multi, libbsm), Cint,
+        (Ptr{Cvoid}, Cint, Int64, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Int64, Ref{T}, Ref{T}, Cint, Cint, Ptr{Cvoid}),
+        h.ptr, _op(A), size(X, 2), X, stride(X, 2), Y, stride(Y, 2), a, b, β === false, 0, C_NULL))
+    return Y
+end
+
+# VariableBlockCompressedRowStorage(sbm) without materialising transpose(offdiagonals)
+# (reference src/vbcrs.jl:189-264): bsm_vbcrs_create_from_symmetric with first(...) of every list.
 
 end # module
