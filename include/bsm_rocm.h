@@ -68,7 +68,8 @@ typedef struct {
     int32_t device;      /* HIP ordinal, BSM_DEVICE_CURRENT or BSM_DEVICE_NONE */
     int32_t scheduler;   /* bsm_scheduler */
     int32_t accumulate;  /* bsm_accumulate */
-    int32_t validate;    /* 1: range-check every index at create time (default 1) */
+    int32_t validate;    /* kept for ABI stability: every index is ALWAYS range-checked at create time
+                            (an out-of-range index must never reach a kernel) */
     /* 1: VBCRS / BlockSparseMatrix handles also keep a SECOND, transposed ordering of the blocks
      * (the reference's own TODO, src/vbcrs.jl:124): transpose(A)*x and A'*x then run as a forward
      * product on it -- one launch, no atomics, bitwise reproducible -- at twice the device
