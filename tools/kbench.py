@@ -24,7 +24,8 @@ prob = {"c2": lambda: S.config2(), "c3": lambda: S.config3(), "c3s": lambda: S.c
         "c5u40": lambda: S.config5(n=300_000, lo=40, hi=40),
         "c5u100": lambda: S.config5(n=600_000, lo=100, hi=100),
         "c5m": lambda: S.config5(n=600_000, lo=65, hi=127),
-        "c5h": lambda: S.config5(n=2_500_000)}[which]()
+        "c5h": lambda: S.config5(n=2_500_000),
+        "bem": lambda: S.config5(n=1_500_000, lo=8, hi=28, halfband=8)}[which]()
 kw = {"accumulate": os.environ.get("KB_ACC", "auto")}
 if os.environ.get("KB_TIMG") and prob["kind"] != "symmetric":
     kw["transpose_image"] = True
