@@ -386,3 +386,50 @@ def test_config5_one_gpu_share_properties(torch_cuda, bsm):
     V = bsm.VariableBlockCompressedRowStorage(S)                        # view: blocks stored once
     assert bsm.nnz(V) == bsm.nnz(S)
     assert relerr(gpu_mul(torch_cuda, bsm, V, N, x, zero, 1, 0, True), sx) < 1e-12
+
+
+# ---- more edge cases ------------------------------------------------------------------------------------
+def test_degenerate_shapes_and_scalars(torch_cuda, bsm, oracle):
+    rng = np.random.default_rng(41)
+    # no blocks at all: y = beta*y (LinearMaps would still call _unsafe_mul!)
+    E0 = bsm.BlockSparseMatrix([], [], [], (7, 5))
+    y = gpu_mul(torch_cuda, bsm, E0, N, np.ones(5), np.arange(7.0), 1, 2.0, False)
+    assert np.array_equal(y, 2.0 * np.arange(7.0))
+    y = gpu_mul(torch_cuda, bsm, E0, T, np.ones(7), np.full(5, np.nan), 1, 0, True)
+    assert np.array_equal(y, np.zeros(5))
+    # one very wide row, one very tall column, one big dense block, a 1x1, all rectangular
+    blocks = [rng.standard_normal((1, 5000)), rng.standard_normal((3000, 1)), rng.standard_normal((700, 900)),
+              rng.standard_normal((1, 1))]
+    p = dict(kind="blocksparse", blocks=[np.asfortranarray(b) for b in blocks],
+             rowindices=[[4000], list(range(1, 3001)), list(range(3100, 3800)), [3900]],
+             colindices=[list(range(1, 5001)), [77], list(range(4000, 4900)), [5000]], size=(4000, 5000))
+    A = bsm.synthetic.build(p)
+    check_all(torch_cuda, bsm, oracle, p, A, np.float64, host_too=False)
+    At = bsm.synthetic.build(p, transpose_image=True)
+    check_all(torch_cuda, bsm, oracle, p, At, np.float64, ops=[T], host_too=False)
+    # alpha = 0, beta = true (1): y unchanged; alpha = true, beta = true accumulates
+    x, y0 = rand_vec(rng, 5000, np.float64), rand_vec(rng, 4000, np.float64)
+    assert np.array_equal(gpu_mul(torch_cuda, bsm, A, N, x, y0, 0.0, True, False), y0)
+    ref = oracle_mul(oracle, p, N, x, y0, 1, 1, False)
+    assert relerr(gpu_mul(torch_cuda, bsm, A, N, x, y0, True, True, False), ref) < 1e-12
+    # NaN / Inf in x propagate exactly where the reference's arithmetic puts them
+    xn = x.copy()
+    xn[76] = np.inf  # column 77: feeds the tall 3000 x 1 block only
+    yn = gpu_mul(torch_cuda, bsm, A, N, xn, np.zeros(4000), 1, 0, True)
+    refn = oracle_mul(oracle, p, N, xn, np.zeros(4000))
+    assert np.array_equal(np.isfinite(yn), np.isfinite(refn))
+
+
+def test_vbcrs_wide_block_row_many_blocks(torch_cuda, bsm, oracle):
+    # a block row with many blocks (> 3 column runs -> cols pool path) and unsorted input order
+    rng = np.random.default_rng(42)
+    nb = 40
+    cs = rng.permutation(np.arange(nb)) * 50 + 1
+    blocks = [np.asfortranarray(rng.standard_normal((20, int(w)))) for w in rng.integers(1, 50, nb)]
+    blocks += [np.asfortranarray(rng.standard_normal((9, 33)))]
+    p = dict(kind="vbcrs", blocks=blocks, rowstart=np.array([5] * nb + [100]), colstart=np.append(cs, 7),
+             size=(120, nb * 50))
+    A = bsm.synthetic.build(p)
+    assert A.stats()["exclusive"] == 1
+    check_all(torch_cuda, bsm, oracle, p, A, np.float64)
+    _check_multi(torch_cuda, bsm, oracle, p, A, np.float64, nrhs_list=(8,), ops=[N, T])
