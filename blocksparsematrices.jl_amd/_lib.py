@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libbsmrocm.so")
+LIB_PATH = os.environ.get("BSM_LIB", os.path.join(_HERE, "libbsmrocm.so"))  # BSM_LIB: developer A/B builds
 
 BSM_F32, BSM_F64, BSM_C64, BSM_C128 = 0, 1, 2, 3
 BSM_OP_N, BSM_OP_T, BSM_OP_C = 0, 1, 2

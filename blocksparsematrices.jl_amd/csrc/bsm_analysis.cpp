@@ -26,6 +26,7 @@ Tunables Tunables::from_env() {
     t.wgitem_max_bytes = geti("BSM_WGITEM_MAX_BYTES", t.wgitem_max_bytes);
     t.pack_threads = (int)geti("BSM_PACK_THREADS", t.pack_threads);
     t.wg_order = (int)geti("BSM_ORDER", t.wg_order);
+    t.lds_window = (int)geti("BSM_WINDOW", t.lds_window);
     if (t.pack_threads < 1) t.pack_threads = 1;
     return t;
 }
@@ -454,9 +455,18 @@ std::string Analysis::build(int mtype_, int dtype_, int64_t nrows_, int64_t ncol
             items.push_back(it);
         }
     }
-    std::stable_sort(items.begin(), items.end(), [](const Item &a, const Item &b) {
+    // symmetric operators: small items (1 or 2 waves) are ordered by LOCALITY (first row of their
+    // group) so that the waves of one workgroup touch neighbouring y entries and can share an LDS
+    // accumulation window; everything else largest-first
+    const bool use_window = sym && !colored && !exclusive_fwd && tun.lds_window;
+    auto locality = [&](const Item &it) -> int64_t {
+        const Group &G = groups[it.group];
+        return (G.rbase >= 0) ? G.rbase : rows[G.row_off];
+    };
+    std::stable_sort(items.begin(), items.end(), [&](const Item &a, const Item &b) {
         if (a.color != b.color) return a.color < b.color;
         if (a.nw != b.nw) return a.nw > b.nw;
+        if (use_window && a.nw < 4) return locality(a) < locality(b);
         return a.bytes > b.bytes;
     });
 
@@ -597,6 +607,44 @@ std::string Analysis::build(int mtype_, int dtype_, int64_t nrows_, int64_t ncol
         uint8_t sync = 0;
         for (int w = 0; w < kWavesPerWg; w++) sync |= (waves[wg + w].work == WORK_PANEL && waves[wg + w].grp > 1);
         for (int w = 0; w < kWavesPerWg; w++) waves[wg + w].wg_sync = sync;
+    }
+    if (use_window) {
+        for (size_t wg = 0; wg + kWavesPerWg <= (size_t)nwg_main * kWavesPerWg; wg += kWavesPerWg) {
+            int64_t lo = INT64_MAX, hi = -1, touched = 0;
+            int npanel = 0;
+            int32_t first_rbase = INT32_MIN, first_rowoff = INT32_MIN;
+            bool distinct = false;
+            for (int w = 0; w < kWavesPerWg; w++) {
+                const WaveWork &W = waves[wg + w];
+                if (W.work != WORK_PANEL || W.npieces == 0) continue;
+                if (npanel == 0) {
+                    first_rbase = W.rbase;
+                    first_rowoff = W.row_off;
+                } else if (W.rbase != first_rbase || W.row_off != first_rowoff) {
+                    distinct = true;
+                }
+                npanel++;
+                for (int i = 0; i < W.m; i++) {
+                    const int64_t r = (W.rbase >= 0) ? (int64_t)W.rbase + i : rows[W.row_off + i];
+                    lo = std::min(lo, r);
+                    hi = std::max(hi, r);
+                }
+                touched += W.m + W.first.ncols;
+                for (int32_t k = 0; k < W.first.ncols; k++) {
+                    const int64_t c = cols[W.first.col_off + k];
+                    lo = std::min(lo, c);
+                    hi = std::max(hi, c);
+                }
+            }
+            // worth it only when different groups meet and the window is reasonably dense
+            if (!distinct || hi < lo) continue;
+            const int64_t span = hi - lo + 1;
+            if (span > kWindowEntries || touched < span) continue;
+            for (int w = 0; w < kWavesPerWg; w++) {
+                waves[wg + w].win_base = (int32_t)lo;
+                waves[wg + w].win_span8 = (uint8_t)((span + 7) / 8);
+            }
+        }
     }
     if (rows.empty()) rows.push_back(0);
     if (cols.empty()) cols.push_back(0);

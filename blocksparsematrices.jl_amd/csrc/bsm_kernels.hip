@@ -112,31 +112,85 @@ __device__ __forceinline__ void atomic_acc(c128 *p, c128 v) {
     atomicAdd(&p->im, v.im);
 }
 
+// LDS accumulation (ds_add_f32 / ds_add_f64): the workgroup's y window
+__device__ __forceinline__ void lds_acc(float *p, float v) { atomicAdd(p, v); }
+__device__ __forceinline__ void lds_acc(double *p, double v) { atomicAdd(p, v); }
+__device__ __forceinline__ void lds_acc(c64 *p, c64 v) {
+    atomicAdd(&p->re, v.re);
+    atomicAdd(&p->im, v.im);
+}
+__device__ __forceinline__ void lds_acc(c128 *p, c128 v) {
+    atomicAdd(&p->re, v.re);
+    atomicAdd(&p->im, v.im);
+}
+__device__ __forceinline__ bool is_zero(float a) { return a == 0.f; }
+__device__ __forceinline__ bool is_zero(double a) { return a == 0.0; }
+__device__ __forceinline__ bool is_zero(c64 a) { return a.re == 0.f && a.im == 0.f; }
+__device__ __forceinline__ bool is_zero(c128 a) { return a.re == 0.0 && a.im == 0.0; }
+
 // ----------------------------------------------------------------------------------------
-// halving butterfly: every lane of a P-lane group holds CUR partial values; afterwards the
-// group's sums are spread over its lanes: lane i keeps max(1, V/P) of them, starting at
-// value index `pos`; lanes with (i & dup) != 0 hold duplicates and must not emit.
+// halving butterfly: every lane of a P-lane group holds V partial values; afterwards the group's
+// sums are spread over its lanes: lane i keeps max(1, V/P) of them, starting at value index `pos`;
+// lanes with (i & dup) != 0 hold duplicates and must not emit.
+// The four exchanges inside a 16-lane row are DPP moves (row_mirror = lane^15, row_half_mirror =
+// lane^7, quad_perm = lane^3, lane^1: plain VALU, no LDS traffic); only the 16- and 32-lane
+// exchanges, which carry the fewest values, go through ds_bpermute.  Each exchange pairs lanes
+// that agree on every bit decided so far, so both hold the same value subset.
 // ----------------------------------------------------------------------------------------
-template <typename T, int CUR, int D, int P> struct Butterfly {
-    static __device__ __forceinline__ void run(T *v, int i, int &pos, int &dup) {
-        if constexpr (D < P) {
-            const bool hi = (i & D) != 0;
-            if constexpr (CUR >= 2) {
-                constexpr int H = CUR / 2;
+template <int CTRL> __device__ __forceinline__ int dpp32(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, false);
+}
+template <int CTRL> __device__ __forceinline__ float dppx(float a) {
+    return __int_as_float(dpp32<CTRL>(__float_as_int(a)));
+}
+template <int CTRL> __device__ __forceinline__ double dppx(double a) {
+    const long long v = __double_as_longlong(a);
+    const int lo = dpp32<CTRL>((int)(v & 0xffffffffll));
+    const int hi = dpp32<CTRL>((int)(v >> 32));
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+template <int CTRL> __device__ __forceinline__ c64 dppx(c64 a) { return c64{dppx<CTRL>(a.re), dppx<CTRL>(a.im)}; }
+template <int CTRL> __device__ __forceinline__ c128 dppx(c128 a) { return c128{dppx<CTRL>(a.re), dppx<CTRL>(a.im)}; }
+
+constexpr int DPP_ROW_MIRROR = 0x140;       // lane ^ 15
+constexpr int DPP_ROW_HALF_MIRROR = 0x141;  // lane ^ 7
+constexpr int DPP_QUAD_XOR3 = 0x1B;         // quad_perm [3,2,1,0]
+constexpr int DPP_QUAD_XOR1 = 0xB1;         // quad_perm [1,0,3,2]
+
+// one exchange: BIT decides who keeps which half; XCH(v) returns the partner's value
+template <typename T, int CUR, int BIT, typename XCH>
+__device__ __forceinline__ void bfly_step(T *v, int i, int &pos, int &dup, XCH xch) {
+    const bool hi = (i & BIT) != 0;
+    if constexpr (CUR >= 2) {
+        constexpr int H = CUR / 2;
 #pragma unroll
-                for (int j = 0; j < H; ++j) {
-                    const T keep = hi ? v[H + j] : v[j];
-                    const T send = hi ? v[j] : v[H + j];
-                    v[j] = add(keep, shx(send, D));
-                }
-                if (hi) pos += H;
-                Butterfly<T, H, D * 2, P>::run(v, i, pos, dup);
-            } else {
-                v[0] = add(v[0], shx(v[0], D));
-                dup |= D;
-                Butterfly<T, 1, D * 2, P>::run(v, i, pos, dup);
-            }
+        for (int j = 0; j < H; ++j) {
+            const T keep = hi ? v[H + j] : v[j];
+            const T send = hi ? v[j] : v[H + j];
+            v[j] = add(keep, xch(send));
         }
+        if (hi) pos += H;
+    } else {
+        v[0] = add(v[0], xch(v[0]));
+        dup |= BIT;
+    }
+}
+
+template <typename T, int V, int P> struct Butterfly {
+    static constexpr int half(int cur) { return cur >= 2 ? cur / 2 : 1; }
+    static __device__ __forceinline__ void run(T *v, int i, int &pos, int &dup) {
+        constexpr int C0 = V;
+        constexpr int C1 = (P >= 16) ? half(C0) : C0;  // after lane^15 (bit 3)
+        constexpr int C2 = half(C1);                   // after lane^7  (bit 2)   (P >= 8 always)
+        constexpr int C3 = half(C2);                   // after lane^3  (bit 1)
+        constexpr int C4 = half(C3);                   // after lane^1  (bit 0)
+        constexpr int C5 = (P >= 32) ? half(C4) : C4;  // after lane^16 (bit 4)
+        if constexpr (P >= 16) bfly_step<T, C0, 8>(v, i, pos, dup, [](T a) { return dppx<DPP_ROW_MIRROR>(a); });
+        bfly_step<T, C1, 4>(v, i, pos, dup, [](T a) { return dppx<DPP_ROW_HALF_MIRROR>(a); });
+        bfly_step<T, C2, 2>(v, i, pos, dup, [](T a) { return dppx<DPP_QUAD_XOR3>(a); });
+        bfly_step<T, C3, 1>(v, i, pos, dup, [](T a) { return dppx<DPP_QUAD_XOR1>(a); });
+        if constexpr (P >= 32) bfly_step<T, C4, 16>(v, i, pos, dup, [](T a) { return shx(a, 16); });
+        if constexpr (P >= 64) bfly_step<T, C5, 32>(v, i, pos, dup, [](T a) { return shx(a, 32); });
     }
 };
 
@@ -155,7 +209,7 @@ struct PieceD {
     int xbase, col_off, nstrips, ncols, kind, seg2_x;
 };
 struct WaveD {
-    int npieces, row_off, rbase, m, work, grp, lead, wg_sync, seg1_w, seg1_x, seg2_w;
+    int npieces, row_off, rbase, m, work, grp, lead, wg_sync, seg1_w, seg1_x, seg2_w, win_base, win_n;
     PieceD first;
 };
 
@@ -177,7 +231,7 @@ __device__ __forceinline__ WaveD load_wave(const WaveWork *__restrict__ wp) {
     const uint4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
     WaveD w;
     w.seg1_w = (int)q0.x;
-    w.npieces = (int)q0.y;
+    w.win_base = (int)q0.y;
     w.row_off = (int)q0.z;
     w.rbase = (int)q0.w;
     w.m = (int)(q1.x & 0xffffu);
@@ -185,6 +239,8 @@ __device__ __forceinline__ WaveD load_wave(const WaveWork *__restrict__ wp) {
     w.grp = (int)(q1.x >> 24);
     w.lead = (int)(q1.y & 0xffu);
     w.wg_sync = (int)((q1.y >> 8) & 0xffu);
+    w.npieces = (int)((q1.y >> 16) & 0xffu);
+    w.win_n = (int)(q1.y >> 24) * 8;
     w.seg1_x = (int)q1.z;
     w.seg2_w = (int)q1.w;
     w.first = decode_piece(q2, q3);
@@ -201,7 +257,7 @@ template <typename T, int L, int P, bool FWD, bool TRN>
 __device__ __forceinline__ T run_panel(const WaveD &wd, const uint4 *__restrict__ values,
                                        const int *__restrict__ rows, const int *__restrict__ cols,
                                        const T *__restrict__ x, T *__restrict__ y, T alpha,
-                                       int flags, int lane, T *xs, T *vs) {
+                                       int flags, int lane, T *xs, T *vs, T *win, int win_n) {
     constexpr int E = TT<T>::E;
     constexpr int G = 64 / P;
     constexpr int V = L * E;
@@ -291,7 +347,7 @@ __device__ __forceinline__ T run_panel(const WaveD &wd, const uint4 *__restrict_
 #pragma unroll
                         for (int e = 0; e < E; ++e) vals[l * E + e] = mul(cj(b[l].v[e], cjf), xr);
                     int pos = 0, dup = 0;
-                    Butterfly<T, V, 1, P>::run(vals, i, pos, dup);
+                    Butterfly<T, V, P>::run(vals, i, pos, dup);
                     constexpr int CF = (V / P) > 1 ? (V / P) : 1;
                     // the column sums of BF consecutive iterations are parked in LDS and leave the
                     // wave together: atomics are priced per wave-instruction, so 64 busy lanes
@@ -315,7 +371,10 @@ __device__ __forceinline__ T run_panel(const WaveD &wd, const uint4 *__restrict_
                             if (c < (slot + 1) * NC && w < ncols) {
                                 const int yi = col_index(w);
                                 const T val = mul(alpha, vs[c]);
-                                if (flags & FLAG_RMW)
+                                const unsigned wi = (unsigned)(yi - wd.win_base);
+                                if (wi < (unsigned)win_n)
+                                    lds_acc(&win[wi], val);  // leaves the CU once, with the window
+                                else if (flags & FLAG_RMW)
                                     y[yi] = add(y[yi], val);
                                 else
                                     atomic_acc(&y[yi], val);
@@ -349,23 +408,32 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((!TRN 
     __shared__ __attribute__((aligned(16))) T xs[kWavesPerWg][FWD ? XS : 1];
     __shared__ __attribute__((aligned(16))) T vs[kWavesPerWg][TRN ? VS : 1];
     __shared__ T red[kWavesPerWg][64];
+    // y window of workgroups that pack neighbouring small row groups of a symmetric operator
+    constexpr bool WIN = FWD && TRN;
+    __shared__ T win[WIN ? kWindowEntries : 1];
 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const WaveD wd = load_wave(waves + ((size_t)(blockIdx.x + wg_base) * kWavesPerWg + wave));
     const int work = wd.work;
     const int m = wd.m;
+    // workgroup-uniform (all 4 descriptors carry the same window; coloured launches keep plain RMW)
+    const int win_n = (WIN && !(flags & FLAG_RMW)) ? wd.win_n : 0;
+    if (WIN && win_n > 0) {
+        for (int e = threadIdx.x; e < win_n; e += 256) win[e] = zero_of(T{});
+        __syncthreads();
+    }
 
     T u = zero_of(T{});
     if (work == WORK_PANEL) {
         if (m <= 8)
-            u = run_panel<T, L, 8, FWD, TRN>(wd, values, rows, cols, x, y, alpha, flags, lane, xs[wave], vs[wave]);
+            u = run_panel<T, L, 8, FWD, TRN>(wd, values, rows, cols, x, y, alpha, flags, lane, xs[wave], vs[wave], win, win_n);
         else if (m <= 16)
-            u = run_panel<T, L, 16, FWD, TRN>(wd, values, rows, cols, x, y, alpha, flags, lane, xs[wave], vs[wave]);
+            u = run_panel<T, L, 16, FWD, TRN>(wd, values, rows, cols, x, y, alpha, flags, lane, xs[wave], vs[wave], win, win_n);
         else if (m <= 32)
-            u = run_panel<T, L, 32, FWD, TRN>(wd, values, rows, cols, x, y, alpha, flags, lane, xs[wave], vs[wave]);
+            u = run_panel<T, L, 32, FWD, TRN>(wd, values, rows, cols, x, y, alpha, flags, lane, xs[wave], vs[wave], win, win_n);
         else
-            u = run_panel<T, L, 64, FWD, TRN>(wd, values, rows, cols, x, y, alpha, flags, lane, xs[wave], vs[wave]);
+            u = run_panel<T, L, 64, FWD, TRN>(wd, values, rows, cols, x, y, alpha, flags, lane, xs[wave], vs[wave], win, win_n);
     }
     const bool direct = (flags & FLAG_DIRECT) != 0;
     const bool sz = (flags & FLAG_STRONG_ZERO) != 0;
@@ -379,14 +447,26 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((!TRN 
             if (lane < m) {
                 const int yi = (wd.rbase >= 0) ? wd.rbase + lane : rows[wd.row_off + lane];
                 const T val = mul(alpha, u);
+                const unsigned wi = (unsigned)(yi - wd.win_base);
                 if (direct) {
                     y[yi] = sz ? val : madd(val, beta, y[yi]);
+                } else if (wi < (unsigned)win_n) {
+                    lds_acc(&win[wi], val);
                 } else if (flags & FLAG_RMW) {
                     y[yi] = add(y[yi], val);
                 } else {
                     atomic_acc(&y[yi], val);
                 }
             }
+        }
+    }
+    if (WIN && win_n > 0) {
+        // every wave has parked its sums: the window leaves the CU once, 64 contiguous entries
+        // per atomic wave-instruction
+        __syncthreads();
+        for (int e = threadIdx.x; e < win_n; e += 256) {
+            const T v = win[e];
+            if (!is_zero(v)) atomic_acc(&y[wd.win_base + e], v);
         }
     }
     if (work == WORK_SCALE && direct) {
@@ -505,7 +585,7 @@ __device__ __forceinline__ void run_panel_multi(const WaveD &wd, const uint4 *__
 #pragma unroll
                             for (int e = 0; e < E; ++e) vals[l * E + e] = mul(cj(b[l].v[e], cjf), xr[k]);
                         int pos = 0, dup = 0;
-                        Butterfly<T, V, 1, P>::run(vals, i, pos, dup);
+                        Butterfly<T, V, P>::run(vals, i, pos, dup);
                         constexpr int CF = (V / P) > 1 ? (V / P) : 1;
                         if ((i & dup) == 0) {
 #pragma unroll

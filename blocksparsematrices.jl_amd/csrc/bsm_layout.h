@@ -47,9 +47,14 @@ static_assert(sizeof(Piece) == 32, "Piece must be 32 bytes");
 // row).  Up to three runs are described inline -- segment k covers piece columns
 // [seg_k_w, seg_{k+1}_w) and maps column w to x index seg_k_x + (w - seg_k_w), seg_0_w = 0 --
 // so the wave computes its x addresses without a dependent load of the cols pool.
+// Workgroups whose waves work on DIFFERENT small row groups of a symmetric operator are packed by
+// locality; their y contributions (forward rows and transposed columns) largely coincide, so they
+// are accumulated in an LDS window [win_base, win_base + 8*win_span8) and leave the CU once.
+constexpr int kWindowEntries = 1024;
+
 struct WaveWork {
     int32_t seg1_w;       // first piece column of segment 1 (>= ncols when unused)
-    int32_t npieces;      // 0 (nothing to stream) or 1
+    int32_t win_base;     // first y index of the workgroup's LDS accumulation window
     int32_t row_off;      // rows pool offset (indexed row groups)
     int32_t rbase;        // >= 0: rows are the contiguous range starting here (0-based); -1: indexed
     uint16_t m;           // rows of the group (1..64)
@@ -57,7 +62,8 @@ struct WaveWork {
     uint8_t grp;          // waves of this workgroup sharing the row group (1, 2 or 4)
     uint8_t lead;         // 1: this wave combines the group's partial sums and writes y
     uint8_t wg_sync;      // 1: some wave of this workgroup has grp > 1 (all 4 waves carry the same value)
-    uint8_t pad0[2];
+    uint8_t npieces;      // 0 (nothing to stream) or 1
+    uint8_t win_span8;    // window length / 8 (0: no window); same value in all 4 waves
     int32_t seg1_x;       // first x index of segment 1
     int32_t seg2_w;       // first piece column of segment 2 (>= ncols when unused)
     Piece first;

@@ -150,8 +150,9 @@ def scipy_mul(problem, op, x, y0, alpha=1, beta=0, strong=True):
 # ---- packed-image interpreter -------------------------------------------------------------------
 PIECE_DT = np.dtype([("val_off", "<u8"), ("xbase", "<i4"), ("col_off", "<i4"), ("nstrips", "<i4"),
                      ("ncols", "<i4"), ("kind", "<i4"), ("seg2_x", "<i4")])
-WAVE_DT = np.dtype([("seg1_w", "<i4"), ("npieces", "<i4"), ("row_off", "<i4"), ("rbase", "<i4"),
-                    ("m", "<u2"), ("work", "u1"), ("grp", "u1"), ("lead", "u1"), ("wg_sync", "u1"), ("pad0", "u1", 2),
+WAVE_DT = np.dtype([("seg1_w", "<i4"), ("win_base", "<i4"), ("row_off", "<i4"), ("rbase", "<i4"),
+                    ("m", "<u2"), ("work", "u1"), ("grp", "u1"), ("lead", "u1"), ("wg_sync", "u1"),
+                    ("npieces", "u1"), ("win_span8", "u1"),
                     ("seg1_x", "<i4"), ("seg2_w", "<i4"), ("first", PIECE_DT)])
 assert PIECE_DT.itemsize == 32 and WAVE_DT.itemsize == 64
 WORK_NOP, WORK_PANEL, WORK_SCALE = 0, 1, 2

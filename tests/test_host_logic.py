@@ -316,6 +316,37 @@ def test_second_ordering_transposed_image(bsm, oracle):
     assert relerr(interpret_image(Cm, T, x, y0, 0.5, 2.0, False, timage=True), ref) < 1e-13
 
 
+def test_lds_window_descriptors_cover_their_workgroup(bsm):
+    # workgroups of a symmetric operator that pack neighbouring small row groups carry an LDS
+    # accumulation window: it must be workgroup-uniform and hold at most kWindowEntries entries
+    from _common import WORK_PANEL, get_image
+    p = bsm.synthetic.config5(n=20000, lo=8, hi=28, halfband=6)
+    A = bsm.synthetic.build(p, device=NODEV)
+    values, rows, cols, waves = get_image(A)
+    wg = waves.reshape(-1, 4)
+    nwin = 0
+    for quad in wg:
+        assert len(set(quad["win_span8"])) == 1 and len(set(quad["win_base"])) == 1
+        span = int(quad["win_span8"][0]) * 8
+        assert span <= 1024
+        if span == 0:
+            continue
+        nwin += 1
+        base = int(quad["win_base"][0])
+        groups = set()
+        for W in quad[(quad["work"] == WORK_PANEL) & (quad["npieces"] > 0)]:
+            m = int(W["m"])
+            r = np.arange(W["rbase"], W["rbase"] + m) if W["rbase"] >= 0 else rows[W["row_off"]:W["row_off"] + m]
+            c = cols[W["first"]["col_off"]:W["first"]["col_off"] + W["first"]["ncols"]]
+            assert r.min() >= base and r.max() < base + span and c.min() >= base and c.max() < base + span
+            groups.add((int(W["rbase"]), int(W["row_off"])))
+        assert len(groups) >= 2
+    assert nwin > 0
+    # coloured handles never use the window (plain RMW per colour class)
+    B = bsm.synthetic.build(p, device=NODEV, accumulate="colored")
+    assert not np.any(get_image(B)[3]["win_span8"])
+
+
 def test_own_range_limits_scale_work(bsm):
     p = bsm.synthetic.config2(n=2000, nblocks=40)
     A = bsm.VariableBlockCompressedRowStorage(p["blocks"], p["rowstart"], p["colstart"], p["size"],

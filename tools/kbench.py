@@ -29,6 +29,15 @@ prob = {"c2": lambda: S.config2(), "c3": lambda: S.config3(), "c3s": lambda: S.c
 kw = {"accumulate": os.environ.get("KB_ACC", "auto")}
 if os.environ.get("KB_TIMG") and prob["kind"] != "symmetric":
     kw["transpose_image"] = True
+if os.environ.get("KB_COMPLEX"):
+    # complex variant of the same structure (BEM operators are ComplexF64 in the reference's fixtures)
+    cdt = np.complex64 if prob["x"].dtype == np.float32 else np.complex128
+    for key in ("blocks", "diagonals", "offdiagonals"):
+        if key in prob:
+            prob[key] = [np.asfortranarray(b + 1j * b[::-1, ::-1]).astype(cdt) for b in prob[key]]
+    if prob["kind"] == "symmetric":
+        prob["diagonals"] = [np.asfortranarray((d + d.T) / 2) for d in prob["diagonals"]]
+    prob["x"] = (prob["x"] + 1j * prob["x"][::-1]).astype(cdt)
 if os.environ.get("KB_AS_BSM") and prob["kind"] == "symmetric":
     # same bytes as a forward-only BlockSparseMatrix (isolates the cost of the transposed half)
     prob = dict(kind="blocksparse", blocks=prob["diagonals"] + prob["offdiagonals"],
