@@ -433,3 +433,23 @@ def test_vbcrs_wide_block_row_many_blocks(torch_cuda, bsm, oracle):
     assert A.stats()["exclusive"] == 1
     check_all(torch_cuda, bsm, oracle, p, A, np.float64)
     _check_multi(torch_cuda, bsm, oracle, p, A, np.float64, nrhs_list=(8,), ops=[N, T])
+
+
+def test_symmetric_getindex_and_adjoint_semantics(torch_cuda, bsm):
+    # test_symmetricblockmatrix.jl:46-64: sparse(b[:, :]) vs sparse(b), adjoint(b)[:, :] vs conj(transpose),
+    # transpose(b)[:, :] vs transpose -- on a small complex-symmetric operator with non-symmetric blocks
+    rng = np.random.default_rng(51)
+    d1 = rng.standard_normal((3, 3)) + 1j * rng.standard_normal((3, 3))   # deliberately NOT symmetric
+    d2 = rng.standard_normal((2, 2)) + 1j * rng.standard_normal((2, 2))
+    o1 = rng.standard_normal((3, 2)) + 1j * rng.standard_normal((3, 2))
+    o2 = rng.standard_normal((2, 4)) + 1j * rng.standard_normal((2, 4))
+    S = bsm.SymmetricBlockMatrix([d1, d2], [[1, 4, 2], [7, 9]], [o1, o2], [[1, 4, 2], [7, 9]],
+                                 [[9, 7], [3, 5, 6, 8]], (9, 9), scheduler=bsm.SerialScheduler())
+    ref = bsm.sparse(S).toarray()
+    assert np.max(np.abs(S[:, :] - ref)) < 1e-13
+    # reference semantics of the wrappers (src/symmetricblockmatrix.jl:219-237): the transpose map uses
+    # transpose(D) on the diagonal and swaps the off-diagonal roles, the adjoint map conjugates as well
+    assert np.max(np.abs(bsm.transpose(S)[:, :] - ref.T)) < 1e-13
+    assert np.max(np.abs(bsm.adjoint(S)[:, :] - ref.conj().T)) < 1e-13
+    assert np.max(np.abs(bsm.sparse(bsm.transpose(S)).toarray() - ref.T)) < 1e-13
+    assert np.max(np.abs(bsm.sparse(bsm.adjoint(S)).toarray() - ref.conj().T)) < 1e-13
