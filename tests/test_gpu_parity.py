@@ -453,3 +453,78 @@ def test_symmetric_getindex_and_adjoint_semantics(torch_cuda, bsm):
     assert np.max(np.abs(bsm.adjoint(S)[:, :] - ref.conj().T)) < 1e-13
     assert np.max(np.abs(bsm.sparse(bsm.transpose(S)).toarray() - ref.T)) < 1e-13
     assert np.max(np.abs(bsm.sparse(bsm.adjoint(S)).toarray() - ref.conj().T)) < 1e-13
+
+
+# ---- boundary properties promised by include/bsm_rocm.h ----------------------------------------------------
+def test_mul_is_graph_capturable_and_stream_ordered(torch_cuda, bsm, oracle):
+    # bsm_mul with BSM_MEM_DEVICE only enqueues work: no allocation, no synchronisation
+    torch = torch_cuda
+    p = bsm.synthetic.config3(nseg=40)
+    A = bsm.synthetic.build(p)              # symmetric: scale kernel + fused kernel (2 launches)
+    n = p["size"][0]
+    x = torch.from_numpy(p["x"]).cuda()
+    y = torch.zeros(n, dtype=torch.float64, device="cuda")
+    plan = bsm.MulPlan(y, A, x, 0.5, 2.0)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        plan()                               # warm-up outside capture
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            plan()
+    torch.cuda.current_stream().wait_stream(s)
+    rng = np.random.default_rng(61)
+    for _ in range(3):
+        xh, yh = rand_vec(rng, n, np.float64), rand_vec(rng, n, np.float64)
+        x.copy_(torch.from_numpy(xh))
+        y.copy_(torch.from_numpy(yh))
+        g.replay()
+        torch.cuda.synchronize()
+        ref = oracle_mul(oracle, p, N, xh, yh, 0.5, 2.0, False)
+        assert relerr(y.cpu().numpy(), ref) < 1e-12
+
+
+def test_concurrent_mul_on_two_streams_and_threads(torch_cuda, bsm, oracle):
+    # a handle is immutable: concurrent products with distinct y on distinct streams are legal
+    import threading
+    torch = torch_cuda
+    p = bsm.synthetic.config2(n=30000, nblocks=1500)
+    A = bsm.synthetic.build(p)
+    n = p["size"][0]
+    rng = np.random.default_rng(62)
+    xs = [rand_vec(rng, n, np.float64) for _ in range(2)]
+    refs = [oracle_mul(oracle, p, N, xv, np.zeros(n)) for xv in xs]
+    outs = [None, None]
+
+    def work(k):
+        st = torch.cuda.Stream()
+        with torch.cuda.stream(st):
+            xd = torch.from_numpy(xs[k]).cuda()
+            yd = torch.full((n,), float("nan"), dtype=torch.float64, device="cuda")
+            for _ in range(50):
+                bsm.mul(yd, A, xd)
+            st.synchronize()
+            outs[k] = yd.cpu().numpy()
+
+    th = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for k in range(2):
+        assert relerr(outs[k], refs[k]) < 1e-12
+
+
+def test_row_partitioned_single_rank_path(torch_cuda, bsm, oracle):
+    # distributed.RowPartitioned with world size 1 (no process group): the local product only
+    from bsm_amd import distributed as D
+    torch = torch_cuda
+    p = bsm.synthetic.config2(n=20000, nblocks=800)
+    local, own = D.split_vbcrs(p, 0, 1)
+    A = bsm.synthetic.build(local, own=own)
+    P = D.RowPartitioned(A, own)
+    x = torch.from_numpy(p["x"]).cuda()
+    y = torch.full((p["size"][0],), float("nan"), dtype=torch.float64, device="cuda")
+    P.mul(y, x)
+    torch.cuda.synchronize()
+    assert relerr(y.cpu().numpy(), oracle_mul(oracle, p, N, p["x"], np.zeros(p["size"][0]))) < 1e-12
