@@ -16,6 +16,8 @@ S = bsm.synthetic
 prob = {"c2": lambda: S.config2(), "c3": lambda: S.config3(), "c3s": lambda: S.config3(nseg=800),
         "c4s": lambda: S.config4(row_lo=0, row_hi=1953),
         "c2t": lambda: S.config2(n=6000, lo=1, hi=1, nblocks=14000),
+        "c2q": lambda: S.config2(n=30000, nblocks=1500),
+        "c2h": lambda: S.config2(n=50000, nblocks=2500),
         "c2u": lambda: S.config2(n=100000, lo=36, hi=36, nblocks=5000),
         "c2p": lambda: S.config2(n=100000, lo=32, hi=32, nblocks=6400),
         "c2w": lambda: S.config2(n=100000, lo=64, hi=64, nblocks=1650), "c5s": lambda: S.config5(n=600_000),
