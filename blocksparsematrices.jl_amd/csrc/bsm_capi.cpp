@@ -4,6 +4,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -23,7 +24,59 @@ struct bsm_matrix_s {
     bool has_t = false;
     Analysis an_t;
     DeviceImage img_t;
+    // device staging buffers of the BSM_MEM_HOST path, kept between calls (grow-only); a second
+    // concurrent host call on the same handle falls back to temporary buffers
+    std::mutex host_mu;
+    void *stage_x = nullptr, *stage_y = nullptr;
+    size_t stage_x_bytes = 0, stage_y_bytes = 0;
 };
+
+namespace {
+// RAII staging buffers: cached in the handle when uncontended, temporary otherwise
+struct Staging {
+    bsm_matrix_s *A;
+    bool locked = false;
+    void *dx = nullptr, *dy = nullptr;
+    bool own = false;
+    hipError_t acquire(bsm_matrix_s *a, size_t xbytes, size_t ybytes) {
+        A = a;
+        locked = A->host_mu.try_lock();
+        hipError_t e = hipSuccess;
+        if (locked) {
+            if (A->stage_x_bytes < xbytes) {
+                if (A->stage_x) (void)hipFree(A->stage_x);
+                A->stage_x = nullptr;
+                A->stage_x_bytes = 0;
+                e = hipMalloc(&A->stage_x, xbytes + 16);
+                if (e != hipSuccess) return e;
+                A->stage_x_bytes = xbytes;
+            }
+            if (A->stage_y_bytes < ybytes) {
+                if (A->stage_y) (void)hipFree(A->stage_y);
+                A->stage_y = nullptr;
+                A->stage_y_bytes = 0;
+                e = hipMalloc(&A->stage_y, ybytes + 16);
+                if (e != hipSuccess) return e;
+                A->stage_y_bytes = ybytes;
+            }
+            dx = A->stage_x;
+            dy = A->stage_y;
+        } else {
+            own = true;
+            e = hipMalloc(&dx, xbytes + 16);
+            if (e == hipSuccess) e = hipMalloc(&dy, ybytes + 16);
+        }
+        return e;
+    }
+    ~Staging() {
+        if (own) {
+            if (dx) (void)hipFree(dx);
+            if (dy) (void)hipFree(dy);
+        }
+        if (locked) A->host_mu.unlock();
+    }
+};
+}  // namespace
 
 static thread_local std::string g_err;
 
@@ -404,17 +457,15 @@ extern "C" int bsm_mul(bsm_matrix_t A, int op, const void *x, void *y, const voi
     const size_t es = (size_t)A->an.es;
     const size_t xlen = (size_t)(op == 0 ? A->img.ncols : A->img.nrows);
     const size_t ylen = (size_t)(op == 0 ? A->img.nrows : A->img.ncols);
-    void *dx = nullptr, *dy = nullptr;
-    e = hipMalloc(&dx, xlen * es + 16);
-    if (e == hipSuccess) e = hipMalloc(&dy, ylen * es + 16);
+    Staging sg;
+    e = sg.acquire(A, xlen * es, ylen * es);
+    void *dx = sg.dx, *dy = sg.dy;
     if (e == hipSuccess) e = hipMemcpyAsync(dx, x, xlen * es, hipMemcpyHostToDevice, st);
     if (e == hipSuccess && !beta_strong_zero)
         e = hipMemcpyAsync(dy, y, ylen * es, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = launch_mul(img, opT, conj, dx, dy, alpha, beta, beta_strong_zero, st);
     if (e == hipSuccess) e = hipMemcpyAsync(y, dy, ylen * es, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
-    if (dx) (void)hipFree(dx);
-    if (dy) (void)hipFree(dy);
     if (e != hipSuccess) return hip_fail(e, "host-staged mul");
     return BSM_OK;
 }
@@ -448,9 +499,9 @@ extern "C" int bsm_mul_multi(bsm_matrix_t A, int op, int64_t nrhs, const void *X
     }
     if (memspace != BSM_MEM_HOST) return fail(BSM_ERR_INVALID, "bad memspace");
     const size_t es = (size_t)A->an.es;
-    void *dx = nullptr, *dy = nullptr;
-    e = hipMalloc(&dx, (size_t)xlen * nrhs * es + 16);
-    if (e == hipSuccess) e = hipMalloc(&dy, (size_t)ylen * nrhs * es + 16);
+    Staging sg;
+    e = sg.acquire(A, (size_t)xlen * nrhs * es, (size_t)ylen * nrhs * es);
+    void *dx = sg.dx, *dy = sg.dy;
     if (e == hipSuccess)
         e = hipMemcpy2DAsync(dx, (size_t)xlen * es, X, (size_t)ldx * es, (size_t)xlen * es, (size_t)nrhs,
                              hipMemcpyHostToDevice, st);
@@ -463,8 +514,6 @@ extern "C" int bsm_mul_multi(bsm_matrix_t A, int op, int64_t nrhs, const void *X
         e = hipMemcpy2DAsync(Y, (size_t)ldy * es, dy, (size_t)ylen * es, (size_t)ylen * es, (size_t)nrhs,
                              hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
-    if (dx) (void)hipFree(dx);
-    if (dy) (void)hipFree(dy);
     if (e != hipSuccess) return hip_fail(e, "host-staged multi mul");
     return BSM_OK;
 }
@@ -581,6 +630,8 @@ extern "C" int bsm_destroy(bsm_matrix_t A) {
         (void)guard.enter(A->img.device);
         free_image(A->img);
         free_image(A->img_t);
+        if (A->stage_x) (void)hipFree(A->stage_x);
+        if (A->stage_y) (void)hipFree(A->stage_y);
     }
     delete A;
     return BSM_OK;
