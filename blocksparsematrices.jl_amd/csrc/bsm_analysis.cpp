@@ -139,6 +139,24 @@ struct Item {
     int32_t color;
 };
 
+// scattered variant: block column w lands at merged panel column dstpos[w] (the merged column
+// list of a row group with index lists is kept SORTED by x index, see build())
+template <typename U>
+void pack_chunk_perm(const U *src, int64_t ld, int ra, int mc, int64_t n, const int32_t *dstpos, int E,
+                     bool trans, U *dst) {
+    for (int64_t w = 0; w < n; w++) {
+        const int64_t mp = dstpos[w];
+        U *d = dst + ((mp / E) * mc) * E + (mp % E);
+        if (!trans) {
+            const U *col = src + ra + w * ld;
+            for (int i = 0; i < mc; i++) d[(int64_t)i * E] = col[i];
+        } else {
+            const U *row = src + w + (int64_t)ra * ld;
+            for (int i = 0; i < mc; i++) d[(int64_t)i * E] = row[(int64_t)i * ld];
+        }
+    }
+}
+
 template <typename U>
 void pack_chunk(const U *src, int64_t ld, int ra, int mc, int64_t n, int64_t woff, int E, bool trans,
                 U *dst) {
@@ -324,17 +342,46 @@ std::string Analysis::build(int mtype_, int dtype_, int64_t nrows_, int64_t ncol
         if (total_cols + 8 > INT32_MAX) return "column index pool exceeds int32";
         cols.reserve((size_t)total_cols);
     }
-    for (Group &G : groups) {
-        G.strips = (G.width + E - 1) / E;
-        if (G.strips * (int64_t)G.mc * 16 >= ((int64_t)1 << 31)) return "row group panel exceeds 2 GiB";
-        G.col_off = (int64_t)cols.size();
-        for (int32_t ci : G.chunks) {
-            const BlockIn &B = blocks[chunks[ci].blk];
-            for (int64_t k = 0; k < B.n; k++)
-                cols.push_back((int32_t)((B.cidx ? B.cidx[k] : B.c0 + k) - 1));
+    // colpos[G.col_off + q]: merged panel column of the q-th column in chunk order.  The order of
+    // the columns inside a panel is free (a sum), so the merged column list is kept SORTED by x
+    // index: neighbouring lanes then gather neighbouring x entries and emit neighbouring y
+    // entries, and scattered index lists (BEM near-field panels) collapse into contiguous runs.
+    std::vector<int32_t> colpos;
+    std::vector<uint8_t> group_perm(groups.size(), 0);
+    colpos.reserve(cols.capacity());
+    {
+        std::vector<int32_t> ord;
+        size_t gi = 0;
+        for (Group &G : groups) {
+            G.strips = (G.width + E - 1) / E;
+            if (G.strips * (int64_t)G.mc * 16 >= ((int64_t)1 << 31)) return "row group panel exceeds 2 GiB";
+            G.col_off = (int64_t)cols.size();
+            for (int32_t ci : G.chunks) {
+                const BlockIn &B = blocks[chunks[ci].blk];
+                for (int64_t k = 0; k < B.n; k++)
+                    cols.push_back((int32_t)((B.cidx ? B.cidx[k] : B.c0 + k) - 1));
+            }
+            int32_t *gc = cols.data() + G.col_off;
+            colpos.resize(cols.size());
+            int32_t *gp = colpos.data() + G.col_off;
+            if (std::is_sorted(gc, gc + G.width)) {
+                for (int64_t q = 0; q < G.width; q++) gp[q] = (int32_t)q;
+            } else {
+                group_perm[gi] = 1;
+                ord.resize((size_t)G.width);
+                std::iota(ord.begin(), ord.end(), 0);
+                std::stable_sort(ord.begin(), ord.end(), [&](int32_t a, int32_t b) { return gc[a] < gc[b]; });
+                std::vector<int32_t> sorted((size_t)G.width);
+                for (int64_t r = 0; r < G.width; r++) {
+                    sorted[r] = gc[ord[r]];
+                    gp[ord[r]] = (int32_t)r;
+                }
+                std::copy(sorted.begin(), sorted.end(), gc);
+            }
+            G.val_off = val_units;
+            val_units += (uint64_t)G.mc * (uint64_t)G.strips;
+            gi++;
         }
-        G.val_off = val_units;
-        val_units += (uint64_t)G.mc * (uint64_t)G.strips;
     }
 
     lap("groups + column lists");
@@ -418,6 +465,16 @@ std::string Analysis::build(int mtype_, int dtype_, int64_t nrows_, int64_t ncol
                 const Chunk &c = chunks[ci];
                 const BlockIn &B = blocks[c.blk];
                 char *dst = values.data() + (size_t)groups[c.group].val_off * 16;
+                if (group_perm[c.group]) {
+                    const int32_t *dp = colpos.data() + groups[c.group].col_off + c.woff;
+                    if (es == 4)
+                        pack_chunk_perm<uint32_t>((const uint32_t *)B.data, B.ld, c.ra, c.mc, B.n, dp, E, B.trans, (uint32_t *)dst);
+                    else if (es == 8)
+                        pack_chunk_perm<uint64_t>((const uint64_t *)B.data, B.ld, c.ra, c.mc, B.n, dp, E, B.trans, (uint64_t *)dst);
+                    else
+                        pack_chunk_perm<U16>((const U16 *)B.data, B.ld, c.ra, c.mc, B.n, dp, E, B.trans, (U16 *)dst);
+                    continue;
+                }
                 if (es == 4)
                     pack_chunk<uint32_t>((const uint32_t *)B.data, B.ld, c.ra, c.mc, B.n, c.woff, E, B.trans, (uint32_t *)dst);
                 else if (es == 8)
