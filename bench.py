@@ -48,7 +48,9 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to "
                     "rehearse the N > 1 code path on a single GPU)")
     ap.add_argument("--device", type=int, default=None, help="override LOCAL_RANK as the HIP device (rehearsal)")
-    ap.add_argument("--cold", action="store_true", help="also report a cold-cache figure")
+    ap.add_argument("--cold", action="store_true", default=True,
+                    help="also report a cold-cache figure (512 MiB flush before every launch); default on")
+    ap.add_argument("--no-cold", dest="cold", action="store_false")
     args = ap.parse_args()
 
     import numpy as np
