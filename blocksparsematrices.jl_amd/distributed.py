@@ -112,6 +112,8 @@ class RowPartitioned:
         self.world = dist.get_world_size(group) if dist is not None and dist.is_initialized() else 1
         self._ranges = None
         self._work = None
+        self._gbuf = None
+        self._sbuf = None
 
     def _exchange_ranges(self):
         """(own, touched) of every rank -- one small all_gather at first use."""
@@ -166,9 +168,18 @@ class RowPartitioned:
             for a, b, buf in recvs:
                 y[a - 1:b] += buf
         if self.gather and self.world > 1:
+            # one all-gather of the (padded) own slices instead of one broadcast per rank: a single
+            # collective whose per-peer messages (~n/N entries) use all xGMI links at once
             ranges = self._exchange_ranges()
+            maxlen = max(max(rh - rl + 1, 0) for rl, rh, _, _ in ranges)
+            if self._gbuf is None or self._gbuf.shape[0] != self.world * maxlen or self._gbuf.device != y.device:
+                self._gbuf = torch.empty(self.world * maxlen, dtype=y.dtype, device=y.device)
+                self._sbuf = torch.zeros(maxlen, dtype=y.dtype, device=y.device)
+            olo, ohi = self.own
+            if ohi >= olo:
+                self._sbuf[:ohi - olo + 1] = y[olo - 1:ohi]
+            dist.all_gather(list(self._gbuf.view(self.world, maxlen).unbind(0)), self._sbuf, group=self.group)
             for r, (rlo, rhi, _, _) in enumerate(ranges):
-                if rhi >= rlo:
-                    dist.broadcast(y[rlo - 1:rhi], src=dist.get_global_rank(self.group, r) if self.group else r,
-                                   group=self.group)
+                if r != self.rank and rhi >= rlo:
+                    y[rlo - 1:rhi] = self._gbuf[r * maxlen:r * maxlen + (rhi - rlo + 1)]
         return y
