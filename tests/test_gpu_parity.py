@@ -528,3 +528,22 @@ def test_row_partitioned_single_rank_path(torch_cuda, bsm, oracle):
     P.mul(y, x)
     torch.cuda.synchronize()
     assert relerr(y.cpu().numpy(), oracle_mul(oracle, p, N, p["x"], np.zeros(p["size"][0]))) < 1e-12
+
+
+def test_multi_rhs_padded_leading_dimension(torch_cuda, bsm, oracle):
+    # X / Y stored with ldx, ldy larger than the vector length (views into bigger Julia matrices)
+    torch = torch_cuda
+    p = bsm.synthetic.config2(n=8000, nblocks=400)
+    A = bsm.synthetic.build(p)
+    n, k = 8000, 6
+    rng = np.random.default_rng(71)
+    X = np.stack([rand_vec(rng, n, np.float64) for _ in range(k)], axis=1)
+    Xbig = torch.zeros((k, n + 7), dtype=torch.float64, device="cuda")
+    Ybig = torch.full((k, n + 13), float("nan"), dtype=torch.float64, device="cuda")
+    Xbig[:, :n] = torch.from_numpy(X.T.copy()).cuda()
+    Xd, Yd = Xbig.t()[:n], Ybig.t()[:n]          # column-major views: stride (1, n+7) / (1, n+13)
+    bsm.mul(Yd, A, Xd)
+    torch.cuda.synchronize()
+    ref = np.stack([oracle_mul(oracle, p, N, X[:, j].copy(), np.zeros(n)) for j in range(k)], axis=1)
+    assert relerr(Yd.cpu().numpy().ravel(), ref.ravel()) < 1e-12
+    assert torch.isnan(Ybig[:, n:]).all()           # the padding rows of Y are not touched
