@@ -406,8 +406,9 @@ std::string Analysis::build(int mtype_, int dtype_, int64_t nrows_, int64_t ncol
     exclusive_fwd = excl;
     // forced atomics: schedule like a non-exclusive matrix (large row groups are cut into several
     // workgroup items; their partial sums meet in y through atomics)
-    if (opt.accumulate == 1) exclusive_fwd = false;
+    if (opt.accumulate == 1 || opt.accumulate == 3) exclusive_fwd = false;
     const bool colored = (opt.accumulate == 2);
+    gather = (opt.accumulate == 3);
     std::vector<int32_t> group_color(groups.size(), 0);
     int32_t ncolors_fused = 1;
     if (colored) {
@@ -515,7 +516,7 @@ std::string Analysis::build(int mtype_, int dtype_, int64_t nrows_, int64_t ncol
     // symmetric operators: small items (1 or 2 waves) are ordered by LOCALITY (first row of their
     // group) so that the waves of one workgroup touch neighbouring y entries and can share an LDS
     // accumulation window; everything else largest-first
-    const bool use_window = sym && !colored && !exclusive_fwd && tun.lds_window;
+    const bool use_window = sym && !colored && !gather && !exclusive_fwd && tun.lds_window;
     auto locality = [&](const Item &it) -> int64_t {
         const Group &G = groups[it.group];
         return (G.rbase >= 0) ? G.rbase : rows[G.row_off];
@@ -710,6 +711,74 @@ std::string Analysis::build(int mtype_, int dtype_, int64_t nrows_, int64_t ncol
         std::memset(values.data(), 0, 16);
     }
 
+    // ---- gather mode: workspace slots + inverted indices ------------------------------------------
+    inv_ptr[0].clear();
+    inv_ptr[1].clear();
+    inv_idx[0].clear();
+    inv_idx[1].clear();
+    ws_fbase = ws_slots = 0;
+    if (gather) {
+        ws_fbase = (int64_t)cols.size();
+        int64_t nf = 0;
+        for (WaveWork &W : waves) {
+            if (W.work != WORK_PANEL || !W.lead) continue;
+            W.win_base = (int32_t)nf;  // forward slots of this workgroup item
+            nf += W.m;
+        }
+        ws_slots = ws_fbase + nf;
+        if (ws_slots + 8 > INT32_MAX) return "gather workspace exceeds int32 slots";
+        const int64_t ylen[2] = {nrows, ncols};
+        for (int k = 0; k < 2; k++) {  // k = 0: op N, k = 1: op T / C
+            // per-row contribution lists first (CSR), then re-laid out as ELL per 64-row tile:
+            // inv_ptr[t] = first 64-slot line of tile t, line l of a tile holds the l-th
+            // contribution of each of its 64 rows (-1 = none) -> coalesced index reads
+            std::vector<int64_t> ptr((size_t)ylen[k] + 1, 0);
+            auto visit = [&](auto &&emit) {
+                // transposed column sums: slot = position in the cols pool, ascending
+                for (const Group &G : groups) {
+                    const bool trn = (k == 1) || G.kind == KIND_OFF;
+                    if (!trn) continue;
+                    for (int64_t q = 0; q < G.width; q++) emit(cols[G.col_off + q], G.col_off + q);
+                }
+                // forward partial sums of every workgroup item
+                for (const WaveWork &W : waves) {
+                    if (W.work != WORK_PANEL || !W.lead) continue;
+                    const bool fwd = (k == 0) || W.first.kind == KIND_OFF;
+                    if (!fwd) continue;
+                    for (int i = 0; i < W.m; i++) {
+                        const int64_t r = (W.rbase >= 0) ? (int64_t)W.rbase + i : rows[W.row_off + i];
+                        emit(r, ws_fbase + W.win_base + i);
+                    }
+                }
+            };
+            visit([&](int64_t yi, int64_t) {
+                if (yi < ylen[k]) ptr[yi + 1]++;
+            });
+            for (int64_t j = 0; j < ylen[k]; j++) ptr[j + 1] += ptr[j];
+            std::vector<int32_t> csr((size_t)ptr[ylen[k]] + 1, 0);
+            {
+                std::vector<int64_t> fill(ptr.begin(), ptr.end() - 1);
+                visit([&](int64_t yi, int64_t slot) {
+                    if (yi < ylen[k]) csr[fill[yi]++] = (int32_t)slot;
+                });
+            }
+            const int64_t ntiles = (ylen[k] + 63) / 64;
+            std::vector<int64_t> &tp = inv_ptr[k];
+            tp.assign((size_t)ntiles + 1, 0);
+            for (int64_t t = 0; t < ntiles; t++) {
+                int64_t kmax = 0;
+                for (int64_t j = t * 64; j < std::min(ylen[k], (t + 1) * 64); j++)
+                    kmax = std::max(kmax, ptr[j + 1] - ptr[j]);
+                tp[t + 1] = tp[t] + kmax;
+            }
+            if (tp[ntiles] * 64 + 64 > INT32_MAX) return "gather index exceeds int32";
+            inv_idx[k].assign((size_t)tp[ntiles] * 64 + 64, -1);
+            for (int64_t t = 0; t < ntiles; t++)
+                for (int64_t j = t * 64; j < std::min(ylen[k], (t + 1) * 64); j++)
+                    for (int64_t c = ptr[j]; c < ptr[j + 1]; c++)
+                        inv_idx[k][(size_t)(tp[t] + (c - ptr[j])) * 64 + (size_t)(j - t * 64)] = csr[c];
+        }
+    }
     lap("schedule");
     // ---- colouring (reference bookkeeping) ---------------------------------------------------
     for (auto &c : colors) c.clear();

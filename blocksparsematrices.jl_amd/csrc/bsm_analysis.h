@@ -64,7 +64,7 @@ struct Tunables {
 struct AnalysisOptions {
     int scheduler = 0;   // 0 serial, 1 dynamic (colour like the reference)
     int validate = 1;
-    int accumulate = 0;  // 0 auto, 1 atomic, 2 coloured launches (bitwise reproducible)
+    int accumulate = 0;  // 0 auto, 1 atomic, 2 coloured launches, 3 gather (both bitwise reproducible)
     int64_t own_lo = 0, own_hi = 0;  // 1-based inclusive, 0,0 = all rows
 };
 
@@ -99,6 +99,14 @@ class Analysis {
     // coloured mode: workgroups [color_wg_ptr[c], color_wg_ptr[c+1]) form launch c; the row groups
     // of one launch touch pairwise disjoint y entries (rows and columns), for every op
     std::vector<int64_t> color_wg_ptr;
+    // gather mode: workspace slots.  Transposed column sum of merged panel column q of a group:
+    // slot col_off + q (its position in the cols pool); forward partial sums of a workgroup item:
+    // slots ws_fbase + WaveWork::win_base + row.  inv_ptr/inv_idx[k]: CSR over the y entries of
+    // op N (k = 0) and op T / C (k = 1) listing the slots that contribute, in ascending order.
+    bool gather = false;
+    int64_t ws_fbase = 0, ws_slots = 0;
+    std::vector<int64_t> inv_ptr[2];
+    std::vector<int32_t> inv_idx[2];
 
     // Builds everything.  Returns "" on success, else an error message.
     std::string build(int mtype, int dtype, int64_t nrows, int64_t ncols,

@@ -26,6 +26,7 @@ struct bsm_matrix_s {
     DeviceImage img_t;
     // device staging buffers of the BSM_MEM_HOST path, kept between calls (grow-only); a second
     // concurrent host call on the same handle falls back to temporary buffers
+    std::mutex gather_mu;  // the gather workspace admits one product in flight per handle
     std::mutex host_mu;
     void *stage_x = nullptr, *stage_y = nullptr;
     size_t stage_x_bytes = 0, stage_y_bytes = 0;
@@ -130,7 +131,8 @@ int read_options(const bsm_options *opts, bsm_options &o) {
             return fail(BSM_ERR_INVALID, "bsm_options.struct_size mismatch (call bsm_options_default)");
         o = *opts;
     }
-    if (o.accumulate != BSM_ACC_AUTO && o.accumulate != BSM_ACC_ATOMIC && o.accumulate != BSM_ACC_COLORED)
+    if (o.accumulate != BSM_ACC_AUTO && o.accumulate != BSM_ACC_ATOMIC && o.accumulate != BSM_ACC_COLORED &&
+        o.accumulate != BSM_ACC_GATHER)
         return fail(BSM_ERR_INVALID, "unknown accumulate mode");
     if (o.own_lo < 0 || o.own_hi < 0 || (o.own_hi > 0 && o.own_hi < o.own_lo))
         return fail(BSM_ERR_INVALID, "bad own_lo/own_hi");
@@ -147,7 +149,8 @@ template <typename V> hipError_t upload(const V &v, void **dptr, long long &tota
 }
 
 void free_image(DeviceImage &img) {
-    for (void **p : {&img.d_values, &img.d_rows, &img.d_cols, &img.d_waves}) {
+    for (void **p : {&img.d_values, &img.d_rows, &img.d_cols, &img.d_waves, &img.d_ws, &img.d_inv_ptr[0],
+                     &img.d_inv_ptr[1], &img.d_inv_idx[0], &img.d_inv_idx[1]}) {
         if (*p) (void)hipFree(*p);
         *p = nullptr;
     }
@@ -169,6 +172,9 @@ void fill_image(const Analysis &an, const bsm_options &o, bool use_own, DeviceIm
     img.color_wg_ptr.assign(an.color_wg_ptr.begin(), an.color_wg_ptr.end());
     img.device_bytes = (long long)(an.values.size() + an.rows.size() * 4 + an.cols.size() * 4 +
                                    an.waves.size() * sizeof(WaveWork));
+    if (an.gather)
+        img.device_bytes += (long long)((an.ws_slots + 8) * an.es + (an.inv_ptr[0].size() + an.inv_ptr[1].size()) * 8 +
+                                        (an.inv_idx[0].size() + an.inv_idx[1].size()) * 4);
 }
 
 hipError_t upload_image(Analysis &an, DeviceImage &img, int dev) {
@@ -178,6 +184,19 @@ hipError_t upload_image(Analysis &an, DeviceImage &img, int dev) {
     if (e == hipSuccess) e = upload(an.rows, &img.d_rows, total);
     if (e == hipSuccess) e = upload(an.cols, &img.d_cols, total);
     if (e == hipSuccess) e = upload(an.waves, &img.d_waves, total);
+    if (e == hipSuccess && an.gather) {
+        img.ws_fbase = an.ws_fbase;
+        for (int k = 0; k < 2 && e == hipSuccess; k++) {
+            e = upload(an.inv_ptr[k], &img.d_inv_ptr[k], total);
+            if (e == hipSuccess) e = upload(an.inv_idx[k], &img.d_inv_idx[k], total);
+        }
+        if (e == hipSuccess) {
+            const size_t wsb = (size_t)(an.ws_slots + 8) * (size_t)an.es;
+            e = hipMalloc(&img.d_ws, wsb);
+            if (e == hipSuccess) e = hipMemset(img.d_ws, 0, wsb);
+            total += (long long)wsb;
+        }
+    }
     if (e == hipSuccess) an.values.release();  // packed host copy no longer needed
     return e;
 }
@@ -447,8 +466,12 @@ extern "C" int bsm_mul(bsm_matrix_t A, int op, const void *x, void *y, const voi
     hipError_t e = guard.enter(img.device);
     if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
     hipStream_t st = (hipStream_t)stream;
+    // gather mode: the workspace belongs to the handle, so the enqueue is serialised; a caller that
+    // races on the same handle from another thread gets the atomic path for that call
+    std::unique_lock<std::mutex> glock(A->gather_mu, std::defer_lock);
+    const bool use_gather = img.d_ws != nullptr && glock.try_lock();
     if (memspace == BSM_MEM_DEVICE) {
-        e = launch_mul(img, opT, conj, x, y, alpha, beta, beta_strong_zero, st);
+        e = launch_mul(img, opT, conj, x, y, alpha, beta, beta_strong_zero, st, use_gather);
         if (e != hipSuccess) return hip_fail(e, "kernel launch");
         return BSM_OK;
     }
@@ -463,7 +486,7 @@ extern "C" int bsm_mul(bsm_matrix_t A, int op, const void *x, void *y, const voi
     if (e == hipSuccess) e = hipMemcpyAsync(dx, x, xlen * es, hipMemcpyHostToDevice, st);
     if (e == hipSuccess && !beta_strong_zero)
         e = hipMemcpyAsync(dy, y, ylen * es, hipMemcpyHostToDevice, st);
-    if (e == hipSuccess) e = launch_mul(img, opT, conj, dx, dy, alpha, beta, beta_strong_zero, st);
+    if (e == hipSuccess) e = launch_mul(img, opT, conj, dx, dy, alpha, beta, beta_strong_zero, st, use_gather);
     if (e == hipSuccess) e = hipMemcpyAsync(y, dy, ylen * es, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) return hip_fail(e, "host-staged mul");
@@ -575,6 +598,10 @@ extern "C" int bsm_get_image(bsm_matrix_t A, int which, void *out, int64_t *nbyt
         case 1: src = an.rows.data(); bytes = an.rows.size() * 4; break;
         case 2: src = an.cols.data(); bytes = an.cols.size() * 4; break;
         case 3: src = an.waves.data(); bytes = an.waves.size() * sizeof(WaveWork); break;
+        case 4: src = an.inv_ptr[0].data(); bytes = an.inv_ptr[0].size() * 8; break;
+        case 5: src = an.inv_idx[0].data(); bytes = an.inv_idx[0].size() * 4; break;
+        case 6: src = an.inv_ptr[1].data(); bytes = an.inv_ptr[1].size() * 8; break;
+        case 7: src = an.inv_idx[1].data(); bytes = an.inv_idx[1].size() * 4; break;
         default: return fail(BSM_ERR_INVALID, "unknown image array");
     }
     if (out) {

@@ -19,13 +19,19 @@ struct DeviceImage {
     bool has_off = false;  // SymmetricBlockMatrix off-diagonal pieces present
     long long device_bytes = 0;
     std::vector<long long> color_wg_ptr;  // non-empty: coloured launches, plain read-modify-write
+    // gather mode (BSM_ACC_GATHER): workspace + inverted indices for op N [0] and op T / C [1]
+    void *d_ws = nullptr;
+    void *d_inv_ptr[2] = {nullptr, nullptr}, *d_inv_idx[2] = {nullptr, nullptr};
+    long long ws_fbase = 0;
 };
 
 // Enqueues y = alpha*op(A)*x + beta*y on `stream`.  x, y device pointers.  No allocation,
 // no synchronisation (graph-capturable).
 // opT: apply the transposed operator of the image; conj: conjugate every stored entry.
+// use_gather: take the two-launch gather path (only if the image has a workspace).
 hipError_t launch_mul(const DeviceImage &img, bool opT, bool conj, const void *x, void *y,
-                      const void *alpha, const void *beta, int strong_zero, hipStream_t stream);
+                      const void *alpha, const void *beta, int strong_zero, hipStream_t stream,
+                      bool use_gather = false);
 
 // nrhs right-hand sides: X (ldx) and Y (ldy) column-major; A is streamed once per batch of <= 8.
 hipError_t launch_mul_multi(const DeviceImage &img, bool opT, bool conj, long long nrhs, const void *x,

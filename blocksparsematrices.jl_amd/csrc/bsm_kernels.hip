@@ -198,7 +198,8 @@ constexpr int FLAG_STRONG_ZERO = 1;
 constexpr int FLAG_DIRECT = 2;
 constexpr int FLAG_CONJ = 4;
 constexpr int FLAG_OPT = 8;
-constexpr int FLAG_RMW = 16;  // coloured launch: conflict-free by construction, plain read-modify-write
+constexpr int FLAG_RMW = 16;
+constexpr int FLAG_GATHER = 32;  // contributions are stored in the workspace, gather_kernel sums them  // coloured launch: conflict-free by construction, plain read-modify-write
 
 // ----------------------------------------------------------------------------------------
 // descriptors: fetched as whole 16-byte words through a wave-uniform address (scalar loads),
@@ -257,7 +258,8 @@ template <typename T, int L, int P, bool FWD, bool TRN>
 __device__ __forceinline__ T run_panel(const WaveD &wd, const uint4 *__restrict__ values,
                                        const int *__restrict__ rows, const int *__restrict__ cols,
                                        const T *__restrict__ x, T *__restrict__ y, T alpha,
-                                       int flags, int lane, T *xs, T *vs, T *win, int win_n) {
+                                       int flags, int lane, T *xs, T *vs, T *win, int win_n,
+                                       T *__restrict__ ws) {
     constexpr int E = TT<T>::E;
     constexpr int G = 64 / P;
     constexpr int V = L * E;
@@ -369,6 +371,10 @@ __device__ __forceinline__ T run_panel(const WaveD &wd, const uint4 *__restrict_
                             const int c = k * 64 + lane;
                             const int w = sb * E + c;
                             if (c < (slot + 1) * NC && w < ncols) {
+                                if (flags & FLAG_GATHER) {  // one plain, coalesced store per column sum
+                                    ws[col_off + w] = vs[c];
+                                    continue;
+                                }
                                 const int yi = col_index(w);
                                 const T val = mul(alpha, vs[c]);
                                 const unsigned wi = (unsigned)(yi - wd.win_base);
@@ -401,7 +407,7 @@ template <typename T, int L, bool FWD, bool TRN>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((!TRN && sizeof(T) == 8) ? 6 : 4)))
     panel_kernel(const WaveWork *__restrict__ waves, const uint4 *__restrict__ values, const int *__restrict__ rows,
                  const int *__restrict__ cols, const T *__restrict__ x, T *__restrict__ y, T alpha,
-                 T beta, int flags, unsigned wg_base) {
+                 T beta, int flags, unsigned wg_base, T *__restrict__ ws, long long ws_fbase) {
     constexpr int E = TT<T>::E;
     constexpr int XS = x_chunk_cols<T>();              // staged x slice per wave
     constexpr int VS = 8 * L * E;                      // transposed sums of one iteration
@@ -427,13 +433,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((!TRN 
     T u = zero_of(T{});
     if (work == WORK_PANEL) {
         if (m <= 8)
-            u = run_panel<T, L, 8, FWD, TRN>(wd, values, rows, cols, x, y, alpha, flags, lane, xs[wave], vs[wave], win, win_n);
+            u = run_panel<T, L, 8, FWD, TRN>(wd, values, rows, cols, x, y, alpha, flags, lane, xs[wave], vs[wave], win, win_n, ws);
         else if (m <= 16)
-            u = run_panel<T, L, 16, FWD, TRN>(wd, values, rows, cols, x, y, alpha, flags, lane, xs[wave], vs[wave], win, win_n);
+            u = run_panel<T, L, 16, FWD, TRN>(wd, values, rows, cols, x, y, alpha, flags, lane, xs[wave], vs[wave], win, win_n, ws);
         else if (m <= 32)
-            u = run_panel<T, L, 32, FWD, TRN>(wd, values, rows, cols, x, y, alpha, flags, lane, xs[wave], vs[wave], win, win_n);
+            u = run_panel<T, L, 32, FWD, TRN>(wd, values, rows, cols, x, y, alpha, flags, lane, xs[wave], vs[wave], win, win_n, ws);
         else
-            u = run_panel<T, L, 64, FWD, TRN>(wd, values, rows, cols, x, y, alpha, flags, lane, xs[wave], vs[wave], win, win_n);
+            u = run_panel<T, L, 64, FWD, TRN>(wd, values, rows, cols, x, y, alpha, flags, lane, xs[wave], vs[wave], win, win_n, ws);
     }
     const bool direct = (flags & FLAG_DIRECT) != 0;
     const bool sz = (flags & FLAG_STRONG_ZERO) != 0;
@@ -444,7 +450,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((!TRN 
         }
         if (work == WORK_PANEL && wd.lead) {
             for (int k = 1; k < wd.grp; ++k) u = add(u, red[wave + k][lane]);
-            if (lane < m) {
+            if (flags & FLAG_GATHER) {
+                // forward partial sums of this workgroup item: slots ws_fbase + win_base + row
+                const bool fwd_on = !(flags & FLAG_OPT) || wd.first.kind == KIND_OFF;
+                if (lane < m && fwd_on) ws[ws_fbase + wd.win_base + lane] = u;
+            } else if (lane < m) {
                 const int yi = (wd.rbase >= 0) ? wd.rbase + lane : rows[wd.row_off + lane];
                 const T val = mul(alpha, u);
                 const unsigned wi = (unsigned)(yi - wd.win_base);
@@ -708,6 +718,36 @@ __global__ void __launch_bounds__(256) scale_kernel(T *__restrict__ y, long long
     for (; i < hi; i += stride) yc[i] = strong_zero ? zero_of(T{}) : mul(beta, yc[i]);
 }
 
+// second launch of the gather mode: y[j] = beta*y[j] + alpha * (sum of the workspace slots that
+// contribute to j, in their fixed ascending order).  Outside the owned range only rows that
+// receive contributions are touched (and not scaled), like the atomic path.
+template <typename T>
+__global__ void __launch_bounds__(256)
+    gather_kernel(T *__restrict__ y, long long ylen, long long own_lo, long long own_hi,
+                  const long long *__restrict__ ptr, const int *__restrict__ idx, const T *__restrict__ ws,
+                  T alpha, T beta, int strong_zero) {
+    const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= ylen) return;
+    // ELL per 64-row tile: line l holds the l-th contribution of each row of the tile (-1: none)
+    const long long t = j >> 6;
+    const int lane = (int)(j & 63);
+    const long long a = ptr[t], b = ptr[t + 1];
+    T s = zero_of(T{});
+    bool any = false;
+    for (long long l = a; l < b; ++l) {
+        const int slot = idx[l * 64 + lane];
+        if (slot >= 0) {
+            s = add(s, ws[slot]);
+            any = true;
+        }
+    }
+    const T val = mul(alpha, s);
+    if (j >= own_lo && j < own_hi)
+        y[j] = strong_zero ? val : madd(val, beta, y[j]);
+    else if (any)
+        y[j] = add(y[j], val);
+}
+
 // ----------------------------------------------------------------------------------------
 // launchers
 // ----------------------------------------------------------------------------------------
@@ -730,7 +770,7 @@ template <> bool is_one(c128 v) { return v.re == 1.0 && v.im == 0.0; }
 template <typename T, int L>
 static hipError_t launch_typed(const DeviceImage &img, bool opT, bool conj, const void *x, void *y,
                                const void *alpha_p, const void *beta_p, int strong_zero,
-                               hipStream_t stream) {
+                               hipStream_t stream, bool use_gather = false) {
     const T alpha = load_scalar<T>(alpha_p, 1.0);
     const T beta = load_scalar<T>(beta_p, 0.0);
     int flags = 0;
@@ -751,7 +791,7 @@ static hipError_t launch_typed(const DeviceImage &img, bool opT, bool conj, cons
         flags |= FLAG_DIRECT;
         if (img.nwg_total > 0)
             hipLaunchKernelGGL((panel_kernel<T, L, true, false>), dim3((unsigned)img.nwg_total), block, 0,
-                               stream, waves, values, rows, cols, xd, yd, alpha, beta, flags, 0u);
+                               stream, waves, values, rows, cols, xd, yd, alpha, beta, flags, 0u, (T *)nullptr, 0LL);
         return hipGetLastError();
     }
     // accumulate mode: y .*= beta over the owned range, then hardware atomics
@@ -761,7 +801,10 @@ static hipError_t launch_typed(const DeviceImage &img, bool opT, bool conj, cons
         lo = img.own_lo;
         hi = img.own_hi;
     }
-    if (hi > lo && (strong_zero || !is_one(beta))) {
+    const bool gather = use_gather && img.d_ws != nullptr;
+    T *ws = gather ? (T *)img.d_ws : (T *)nullptr;
+    if (gather) flags |= FLAG_GATHER;
+    if (!gather && hi > lo && (strong_zero || !is_one(beta))) {
         long long nblk = (hi - lo + 255) / 256;
         if (nblk > 2048) nblk = 2048;
         hipLaunchKernelGGL((scale_kernel<T>), dim3((unsigned)nblk), block, 0, stream, yd, 0LL, lo, hi, beta,
@@ -781,18 +824,25 @@ static hipError_t launch_typed(const DeviceImage &img, bool opT, bool conj, cons
         if (!opT) {
             if (img.has_off)
                 hipLaunchKernelGGL((panel_kernel<T, L, true, true>), grid, block, 0, stream, waves,
-                                   values, rows, cols, xd, yd, alpha, beta, flags, wg_base);
+                                   values, rows, cols, xd, yd, alpha, beta, flags, wg_base, ws, img.ws_fbase);
             else
                 hipLaunchKernelGGL((panel_kernel<T, L, true, false>), grid, block, 0, stream, waves,
-                                   values, rows, cols, xd, yd, alpha, beta, flags, wg_base);
+                                   values, rows, cols, xd, yd, alpha, beta, flags, wg_base, ws, img.ws_fbase);
         } else {
             if (img.has_off)
                 hipLaunchKernelGGL((panel_kernel<T, L, true, true>), grid, block, 0, stream, waves,
-                                   values, rows, cols, xd, yd, alpha, beta, flags, wg_base);
+                                   values, rows, cols, xd, yd, alpha, beta, flags, wg_base, ws, img.ws_fbase);
             else
                 hipLaunchKernelGGL((panel_kernel<T, L, false, true>), grid, block, 0, stream, waves,
-                                   values, rows, cols, xd, yd, alpha, beta, flags, wg_base);
+                                   values, rows, cols, xd, yd, alpha, beta, flags, wg_base, ws, img.ws_fbase);
         }
+    }
+    if (gather && ylen > 0) {
+        const int k = opT ? 1 : 0;
+        const long long nblk = (ylen + 255) / 256;
+        hipLaunchKernelGGL((gather_kernel<T>), dim3((unsigned)nblk), block, 0, stream, yd, ylen, lo, hi,
+                           (const long long *)img.d_inv_ptr[k], (const int *)img.d_inv_idx[k], (const T *)ws,
+                           alpha, beta, strong_zero);
     }
     return hipGetLastError();
 }
@@ -892,12 +942,13 @@ hipError_t launch_mul_multi(const DeviceImage &img, bool opT, bool conj, long lo
 }
 
 hipError_t launch_mul(const DeviceImage &img, bool opT, bool conj, const void *x, void *y,
-                      const void *alpha, const void *beta, int strong_zero, hipStream_t stream) {
+                      const void *alpha, const void *beta, int strong_zero, hipStream_t stream,
+                      bool use_gather) {
     switch (img.dtype) {
-        case 0: return launch_typed<float, 8>(img, opT, conj, x, y, alpha, beta, strong_zero, stream);
-        case 1: return launch_typed<double, 8>(img, opT, conj, x, y, alpha, beta, strong_zero, stream);
-        case 2: return launch_typed<c64, 8>(img, opT, conj, x, y, alpha, beta, strong_zero, stream);
-        case 3: return launch_typed<c128, 8>(img, opT, conj, x, y, alpha, beta, strong_zero, stream);
+        case 0: return launch_typed<float, 8>(img, opT, conj, x, y, alpha, beta, strong_zero, stream, use_gather);
+        case 1: return launch_typed<double, 8>(img, opT, conj, x, y, alpha, beta, strong_zero, stream, use_gather);
+        case 2: return launch_typed<c64, 8>(img, opT, conj, x, y, alpha, beta, strong_zero, stream, use_gather);
+        case 3: return launch_typed<c128, 8>(img, opT, conj, x, y, alpha, beta, strong_zero, stream, use_gather);
     }
     return hipErrorInvalidValue;
 }

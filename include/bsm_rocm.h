@@ -56,8 +56,14 @@ typedef enum { BSM_SCHED_SERIAL = 0, BSM_SCHED_DYNAMIC = 1 } bsm_scheduler;
 typedef enum {
     BSM_ACC_AUTO = 0,    /* exclusive direct stores when provably conflict-free, else atomics */
     BSM_ACC_ATOMIC = 1,  /* hardware fp atomics into y, blocks ordered by colour class */
-    BSM_ACC_COLORED = 2  /* one launch per colour class, plain read-modify-write: bitwise
+    BSM_ACC_COLORED = 2, /* one launch per colour class, plain read-modify-write: bitwise
                             reproducible run to run (the reference's own scheme) */
+    BSM_ACC_GATHER = 3   /* no atomics at all: every block contribution is stored once in a
+                            workspace owned by the handle and a second launch sums, per y entry,
+                            its contributions in a fixed order (and applies alpha, beta): bitwise
+                            reproducible, two launches.  The workspace makes products on ONE handle
+                            stream-ordered: at most one bsm_mul in flight per handle (a concurrent
+                            call falls back to atomics).  Single right-hand side only. */
 } bsm_accumulate;
 
 #define BSM_DEVICE_CURRENT (-1)
@@ -183,7 +189,8 @@ int bsm_stats(bsm_matrix_t A, bsm_stats_t *out);
 
 /* Debug / test hook: copies one array of the packed device image (host copy) out.
  * which: 0 values (bytes), 1 rows (int32), 2 cols (int32), 3 waves (64-byte records;
- * layout in blocksparsematrices.jl_amd/csrc/bsm_layout.h).
+ * layout in blocksparsematrices.jl_amd/csrc/bsm_layout.h); gather handles also 4 / 5 = row
+ * pointers (int64) / workspace slots (int32) of the op-N inverted index and 6 / 7 for op T.
  * Add 16 to `which` for the arrays of the transposed image (bsm_options.transpose_image).
  * Only available on analysis-only handles (BSM_DEVICE_NONE), which keep the host copy.
  * Call with out == NULL to obtain the size in bytes. */

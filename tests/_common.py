@@ -172,6 +172,22 @@ def get_image(A, timage=False):
     return out
 
 
+def get_inverted_index(A, timage=False):
+    """gather handles: ((ptrN, idxN), (ptrT, idxT)) or None"""
+    from bsm_amd import _lib as L
+    out = []
+    for which, dt in ((4, np.int64), (5, np.int32), (6, np.int64), (7, np.int32)):
+        which += 16 if timage else 0
+        n = C.c_int64(0)
+        L.check(L.lib().bsm_get_image(A._h.ptr, which, None, C.byref(n)))
+        buf = np.zeros(max(n.value, 1), dtype=np.uint8)
+        L.check(L.lib().bsm_get_image(A._h.ptr, which, buf.ctypes.data, C.byref(n)))
+        out.append(buf[:n.value].view(dt))
+    if len(out[0]) == 0:
+        return None
+    return (out[0], out[1]), (out[2], out[3])
+
+
 def _image_exclusive(waves, rows, ylen):
     """every y row produced by at most one lead wave group (the library's exclusivity proof)"""
     seen = np.zeros(ylen, dtype=np.int32)
@@ -201,7 +217,14 @@ def interpret_image(A, op, x, y0, alpha=1, beta=0, strong=True, timage=False):
         opT = op != N
         direct = (not opT) and st["exclusive"] == 1
     y = np.array(y0, copy=True)
-    if not direct:
+    inv = get_inverted_index(A, timage)
+    gather = inv is not None
+    if gather:
+        assert not direct
+        ws = np.full(len(cols) + int(np.sum(waves["m"][(waves["work"] == WORK_PANEL) & (waves["lead"] == 1)])) + 8,
+                     np.nan, dtype=dt)  # NaN: reading a slot nobody wrote must show
+        fbase = len(cols) if np.any(waves["work"] == WORK_PANEL) else 0
+    elif not direct:
         y[:] = 0 if strong else beta * y
     assert len(waves) % 4 == 0
     pw = waves[waves["work"] == WORK_PANEL]
@@ -244,7 +267,10 @@ def interpret_image(A, op, x, y0, alpha=1, beta=0, strong=True, timage=False):
                 if (not opT) or kind == KIND_OFF:
                     u += B @ x[cidx]
                 if opT or kind == KIND_OFF:
-                    np.add.at(y, cidx, alpha * (B.T @ x[ridx]))
+                    if gather:  # one store per column sum, slot = position in the cols pool
+                        ws[int(P["col_off"]):int(P["col_off"]) + nc] = B.T @ x[ridx]
+                    else:
+                        np.add.at(y, cidx, alpha * (B.T @ x[ridx]))
             us[w] = (u, ridx, int(W["grp"]), int(W["lead"]))
         for w in range(4):
             if us[w] is None or not us[w][3] or not fwd_kernel:
@@ -255,8 +281,23 @@ def interpret_image(A, op, x, y0, alpha=1, beta=0, strong=True, timage=False):
                 assert us[w + k] is not None and not us[w + k][3]
                 assert np.array_equal(us[w + k][1], ridx)
                 u += us[w + k][0]
-            if direct:
+            if gather:
+                lead = waves[wg * 4 + w]
+                if (not opT) or int(lead["first"]["kind"]) == KIND_OFF:
+                    ws[fbase + int(lead["win_base"]):fbase + int(lead["win_base"]) + len(ridx)] = u
+            elif direct:
                 y[ridx] = alpha * u if strong else beta * y[ridx] + alpha * u
             else:
                 np.add.at(y, ridx, alpha * u)
+    if gather:  # second launch: fixed-order sums per y entry
+        ptr, idx = inv[1] if opT else inv[0]  # ELL per 64-row tile, -1 = no contribution
+        assert len(ptr) == (len(y) + 63) // 64 + 1
+        sums = np.zeros(len(y), dtype=dt)
+        for j in range(len(y)):
+            t, lane = divmod(j, 64)
+            sl = idx[ptr[t] * 64 + lane:ptr[t + 1] * 64 + lane:64]
+            sl = sl[sl >= 0]
+            sums[j] = ws[sl].sum() if len(sl) else 0
+        assert not np.any(np.isnan(sums)), "a contributing workspace slot was never written"
+        y = alpha * sums if strong else beta * y + alpha * sums
     return y

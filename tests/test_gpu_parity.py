@@ -547,3 +547,32 @@ def test_multi_rhs_padded_leading_dimension(torch_cuda, bsm, oracle):
     ref = np.stack([oracle_mul(oracle, p, N, X[:, j].copy(), np.zeros(n)) for j in range(k)], axis=1)
     assert relerr(Yd.cpu().numpy().ravel(), ref.ravel()) < 1e-12
     assert torch.isnan(Ybig[:, n:]).all()           # the padding rows of Y are not touched
+
+
+# ---- gather accumulation: no atomics, fixed-order sums, bitwise reproducible --------------------------------
+@pytest.mark.parametrize("key", ["cuboid", "sphere"])
+def test_gather_mode_parity_and_determinism(torch_cuda, bsm, oracle, key):
+    p = fixture_problem(key)
+    A = bsm.synthetic.build(p, accumulate="gather")
+    check_all(torch_cuda, bsm, oracle, p, A, np.complex128)
+    rng = np.random.default_rng(81)
+    n = p["size"][0]
+    x, y0 = rand_vec(rng, n, np.complex128), rand_vec(rng, n, np.complex128)
+    for op in OPS:
+        first = gpu_mul(torch_cuda, bsm, A, op, x, y0, 0.5, 2.0, False)
+        for _ in range(3):
+            assert np.array_equal(first, gpu_mul(torch_cuda, bsm, A, op, x, y0, 0.5, 2.0, False))
+
+
+def test_gather_mode_other_types(torch_cuda, bsm, oracle):
+    r = bsm.synthetic.config3(nseg=150)
+    check_all(torch_cuda, bsm, oracle, r, bsm.synthetic.build(r, accumulate="gather"), np.float64, host_too=False)
+    q = bsm.synthetic.config1()
+    check_all(torch_cuda, bsm, oracle, q, bsm.synthetic.build(q, accumulate="gather"), np.float64, host_too=False)
+    v = bsm.synthetic.config2(n=20000, nblocks=1000, dtype=np.float32)
+    check_all(torch_cuda, bsm, oracle, v, bsm.synthetic.build(v, accumulate="gather", transpose_image=True),
+              np.float32, host_too=False)
+    c5 = bsm.synthetic.config5(n=60000)
+    A = bsm.synthetic.build(c5, accumulate="gather")
+    check_all(torch_cuda, bsm, oracle, c5, A, np.float64, host_too=False)
+    _check_multi(torch_cuda, bsm, oracle, c5, A, np.float64, nrhs_list=(5,), ops=[N])  # multi-RHS: atomic path

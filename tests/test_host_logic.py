@@ -347,6 +347,21 @@ def test_lds_window_descriptors_cover_their_workgroup(bsm):
     assert not np.any(get_image(B)[3]["win_span8"])
 
 
+@pytest.mark.parametrize("key", ["cuboid", "sphere"])
+def test_gather_mode_image_matches_oracle(bsm, oracle, key):
+    # BSM_ACC_GATHER: contributions are stored in workspace slots, an inverted index sums them
+    p = fixture_problem(key)
+    A = bsm.synthetic.build(p, device=NODEV, accumulate="gather")
+    assert A.stats()["exclusive"] == 0
+    _check_image(bsm, oracle, p, A, np.complex128)
+    q = bsm.synthetic.config1()
+    _check_image(bsm, oracle, q, bsm.synthetic.build(q, device=NODEV, accumulate="gather"), np.float64)
+    r = bsm.synthetic.config5(n=3000, lo=1, hi=90, halfband=3)
+    _check_image(bsm, oracle, r, bsm.synthetic.build(r, device=NODEV, accumulate="gather"), np.float64)
+    v = bsm.synthetic.config2(n=3000, nblocks=200)
+    _check_image(bsm, oracle, v, bsm.synthetic.build(v, device=NODEV, accumulate="gather"), np.float64)
+
+
 def test_own_range_limits_scale_work(bsm):
     p = bsm.synthetic.config2(n=2000, nblocks=40)
     A = bsm.VariableBlockCompressedRowStorage(p["blocks"], p["rowstart"], p["colstart"], p["size"],
