@@ -117,11 +117,13 @@ struct Chunk {
     int64_t woff;   // first column of this chunk inside the group's merged panel
 };
 
-// A row group = every chunk (of equal kind) living on the same y rows.  Its chunks are
-// concatenated column-wise into ONE merged panel, so a wave always streams a single piece.
+// A row group = every chunk living on the same y rows (for a symmetric operator the diagonal block
+// of a row set and its off-diagonal blocks share one group: the kind is kept per COLUMN).  Its
+// chunks are concatenated column-wise into ONE merged panel, so a wave always streams a single piece.
 struct Group {
     int32_t mc = 0;
-    int32_t kind = 0;
+    int32_t kind = 0;      // kind of its non-diagonal columns (KIND_OFF if it has any, else the chunks' kind)
+    bool has_off = false, has_diag = false;
     int32_t rbase = -1;    // 0-based first row when contiguous
     int32_t row_off = -1;  // rows pool offset when indexed
     std::vector<int32_t> chunks;
@@ -293,12 +295,15 @@ std::string Analysis::build(int mtype_, int dtype_, int64_t nrows_, int64_t ncol
                 h = ((uint64_t)rbase * 0x9E3779B97F4A7C15ull) ^ ((uint64_t)mc << 56) ^ 0x51ull;
             else
                 h = hash_list(B.ridx + ra, mc);
-            h ^= (uint64_t)B.kind * 0xD6E8FEB86659FD93ull;
+            // plain blocks never share a group with symmetric ones; DIAG and OFF chunks of the same
+            // rows do (per-column kinds)
+            const int gkind = (B.kind == KIND_PLAIN) ? KIND_PLAIN : KIND_OFF;
+            h ^= (uint64_t)gkind * 0xD6E8FEB86659FD93ull;
             int64_t gid = -1;
             auto &cand = gmap[h];
             for (int64_t g : cand) {
                 const Group &G = groups[g];
-                if (G.mc != mc || G.kind != B.kind) continue;
+                if (G.mc != mc || ((G.kind == KIND_PLAIN) != (B.kind == KIND_PLAIN))) continue;
                 if (rcontig) {
                     if (G.rbase == rbase) gid = g;
                 } else if (G.rbase < 0 &&
@@ -329,6 +334,12 @@ std::string Analysis::build(int mtype_, int dtype_, int64_t nrows_, int64_t ncol
             c.group = gid;
             c.woff = groups[gid].width;
             groups[gid].width += B.n;
+            if (B.kind == KIND_OFF) {
+                groups[gid].has_off = true;
+                groups[gid].kind = KIND_OFF;
+            } else if (B.kind == KIND_DIAG) {
+                groups[gid].has_diag = true;
+            }
             groups[gid].chunks.push_back((int32_t)chunks.size());
             chunks.push_back(c);
         }
@@ -347,8 +358,10 @@ std::string Analysis::build(int mtype_, int dtype_, int64_t nrows_, int64_t ncol
     // index: neighbouring lanes then gather neighbouring x entries and emit neighbouring y
     // entries, and scattered index lists (BEM near-field panels) collapse into contiguous runs.
     std::vector<int32_t> colpos;
+    std::vector<uint8_t> ckind;  // kind of every merged panel column (parallel to cols)
     std::vector<uint8_t> group_perm(groups.size(), 0);
     colpos.reserve(cols.capacity());
+    ckind.reserve(cols.capacity());
     {
         std::vector<int32_t> ord;
         size_t gi = 0;
@@ -358,10 +371,13 @@ std::string Analysis::build(int mtype_, int dtype_, int64_t nrows_, int64_t ncol
             G.col_off = (int64_t)cols.size();
             for (int32_t ci : G.chunks) {
                 const BlockIn &B = blocks[chunks[ci].blk];
-                for (int64_t k = 0; k < B.n; k++)
+                for (int64_t k = 0; k < B.n; k++) {
                     cols.push_back((int32_t)((B.cidx ? B.cidx[k] : B.c0 + k) - 1));
+                    ckind.push_back((uint8_t)B.kind);
+                }
             }
             int32_t *gc = cols.data() + G.col_off;
+            uint8_t *gk = ckind.data() + G.col_off;
             colpos.resize(cols.size());
             int32_t *gp = colpos.data() + G.col_off;
             if (std::is_sorted(gc, gc + G.width)) {
@@ -372,11 +388,14 @@ std::string Analysis::build(int mtype_, int dtype_, int64_t nrows_, int64_t ncol
                 std::iota(ord.begin(), ord.end(), 0);
                 std::stable_sort(ord.begin(), ord.end(), [&](int32_t a, int32_t b) { return gc[a] < gc[b]; });
                 std::vector<int32_t> sorted((size_t)G.width);
+                std::vector<uint8_t> sortedk((size_t)G.width);
                 for (int64_t r = 0; r < G.width; r++) {
                     sorted[r] = gc[ord[r]];
+                    sortedk[r] = gk[ord[r]];
                     gp[ord[r]] = (int32_t)r;
                 }
                 std::copy(sorted.begin(), sorted.end(), gc);
+                std::copy(sortedk.begin(), sortedk.end(), gk);
             }
             G.val_off = val_units;
             val_units += (uint64_t)G.mc * (uint64_t)G.strips;
@@ -564,6 +583,7 @@ std::string Analysis::build(int mtype_, int dtype_, int64_t nrows_, int64_t ncol
             W.rbase = G.rbase;
             W.row_off = G.row_off;
             W.npieces = 0;
+            W.first.kind = G.kind | (G.has_off ? kKindGroupHasOff : 0);
             if (wb > wa) {
                 Piece &P = W.first;
                 const int64_t c0 = wa * E;
@@ -572,29 +592,38 @@ std::string Analysis::build(int mtype_, int dtype_, int64_t nrows_, int64_t ncol
                 P.nstrips = (int32_t)(wb - wa);
                 P.ncols = (int32_t)(c1 - c0);
                 P.col_off = (int32_t)(G.col_off + c0);
-                P.kind = G.kind;
-                // contiguous runs of x inside [c0, c1): up to three are described inline
+                // contiguous runs of x (of one kind) inside [c0, c1): up to three are described inline
                 int nseg = 1;
                 int32_t segw[3] = {0, P.ncols, P.ncols};
                 int32_t segx[3] = {cols[G.col_off + c0], 0, 0};
-                for (int64_t k = c0 + 1; k < c1 && nseg <= 3; k++)
-                    if (cols[G.col_off + k] != cols[G.col_off + k - 1] + 1) {
+                int32_t segk[3] = {ckind[G.col_off + c0], 0, 0};
+                bool piece_off = ckind[G.col_off + c0] == KIND_OFF;
+                for (int64_t k = c0 + 1; k < c1; k++) {
+                    piece_off |= ckind[G.col_off + k] == KIND_OFF;
+                    if (nseg <= 3 && (cols[G.col_off + k] != cols[G.col_off + k - 1] + 1 ||
+                                      ckind[G.col_off + k] != ckind[G.col_off + k - 1])) {
                         if (nseg < 3) {
                             segw[nseg] = (int32_t)(k - c0);
                             segx[nseg] = cols[G.col_off + k];
+                            segk[nseg] = ckind[G.col_off + k];
                         }
                         nseg++;
                     }
+                }
                 if (nseg <= 3) {
                     P.xbase = segx[0];
                     W.seg1_w = segw[1];
                     W.seg1_x = segx[1];
                     W.seg2_w = segw[2];
                     P.seg2_x = segx[2];
+                    P.kind = segk[0] | (segk[1] << 2) | (segk[2] << 4);
                 } else {
                     P.xbase = -1;
                     W.seg1_w = W.seg2_w = P.ncols;
+                    P.kind = G.kind;  // kind of the columns without the diagonal flag in the cols pool
                 }
+                if (piece_off) P.kind |= kKindHasOff;
+                if (G.has_off) P.kind |= kKindGroupHasOff;
                 W.npieces = 1;
             }
             waves.push_back(W);
@@ -735,15 +764,13 @@ std::string Analysis::build(int mtype_, int dtype_, int64_t nrows_, int64_t ncol
             std::vector<int64_t> ptr((size_t)ylen[k] + 1, 0);
             auto visit = [&](auto &&emit) {
                 // transposed column sums: slot = position in the cols pool, ascending
-                for (const Group &G : groups) {
-                    const bool trn = (k == 1) || G.kind == KIND_OFF;
-                    if (!trn) continue;
-                    for (int64_t q = 0; q < G.width; q++) emit(cols[G.col_off + q], G.col_off + q);
-                }
+                for (const Group &G : groups)
+                    for (int64_t q = 0; q < G.width; q++)
+                        if (k == 1 || ckind[G.col_off + q] == KIND_OFF) emit(cols[G.col_off + q], G.col_off + q);
                 // forward partial sums of every workgroup item
                 for (const WaveWork &W : waves) {
                     if (W.work != WORK_PANEL || !W.lead) continue;
-                    const bool fwd = (k == 0) || W.first.kind == KIND_OFF;
+                    const bool fwd = (k == 0) || (W.first.kind & kKindGroupHasOff);
                     if (!fwd) continue;
                     for (int i = 0; i < W.m; i++) {
                         const int64_t r = (W.rbase >= 0) ? (int64_t)W.rbase + i : rows[W.row_off + i];
@@ -779,6 +806,12 @@ std::string Analysis::build(int mtype_, int dtype_, int64_t nrows_, int64_t ncol
                         inv_idx[k][(size_t)(tp[t] + (c - ptr[j])) * 64 + (size_t)(j - t * 64)] = csr[c];
         }
     }
+    // the kernels' indexed path learns the kind of a column from the cols pool: flag the diagonal
+    // columns of panels that also hold off-diagonal ones (done last: everything above reads cols)
+    for (const Group &G : groups)
+        if (G.has_off && G.has_diag)
+            for (int64_t q = 0; q < G.width; q++)
+                if (ckind[G.col_off + q] == KIND_DIAG) cols[G.col_off + q] = (int32_t)((uint32_t)cols[G.col_off + q] | kColDiagBit);
     lap("schedule");
     // ---- colouring (reference bookkeeping) ---------------------------------------------------
     for (auto &c : colors) c.clear();

@@ -54,7 +54,7 @@ struct BlockIn {
 struct Tunables {
     int64_t split2_bytes = 8 << 10;     // row groups at least this big get 2 waves
     int64_t split4_bytes = 24 << 10;    // ... and 4 waves
-    int64_t wgitem_max_bytes = 512 << 10;  // non-exclusive groups are cut into items this big
+    int64_t wgitem_max_bytes = 256 << 10;  // non-exclusive groups are cut into items this big
     int pack_threads = 8;
     int lds_window = 1;  // LDS y window for locality-packed small symmetric row groups (BSM_WINDOW)
     int wg_order = 0;  // experimental workgroup dispatch orders (BSM_ORDER)

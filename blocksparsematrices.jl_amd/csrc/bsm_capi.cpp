@@ -167,7 +167,7 @@ void fill_image(const Analysis &an, const bsm_options &o, bool use_own, DeviceIm
     img.exclusive_fwd = an.exclusive_fwd && o.accumulate == BSM_ACC_AUTO;
     img.has_off = false;
     for (const WaveWork &w : an.waves)
-        if (w.work == WORK_PANEL && w.npieces > 0 && w.first.kind == KIND_OFF) img.has_off = true;
+        if (w.work == WORK_PANEL && w.npieces > 0 && (w.first.kind & kKindHasOff)) img.has_off = true;
     if (!img.exclusive_fwd) img.nwg_total = img.nwg_main;
     img.color_wg_ptr.assign(an.color_wg_ptr.begin(), an.color_wg_ptr.end());
     img.device_bytes = (long long)(an.values.size() + an.rows.size() * 4 + an.cols.size() * 4 +

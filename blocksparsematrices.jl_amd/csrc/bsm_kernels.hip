@@ -289,15 +289,27 @@ __device__ __forceinline__ T run_panel(const WaveD &wd, const uint4 *__restrict_
         const int col_off = pc.col_off;
         const int nstrips = pc.nstrips;
         const int ncols = pc.ncols;
-        const bool fwd_en = FWD && (!opT || pc.kind == KIND_OFF);
-        const bool trn_en = TRN && (opT || pc.kind == KIND_OFF);
+        // per-column kinds (a symmetric row group holds its diagonal block and its off-diagonal
+        // blocks in one panel): forward uses a column unless (op T/C and it is not KIND_OFF),
+        // transposed uses it iff (op T/C or KIND_OFF)
+        const int kinds = pc.kind;
+        const bool has_off = (kinds & kKindHasOff) != 0;
+        const bool fwd_en = FWD && (!opT || has_off);
+        const bool trn_en = TRN && (opT || has_off);
         const Vec16<T> *__restrict__ vb = reinterpret_cast<const Vec16<T> *>(
             values + (((uint64_t)pc.val_hi << 32) | pc.val_lo));
         // piece column -> x / y index: up to three inline contiguous runs, else the cols pool
         const int s1w = wd.seg1_w, s1x = wd.seg1_x - wd.seg1_w;
         const int s2w = wd.seg2_w, s2x = pc.seg2_x - wd.seg2_w;
-        auto col_index = [&](int w) -> int {
-            if (xbase < 0) return cols[col_off + w];
+        // -> x / y index of piece column w; `off` tells whether the column is KIND_OFF
+        auto col_lookup = [&](int w, bool &off) -> int {
+            if (xbase < 0) {
+                const int raw = cols[col_off + w];
+                off = raw >= 0 && (kinds & 3) == KIND_OFF;
+                return raw & 0x7fffffff;
+            }
+            const int sh = w < s1w ? 0 : (w < s2w ? 2 : 4);
+            off = ((kinds >> sh) & 3) == KIND_OFF;
             return w + (w < s1w ? xbase : (w < s2w ? s1x : s2x));
         };
 
@@ -312,7 +324,11 @@ __device__ __forceinline__ T run_panel(const WaveD &wd, const uint4 *__restrict_
                     const int w = c0 + c;
                     if (w < ncols + NC) {  // zero the tail one iteration past the last column
                         T xv = zero_of(T{});
-                        if (w < ncols) xv = x[col_index(w)];
+                        if (w < ncols) {
+                            bool off;
+                            const int xi = col_lookup(w, off);
+                            if (!opT || off) xv = x[xi];
+                        }
                         xs[c] = xv;
                     }
                 }
@@ -371,11 +387,13 @@ __device__ __forceinline__ T run_panel(const WaveD &wd, const uint4 *__restrict_
                             const int c = k * 64 + lane;
                             const int w = sb * E + c;
                             if (c < (slot + 1) * NC && w < ncols) {
+                                bool off;
+                                const int yi = col_lookup(w, off);
+                                if (!(opT || off)) continue;  // a diagonal column in op N: forward only
                                 if (flags & FLAG_GATHER) {  // one plain, coalesced store per column sum
                                     ws[col_off + w] = vs[c];
                                     continue;
                                 }
-                                const int yi = col_index(w);
                                 const T val = mul(alpha, vs[c]);
                                 const unsigned wi = (unsigned)(yi - wd.win_base);
                                 if (wi < (unsigned)win_n)
@@ -452,7 +470,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((!TRN 
             for (int k = 1; k < wd.grp; ++k) u = add(u, red[wave + k][lane]);
             if (flags & FLAG_GATHER) {
                 // forward partial sums of this workgroup item: slots ws_fbase + win_base + row
-                const bool fwd_on = !(flags & FLAG_OPT) || wd.first.kind == KIND_OFF;
+                const bool fwd_on = !(flags & FLAG_OPT) || (wd.first.kind & kKindGroupHasOff);
                 if (lane < m && fwd_on) ws[ws_fbase + wd.win_base + lane] = u;
             } else if (lane < m) {
                 const int yi = (wd.rbase >= 0) ? wd.rbase + lane : rows[wd.row_off + lane];
@@ -535,14 +553,26 @@ __device__ __forceinline__ void run_panel_multi(const WaveD &wd, const uint4 *__
         const int col_off = pc.col_off;
         const int nstrips = pc.nstrips;
         const int ncols = pc.ncols;
-        const bool fwd_en = FWD && (!opT || pc.kind == KIND_OFF);
-        const bool trn_en = TRN && (opT || pc.kind == KIND_OFF);
+        // per-column kinds (a symmetric row group holds its diagonal block and its off-diagonal
+        // blocks in one panel): forward uses a column unless (op T/C and it is not KIND_OFF),
+        // transposed uses it iff (op T/C or KIND_OFF)
+        const int kinds = pc.kind;
+        const bool has_off = (kinds & kKindHasOff) != 0;
+        const bool fwd_en = FWD && (!opT || has_off);
+        const bool trn_en = TRN && (opT || has_off);
         const Vec16<T> *__restrict__ vb = reinterpret_cast<const Vec16<T> *>(
             values + (((uint64_t)pc.val_hi << 32) | pc.val_lo));
         const int s1w = wd.seg1_w, s1x = wd.seg1_x - wd.seg1_w;
         const int s2w = wd.seg2_w, s2x = pc.seg2_x - wd.seg2_w;
-        auto col_index = [&](int w) -> int {
-            if (xbase < 0) return cols[col_off + w];
+        // -> x / y index of piece column w; `off` tells whether the column is KIND_OFF
+        auto col_lookup = [&](int w, bool &off) -> int {
+            if (xbase < 0) {
+                const int raw = cols[col_off + w];
+                off = raw >= 0 && (kinds & 3) == KIND_OFF;
+                return raw & 0x7fffffff;
+            }
+            const int sh = w < s1w ? 0 : (w < s2w ? 2 : 4);
+            off = ((kinds >> sh) & 3) == KIND_OFF;
             return w + (w < s1w ? xbase : (w < s2w ? s1x : s2x));
         };
 
@@ -553,8 +583,9 @@ __device__ __forceinline__ void run_panel_multi(const WaveD &wd, const uint4 *__
                     const int c = q * 64 + lane;
                     const int w = c0 + c;
                     if (w < ncols + NC) {
-                        const bool ok = w < ncols;
-                        const int xi = ok ? col_index(w) : 0;
+                        bool ok = w < ncols, off = false;
+                        const int xi = ok ? col_lookup(w, off) : 0;
+                        ok = ok && (!opT || off);
 #pragma unroll
                         for (int k = 0; k < K; ++k) xs[c * K + k] = ok ? x[xi + k * ldx] : zero_of(T{});
                     }
@@ -609,8 +640,10 @@ __device__ __forceinline__ void run_panel_multi(const WaveD &wd, const uint4 *__
                         for (int q = 0; q < (NC + 63) / 64; ++q) {
                             const int c = q * 64 + lane;
                             const int w = s0 * E + c;
-                            if (c < NC && w < ncols) {
-                                T *yp = &y[col_index(w) + k * ldy];
+                            bool off = false;
+                            const int yi = (c < NC && w < ncols) ? col_lookup(w, off) : 0;
+                            if (c < NC && w < ncols && (opT || off)) {
+                                T *yp = &y[yi + k * ldy];
                                 const T val = mul(alpha, vs[c]);
                                 if (flags & FLAG_RMW)
                                     *yp = add(*yp, val);

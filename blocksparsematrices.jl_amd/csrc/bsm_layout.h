@@ -38,7 +38,11 @@ struct Piece {
     int32_t col_off;   // offset into cols pool of the first column
     int32_t nstrips;   // strips in this piece
     int32_t ncols;     // valid columns (<= nstrips * E)
-    int32_t kind;      // KIND_*
+    int32_t kind;      // kinds word: bits 0-1 kind of column segment 0 (of every non-flagged column for
+                       // pieces that use the cols pool), 2-3 segment 1, 4-5 segment 2; bit 8: the
+                       // piece has KIND_OFF columns; bit 9: its ROW GROUP has (other waves of the
+                       // workgroup item may hold them: decides whether forward sums exist in op T).  In the cols pool a set sign bit marks a
+                       // KIND_DIAG column of a panel that also holds KIND_OFF columns.
     int32_t seg2_x;    // first x index of column segment 2
 };
 static_assert(sizeof(Piece) == 32, "Piece must be 32 bytes");
@@ -69,6 +73,10 @@ struct WaveWork {
     Piece first;
 };
 static_assert(sizeof(WaveWork) == 64, "WaveWork must be 64 bytes");
+
+constexpr int kKindHasOff = 1 << 8;
+constexpr int kKindGroupHasOff = 1 << 9;
+constexpr uint32_t kColDiagBit = 0x80000000u;
 
 constexpr int kWavesPerWg = 4;
 constexpr int kMaxRowsPerChunk = 64;

@@ -156,7 +156,9 @@ WAVE_DT = np.dtype([("seg1_w", "<i4"), ("win_base", "<i4"), ("row_off", "<i4"), 
                     ("seg1_x", "<i4"), ("seg2_w", "<i4"), ("first", PIECE_DT)])
 assert PIECE_DT.itemsize == 32 and WAVE_DT.itemsize == 64
 WORK_NOP, WORK_PANEL, WORK_SCALE = 0, 1, 2
-KIND_OFF = 2
+KIND_DIAG, KIND_OFF = 1, 2
+KIND_HAS_OFF = 1 << 8
+KIND_GROUP_HAS_OFF = 1 << 9
 
 
 def get_image(A, timage=False):
@@ -228,7 +230,7 @@ def interpret_image(A, op, x, y0, alpha=1, beta=0, strong=True, timage=False):
         y[:] = 0 if strong else beta * y
     assert len(waves) % 4 == 0
     pw = waves[waves["work"] == WORK_PANEL]
-    has_off = bool(np.any(pw["first"]["kind"][pw["npieces"] > 0] == KIND_OFF))
+    has_off = bool(np.any(pw["first"]["kind"][pw["npieces"] > 0] & KIND_HAS_OFF))
     fwd_kernel = (not opT) or has_off  # the launcher's choice of the FWD template flag
     for wg in range(len(waves) // 4):
         us = [None] * 4
@@ -255,22 +257,30 @@ def interpret_image(A, op, x, y0, alpha=1, beta=0, strong=True, timage=False):
                 assert not np.any(full[:, nc:]), "strip padding must be zero"
                 if conj:
                     B = B.conj()
-                if P["xbase"] >= 0:  # up to three inline contiguous runs
-                    wv = np.arange(nc)
+                kinds = int(P["kind"])
+                wv = np.arange(nc)
+                pool = cols[P["col_off"]:P["col_off"] + nc]
+                if P["xbase"] >= 0:  # up to three inline contiguous runs, each of one kind
                     s1w, s2w = int(W["seg1_w"]), int(W["seg2_w"])
                     cidx = np.where(wv < s1w, int(P["xbase"]) + wv,
                                     np.where(wv < s2w, int(W["seg1_x"]) + wv - s1w, int(P["seg2_x"]) + wv - s2w))
-                    assert np.array_equal(cidx, cols[P["col_off"]:P["col_off"] + nc])
-                else:
-                    cidx = cols[P["col_off"]:P["col_off"] + nc]
-                kind = int(P["kind"])
-                if (not opT) or kind == KIND_OFF:
-                    u += B @ x[cidx]
-                if opT or kind == KIND_OFF:
+                    ckind = np.where(wv < s1w, kinds & 3, np.where(wv < s2w, (kinds >> 2) & 3, (kinds >> 4) & 3))
+                    assert np.array_equal(cidx, pool & 0x7fffffff)
+                else:  # cols pool; a set sign bit flags a diagonal column of a mixed panel
+                    cidx = pool & 0x7fffffff
+                    ckind = np.where(pool < 0, KIND_DIAG, kinds & 3)
+                assert bool(kinds & KIND_HAS_OFF) == bool(np.any(ckind == KIND_OFF))
+                off = ckind == KIND_OFF
+                fcols = np.ones(nc, bool) if not opT else off      # columns used by the forward product
+                tcols = off if not opT else np.ones(nc, bool)      # columns used by the transposed product
+                if np.any(fcols):
+                    u += B[:, fcols] @ x[cidx[fcols]]
+                if np.any(tcols):
+                    v = B[:, tcols].T @ x[ridx]
                     if gather:  # one store per column sum, slot = position in the cols pool
-                        ws[int(P["col_off"]):int(P["col_off"]) + nc] = B.T @ x[ridx]
+                        ws[int(P["col_off"]) + np.nonzero(tcols)[0]] = v
                     else:
-                        np.add.at(y, cidx, alpha * (B.T @ x[ridx]))
+                        np.add.at(y, cidx[tcols], alpha * v)
             us[w] = (u, ridx, int(W["grp"]), int(W["lead"]))
         for w in range(4):
             if us[w] is None or not us[w][3] or not fwd_kernel:
@@ -283,7 +293,7 @@ def interpret_image(A, op, x, y0, alpha=1, beta=0, strong=True, timage=False):
                 u += us[w + k][0]
             if gather:
                 lead = waves[wg * 4 + w]
-                if (not opT) or int(lead["first"]["kind"]) == KIND_OFF:
+                if (not opT) or (int(lead["first"]["kind"]) & KIND_GROUP_HAS_OFF):
                     ws[fbase + int(lead["win_base"]):fbase + int(lead["win_base"]) + len(ridx)] = u
             elif direct:
                 y[ridx] = alpha * u if strong else beta * y[ridx] + alpha * u

@@ -337,7 +337,7 @@ def test_lds_window_descriptors_cover_their_workgroup(bsm):
         for W in quad[(quad["work"] == WORK_PANEL) & (quad["npieces"] > 0)]:
             m = int(W["m"])
             r = np.arange(W["rbase"], W["rbase"] + m) if W["rbase"] >= 0 else rows[W["row_off"]:W["row_off"] + m]
-            c = cols[W["first"]["col_off"]:W["first"]["col_off"] + W["first"]["ncols"]]
+            c = cols[W["first"]["col_off"]:W["first"]["col_off"] + W["first"]["ncols"]] & 0x7fffffff
             assert r.min() >= base and r.max() < base + span and c.min() >= base and c.max() < base + span
             groups.add((int(W["rbase"]), int(W["row_off"])))
         assert len(groups) >= 2
