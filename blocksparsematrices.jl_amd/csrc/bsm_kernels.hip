@@ -422,7 +422,7 @@ __device__ __forceinline__ T run_panel(const WaveD &wd, const uint4 *__restrict_
 // forward-only instances are held to 80 VGPRs (6 waves per SIMD = 1536 resident workgroups:
 // every workgroup of a C2-sized launch is resident at once); the fused instances need ~100.
 template <typename T, int L, bool FWD, bool TRN>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((!TRN && sizeof(T) == 8) ? 6 : 4)))
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((!TRN && std::is_same<T, double>::value) ? 6 : 4)))
     panel_kernel(const WaveWork *__restrict__ waves, const uint4 *__restrict__ values, const int *__restrict__ rows,
                  const int *__restrict__ cols, const T *__restrict__ x, T *__restrict__ y, T alpha,
                  T beta, int flags, unsigned wg_base, T *__restrict__ ws, long long ws_fbase) {
