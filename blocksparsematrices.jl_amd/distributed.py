@@ -12,6 +12,13 @@ MI355X-first counterpart of its `@tasks` fan-out over block rows / colour classe
     previous rank only).  Each rank accumulates into a work vector over the rows it TOUCHES and the
     overlaps are exchanged point-to-point (isend/irecv == ncclSend/ncclRecv over the direct xGMI
     links) and added -- never a ring all-reduce of the full y, which would be bound by one link.
+  * BlockSparseMatrix (index lists): blocks go with the rank that owns their smallest row index;
+    rows a block reaches outside its rank's range travel through the same point-to-point exchange.
+  * Products that run ACROSS the partition (transpose(A)*x of a row-partitioned VBCRS /
+    BlockSparseMatrix, A*x of a column-partitioned one) give a full-length partial result on every
+    rank: one reduce-scatter onto equal chunks (all-reduce when the caller wants the whole y).
+    `split_vbcrs(..., axis=1)` is the column partition that makes the TRANSPOSED products
+    collective-free (mirror of the forward case, reference src/vbcrs.jl:303-329).
 """
 import numpy as np
 
@@ -41,11 +48,12 @@ def balanced_cuts(weights, nparts):
     return cuts
 
 
-def split_vbcrs(problem, rank, nparts):
-    """Row-partition a VBCRS problem dict: contiguous ranges of block rows balanced by stored bytes.
-    Returns (local problem, own=(lo, hi) 1-based inclusive)."""
-    rs = np.asarray(problem["rowstart"], dtype=np.int64)
-    n = problem["size"][0]
+def split_vbcrs(problem, rank, nparts, axis=0):
+    """Partition a VBCRS problem dict into contiguous ranges of block rows (axis=0) or block columns
+    (axis=1: for transposed products) balanced by stored bytes.
+    Returns (local problem, own=(lo, hi) 1-based inclusive along `axis`)."""
+    rs = np.asarray(problem["rowstart" if axis == 0 else "colstart"], dtype=np.int64)
+    n = problem["size"][axis]
     starts = np.unique(rs)  # block rows, sorted
     bytes_per_row = np.zeros(len(starts))
     idx = np.searchsorted(starts, rs)
@@ -57,9 +65,42 @@ def split_vbcrs(problem, rank, nparts):
     if rank == 0:
         lo_row = 1
     keep = [b for b in range(len(rs)) if cuts[rank] <= idx[b] < cuts[rank + 1]]
-    local = dict(kind="vbcrs", blocks=[problem["blocks"][b] for b in keep], rowstart=rs[keep],
+    local = dict(kind="vbcrs", blocks=[problem["blocks"][b] for b in keep],
+                 rowstart=np.asarray(problem["rowstart"], dtype=np.int64)[keep],
                  colstart=np.asarray(problem["colstart"], dtype=np.int64)[keep], size=problem["size"])
     return local, (lo_row, hi_row)
+
+
+def split_blocksparse(problem, rank, nparts):
+    """Partition a BlockSparseMatrix problem (arbitrary index lists): blocks sorted by their smallest
+    row index, cut into ranges balanced by stored bytes; a rank owns the rows from its first block's
+    smallest row up to the next rank's.  Returns (local problem, own, touched), 1-based inclusive."""
+    n = problem["size"][0]
+    first = np.array([int(np.min(r)) if len(r) else 1 for r in problem["rowindices"]], dtype=np.int64)
+    order = np.argsort(first, kind="stable")
+    w = np.array([problem["blocks"][b].size for b in order], dtype=np.float64)
+    cuts = balanced_cuts(w, nparts)
+    # blocks with the same smallest row stay together, so that the row ranges are disjoint
+    for p in range(1, nparts):
+        k = cuts[p]
+        while 0 < k < len(order) and first[order[k]] == first[order[k - 1]]:
+            k += 1
+        cuts[p] = max(k, cuts[p - 1])
+    lo = int(first[order[cuts[rank]]]) if cuts[rank] < len(order) else n + 1
+    hi = int(first[order[cuts[rank + 1]]]) - 1 if cuts[rank + 1] < len(order) else n
+    if rank == 0:
+        lo = 1
+    keep = [int(order[k]) for k in range(cuts[rank], cuts[rank + 1])]
+    local = dict(kind="blocksparse", blocks=[problem["blocks"][b] for b in keep],
+                 rowindices=[problem["rowindices"][b] for b in keep],
+                 colindices=[problem["colindices"][b] for b in keep], size=problem["size"])
+    tlo, thi = lo, hi
+    for lst in local["rowindices"]:
+        if len(lst):
+            tlo, thi = min(tlo, int(np.min(lst))), max(thi, int(np.max(lst)))
+    if thi < tlo:
+        tlo, thi = lo, lo - 1
+    return local, (lo, hi), (tlo, thi)
 
 
 def split_symmetric(problem, rank, nparts):
@@ -96,24 +137,38 @@ def split_symmetric(problem, rank, nparts):
 
 
 class RowPartitioned:
-    """y = alpha*A*x + beta*y with A's block rows spread over the ranks of `group`.
+    """y = alpha*op(A)*x + beta*y with A's blocks spread over the ranks of `group`.
 
-    x must hold the FULL vector on every rank; after mul(), y[own range] is final on every rank
-    (the whole y when gather=True).  `local` is this rank's matrix (built with own=touched range so
+    `axis` = 0: `own` / `touched` are ROW ranges (forward products are local up to the halo);
+    `axis` = 1: column ranges of a column-partitioned operator (the transposed products are).
+    `symmetric`: op(A) has A's structure, every op runs along the partition.
+
+    x must hold the FULL vector on every rank.  After mul() the rank's output range is final in y
+    (the whole y when gather=True): `own` for products along the partition, `out_range(n)` (equal
+    chunks) for products across it.  `local` is this rank's matrix (built with own=touched range so
     its beta pass covers exactly the rows it touches)."""
 
-    def __init__(self, local, own, touched=None, group=None, gather=False):
+    def __init__(self, local, own, touched=None, group=None, gather=False, axis=0, symmetric=None):
         self.local = local
         self.own = (int(own[0]), int(own[1]))
         self.touched = self.own if touched is None else (int(touched[0]), int(touched[1]))
         self.group = group
         self.gather = gather
+        self.axis = axis
+        self.symmetric = isinstance(local, M.SymmetricBlockMatrix) if symmetric is None else symmetric
         self.rank = dist.get_rank(group) if dist is not None and dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist is not None and dist.is_initialized() else 1
         self._ranges = None
         self._work = None
         self._gbuf = None
         self._sbuf = None
+        self._pad = None
+
+    def out_range(self, n, rank=None):
+        """Output rows (1-based, inclusive) rank `rank` holds after a product ACROSS the partition."""
+        r = self.rank if rank is None else rank
+        chunk = -(-n // self.world)
+        return (min(r * chunk, n) + 1, min((r + 1) * chunk, n))
 
     def _exchange_ranges(self):
         """(own, touched) of every rank -- one small all_gather at first use."""
@@ -128,26 +183,46 @@ class RowPartitioned:
                 self._ranges = [tuple(int(v) for v in mine)]
         return self._ranges
 
-    def mul(self, y, x, alpha=True, beta=False, local_mul=None):
-        """local_mul(work_or_y, x, alpha, beta): test hook replacing the HIP product (CPU gloo tests)."""
+    def _workvec(self, y):
+        if self._work is None or self._work.shape != y.shape or self._work.device != y.device or \
+                self._work.dtype != y.dtype:
+            self._work = torch.zeros_like(y)
+        return self._work
+
+    @staticmethod
+    def _combine(y, sl, w, beta):
+        if beta is False:
+            y[sl] = w
+        else:
+            y[sl] = y[sl] * (1 if beta is True else beta) + w
+
+    def mul(self, y, x, alpha=True, beta=False, local_mul=None, op=M.L.BSM_OP_N):
+        """local_mul(work_or_y, x, alpha, beta[, op]): test hook replacing the HIP product (CPU gloo tests)."""
         self._device = y.device
-        lm = local_mul if local_mul is not None else (lambda yy, xx, a, b: M.mul(yy, self.local, xx, a, b))
+        N_ = M.L.BSM_OP_N
+        if local_mul is not None:
+            lm = (lambda yy, xx, a, b: local_mul(yy, xx, a, b)) if op == N_ and self.axis == 0 else \
+                (lambda yy, xx, a, b: local_mul(yy, xx, a, b, op))
+        else:
+            Aop = self.local if op == N_ else (M.transpose(self.local) if op == M.L.BSM_OP_T else M.adjoint(self.local))
+            lm = lambda yy, xx, a, b: M.mul(yy, Aop, xx, a, b)
+        along = self.symmetric or ((op == N_) == (self.axis == 0))
+        ranges = self._exchange_ranges()
+        if not along:
+            return self._mul_across(y, x, alpha, beta, lm)
         # collective decision: if ANY rank touches rows it does not own, every rank takes part in
         # the exchange (a rank without a halo of its own may still receive contributions)
-        ranges = self._exchange_ranges()
         halo = any((rl, rh) != (tl, th) for rl, rh, tl, th in ranges)
-        if not halo:
+        if not halo and self.axis == 0 and op == N_:
             lm(y, x, alpha, beta)  # rows outside `own` are left untouched by the handle
         else:
-            if self._work is None or self._work.shape != y.shape or self._work.device != y.device:
-                self._work = torch.zeros_like(y)
-            w = self._work
+            w = self._workvec(y)
             lm(w, x, alpha, False)  # strong zero over the touched range, then accumulate
             ops, recvs = [], []
             olo, ohi = self.own
             tlo, thi = self.touched
             for r, (rlo, rhi, rtlo, rthi) in enumerate(ranges):
-                if r == self.rank:
+                if r == self.rank or not halo:
                     continue
                 a, b = max(tlo, rlo), min(thi, rhi)  # my contributions to rank r's rows
                 if a <= b:
@@ -161,25 +236,51 @@ class RowPartitioned:
                 for req in dist.batch_isend_irecv(ops):
                     req.wait()
             own_slice = slice(olo - 1, ohi)
-            if beta is False:
-                y[own_slice] = w[own_slice]
-            else:
-                y[own_slice] = y[own_slice] * (1 if beta is True else beta) + w[own_slice]
+            self._combine(y, own_slice, w[own_slice], beta)
             for a, b, buf in recvs:
                 y[a - 1:b] += buf
         if self.gather and self.world > 1:
-            # one all-gather of the (padded) own slices instead of one broadcast per rank: a single
-            # collective whose per-peer messages (~n/N entries) use all xGMI links at once
-            ranges = self._exchange_ranges()
-            maxlen = max(max(rh - rl + 1, 0) for rl, rh, _, _ in ranges)
-            if self._gbuf is None or self._gbuf.shape[0] != self.world * maxlen or self._gbuf.device != y.device:
-                self._gbuf = torch.empty(self.world * maxlen, dtype=y.dtype, device=y.device)
-                self._sbuf = torch.zeros(maxlen, dtype=y.dtype, device=y.device)
-            olo, ohi = self.own
-            if ohi >= olo:
-                self._sbuf[:ohi - olo + 1] = y[olo - 1:ohi]
-            dist.all_gather(list(self._gbuf.view(self.world, maxlen).unbind(0)), self._sbuf, group=self.group)
-            for r, (rlo, rhi, _, _) in enumerate(ranges):
-                if r != self.rank and rhi >= rlo:
-                    y[rlo - 1:rhi] = self._gbuf[r * maxlen:r * maxlen + (rhi - rlo + 1)]
+            self._allgather(y, [(rl, rh) for rl, rh, _, _ in ranges])
+        return y
+
+    def _mul_across(self, y, x, alpha, beta, lm):
+        """Every rank holds a full-length partial result: reduce-scatter onto equal chunks (or one
+        all-reduce when the whole y is wanted on every rank)."""
+        n = y.shape[0]
+        w = self._workvec(y)
+        lm(w, x, alpha, False)
+        if self.world == 1:
+            self._combine(y, slice(0, n), w, beta)
+            return y
+        if self.gather:
+            dist.all_reduce(w, group=self.group)
+            self._combine(y, slice(0, n), w, beta)
+            return y
+        chunk = -(-n // self.world)
+        if self._pad is None or self._pad.shape[0] != chunk * self.world or self._pad.device != y.device or \
+                self._pad.dtype != y.dtype:
+            self._pad = torch.zeros(chunk * self.world, dtype=y.dtype, device=y.device)
+        self._pad[:n] = w
+        out = torch.empty(chunk, dtype=y.dtype, device=y.device)
+        dist.reduce_scatter(out, list(self._pad.view(self.world, chunk).unbind(0)), group=self.group)
+        lo, hi = self.out_range(n)
+        if hi >= lo:
+            self._combine(y, slice(lo - 1, hi), out[:hi - lo + 1], beta)
+        return y
+
+    def _allgather(self, y, own_ranges):
+        # one all-gather of the (padded) own slices instead of one broadcast per rank: a single
+        # collective whose per-peer messages (~n/N entries) use all xGMI links at once
+        maxlen = max(max(rh - rl + 1, 0) for rl, rh in own_ranges)
+        if self._gbuf is None or self._gbuf.shape[0] != self.world * maxlen or self._gbuf.device != y.device or \
+                self._gbuf.dtype != y.dtype:
+            self._gbuf = torch.empty(self.world * maxlen, dtype=y.dtype, device=y.device)
+            self._sbuf = torch.zeros(maxlen, dtype=y.dtype, device=y.device)
+        olo, ohi = self.own
+        if ohi >= olo:
+            self._sbuf[:ohi - olo + 1] = y[olo - 1:ohi]
+        dist.all_gather(list(self._gbuf.view(self.world, maxlen).unbind(0)), self._sbuf, group=self.group)
+        for r, (rlo, rhi) in enumerate(own_ranges):
+            if r != self.rank and rhi >= rlo:
+                y[rlo - 1:rhi] = self._gbuf[r * maxlen:r * maxlen + (rhi - rlo + 1)]
         return y

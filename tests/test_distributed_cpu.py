@@ -39,25 +39,40 @@ def _worker(rank, world, port, kind, q):
         from _common import N, interpret_image, oracle_mul, relerr
         from oracle import load_oracle
 
+        from _common import T
+        op, axis = N, 0
         if kind == "vbcrs":
             prob = bsm.synthetic.config2(n=5000, nblocks=300)
             local, own = D.split_vbcrs(prob, rank, world)
             touched = own
+        elif kind == "vbcrs_T_across":  # transposed product of a ROW-partitioned operator: reduce-scatter
+            prob = bsm.synthetic.config2(n=5000, nblocks=300)
+            local, own = D.split_vbcrs(prob, rank, world)
+            touched, op = own, T
+        elif kind == "vbcrs_cols_T":  # column partition: the transposed product is collective-free
+            prob = bsm.synthetic.config2(n=5000, nblocks=300)
+            local, own = D.split_vbcrs(prob, rank, world, axis=1)
+            touched, op, axis = own, T, 1
+        elif kind == "blocksparse":
+            prob = bsm.synthetic.config1(n=3000, nblocks=120, bs=24)
+            local, own, touched = D.split_blocksparse(prob, rank, world)
         else:
             prob = bsm.synthetic.config5(n=5000, lo=16, hi=96, halfband=3)
             local, own, touched = D.split_symmetric(prob, rank, world)
         # `own` = the rows this handle is responsible for scaling by beta (C ABI bsm_options.own_lo/hi)
-        A = bsm.synthetic.build(local, device=NODEV, own=touched)
+        A = bsm.synthetic.build(local, device=NODEV, **({"own": touched} if axis == 0 else {}))
         n = prob["size"][0]
         x = torch.from_numpy(prob["x"].copy())
         y0 = np.random.default_rng(7).standard_normal(n)
 
-        def local_mul(yy, xx, alpha, beta):
+        def local_mul(yy, xx, alpha, beta, lop=N):
             strong = beta is False
             a = 1 if alpha is True else alpha
             b = 0 if strong else (1 if beta is True else beta)
-            out = interpret_image(A, N, xx.numpy(), yy.numpy(), a, b, strong)
-            if kind == "vbcrs":
+            out = interpret_image(A, lop, xx.numpy(), yy.numpy(), a, b, strong)
+            if lop != N:
+                yy[:] = torch.from_numpy(out)  # transposed products scale the whole y
+            elif kind == "vbcrs":
                 lo, hi = own  # the handle only writes the rows it owns
                 yy[lo - 1:hi] = torch.from_numpy(out[lo - 1:hi])
             else:
@@ -65,17 +80,24 @@ def _worker(rank, world, port, kind, q):
                 yy[lo - 1:hi] = torch.from_numpy(out[lo - 1:hi])
             return yy
 
-        P = D.RowPartitioned(A, own, touched, gather=True)
         results = []
-        for alpha, beta in ((True, False), (0.5, -2.0)):
-            y = torch.from_numpy(y0.copy())
-            P.mul(y, x, alpha, beta, local_mul=local_mul)
-            results.append(y.numpy().copy())
+        for gather in (True, False):
+            P = D.RowPartitioned(A, own, touched, gather=gather, axis=axis)
+            for alpha, beta in ((True, False), (0.5, -2.0)):
+                y = torch.from_numpy(y0.copy())
+                P.mul(y, x, alpha, beta, local_mul=local_mul, op=op)
+                if not gather:  # only this rank's output range is final: keep it, take the rest from
+                    lo, hi = own if (op == N) == (axis == 0) or kind == "symmetric" else P.out_range(n)
+                    part = torch.zeros_like(y)
+                    part[lo - 1:hi] = y[lo - 1:hi]
+                    dist.all_reduce(part)  # test-side assembly of the slices
+                    y = part
+                results.append(y.numpy().copy())
         if rank == 0:
             orc = load_oracle()
             errs = []
-            for (alpha, beta), got in zip(((1, 0), (0.5, -2.0)), results):
-                ref = oracle_mul(orc, prob, N, prob["x"], y0, alpha, beta, strong=(beta == 0))
+            for (alpha, beta), got in zip(((1, 0), (0.5, -2.0)) * 2, results):
+                ref = oracle_mul(orc, prob, op, prob["x"], y0, alpha, beta, strong=(beta == 0))
                 errs.append(relerr(got, ref))
             q.put(("ok", errs, own, touched))
         dist.barrier()
@@ -86,7 +108,8 @@ def _worker(rank, world, port, kind, q):
         raise
 
 
-@pytest.mark.parametrize("kind,world", [("vbcrs", 2), ("symmetric", 2), ("symmetric", 3)])
+@pytest.mark.parametrize("kind,world", [("vbcrs", 2), ("symmetric", 2), ("symmetric", 3), ("blocksparse", 2),
+                                        ("blocksparse", 3), ("vbcrs_T_across", 2), ("vbcrs_cols_T", 2)])
 def test_row_partitioned_over_gloo(kind, world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -125,3 +148,18 @@ def test_partition_is_a_partition():
         assert touched[0] <= own[0] and touched[1] >= own[1]
     assert nd == len(sp["diagonals"]) and no == len(sp["offdiagonals"])
     assert D.balanced_cuts([1, 1, 1, 1], 2) == [0, 2, 4]
+    bp = bsm.synthetic.config1(n=2000, nblocks=90, bs=16)
+    nb, prev_hi = 0, 0
+    for r in range(4):
+        local, own, touched = D.split_blocksparse(bp, r, 4)
+        nb += len(local["blocks"])
+        assert own[0] == prev_hi + 1 and touched[0] <= own[0] and touched[1] >= own[1]
+        prev_hi = own[1]
+        for rows in local["rowindices"]:
+            assert own[0] <= int(np.min(rows)) <= own[1]
+    assert nb == len(bp["blocks"]) and prev_hi == 2000
+    cp = bsm.synthetic.config2(n=8000, nblocks=500)
+    for r in range(3):
+        local, own = D.split_vbcrs(cp, r, 3, axis=1)
+        for cs, b in zip(local["colstart"], local["blocks"]):
+            assert own[0] <= cs and cs + b.shape[1] - 1 <= own[1]
