@@ -27,6 +27,9 @@ struct bsm_matrix_s {
     // device staging buffers of the BSM_MEM_HOST path, kept between calls (grow-only); a second
     // concurrent host call on the same handle falls back to temporary buffers
     std::mutex gather_mu;  // the gather workspace admits one product in flight per handle
+    hipEvent_t ws_done = nullptr;    // recorded after the last gather-mode product
+    hipStream_t ws_stream = nullptr;  // ... on this stream
+    bool ws_pending = false;
     std::mutex host_mu;
     void *stage_x = nullptr, *stage_y = nullptr;
     size_t stage_x_bytes = 0, stage_y_bytes = 0;
@@ -469,10 +472,42 @@ extern "C" int bsm_mul(bsm_matrix_t A, int op, const void *x, void *y, const voi
     // gather mode: the workspace belongs to the handle, so the enqueue is serialised; a caller that
     // races on the same handle from another thread gets the atomic path for that call
     std::unique_lock<std::mutex> glock(A->gather_mu, std::defer_lock);
-    const bool use_gather = img.d_ws != nullptr && glock.try_lock();
+    bool use_gather = img.d_ws != nullptr && glock.try_lock();
+    // ... and a product still in flight on ANOTHER stream owns the workspace too (same stream:
+    // stream order protects it).  Not tracked while the stream is being captured into a graph:
+    // replays of one graph are ordered by the caller.
+    bool track = false;
+    if (use_gather) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &cs) != hipSuccess) {
+            (void)hipGetLastError();
+            cs = hipStreamCaptureStatusNone;
+        }
+        track = (cs == hipStreamCaptureStatusNone);
+        if (track && A->ws_pending && A->ws_stream != st) {
+            if (hipEventQuery(A->ws_done) == hipSuccess)
+                A->ws_pending = false;
+            else {
+                (void)hipGetLastError();  // hipErrorNotReady is not a failure
+                use_gather = track = false;
+            }
+        }
+    }
+    auto mark_gather = [&]() {
+        if (!track) return;
+        if (!A->ws_done && hipEventCreateWithFlags(&A->ws_done, hipEventDisableTiming) != hipSuccess) {
+            A->ws_done = nullptr;
+            return;
+        }
+        if (hipEventRecord(A->ws_done, st) == hipSuccess) {
+            A->ws_stream = st;
+            A->ws_pending = true;
+        }
+    };
     if (memspace == BSM_MEM_DEVICE) {
         e = launch_mul(img, opT, conj, x, y, alpha, beta, beta_strong_zero, st, use_gather);
         if (e != hipSuccess) return hip_fail(e, "kernel launch");
+        mark_gather();
         return BSM_OK;
     }
     if (memspace != BSM_MEM_HOST) return fail(BSM_ERR_INVALID, "bad memspace");
@@ -659,6 +694,7 @@ extern "C" int bsm_destroy(bsm_matrix_t A) {
         free_image(A->img_t);
         if (A->stage_x) (void)hipFree(A->stage_x);
         if (A->stage_y) (void)hipFree(A->stage_y);
+        if (A->ws_done) (void)hipEventDestroy(A->ws_done);
     }
     delete A;
     return BSM_OK;

@@ -62,8 +62,10 @@ typedef enum {
                             workspace owned by the handle and a second launch sums, per y entry,
                             its contributions in a fixed order (and applies alpha, beta): bitwise
                             reproducible, two launches.  The workspace makes products on ONE handle
-                            stream-ordered: at most one bsm_mul in flight per handle (a concurrent
-                            call falls back to atomics).  Single right-hand side only. */
+                            stream-ordered: a call that finds another product of the same handle
+                            still in flight on a DIFFERENT stream (or being enqueued by another
+                            thread) uses the atomic path for that call.  Single right-hand side
+                            only. */
 } bsm_accumulate;
 
 #define BSM_DEVICE_CURRENT (-1)

@@ -576,3 +576,26 @@ def test_gather_mode_other_types(torch_cuda, bsm, oracle):
     A = bsm.synthetic.build(c5, accumulate="gather")
     check_all(torch_cuda, bsm, oracle, c5, A, np.float64, host_too=False)
     _check_multi(torch_cuda, bsm, oracle, c5, A, np.float64, nrhs_list=(5,), ops=[N])  # multi-RHS: atomic path
+
+
+def test_gather_mode_two_streams_share_one_workspace(torch_cuda, bsm, oracle):
+    # the gather workspace belongs to the handle: a product that finds another one in flight on a
+    # different stream must not touch it (it takes the atomic path for that call)
+    torch = torch_cuda
+    p = bsm.synthetic.config5(n=40000, lo=16, hi=96, halfband=3)
+    A = bsm.synthetic.build(p, accumulate="gather")
+    n = p["size"][0]
+    rng = np.random.default_rng(91)
+    xs = [rand_vec(rng, n, np.float64) for _ in range(2)]
+    refs = [oracle_mul(oracle, p, N, xv, np.zeros(n)) for xv in xs]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    xd = [torch.from_numpy(v).cuda() for v in xs]
+    yd = [torch.full((n,), float("nan"), dtype=torch.float64, device="cuda") for _ in range(2)]
+    torch.cuda.synchronize()
+    for it in range(40):
+        for k in range(2):  # alternate the streams without waiting in between
+            with torch.cuda.stream(streams[k]):
+                bsm.mul(yd[k], A, xd[k])
+    torch.cuda.synchronize()
+    for k in range(2):
+        assert relerr(yd[k].cpu().numpy(), refs[k]) < 1e-12
