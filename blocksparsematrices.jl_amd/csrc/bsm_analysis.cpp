@@ -726,7 +726,7 @@ std::string Analysis::build(int mtype_, int dtype_, int64_t nrows_, int64_t ncol
             // worth it only when different groups meet and the window is reasonably dense
             if (!distinct || hi < lo) continue;
             const int64_t span = hi - lo + 1;
-            if (span > kWindowEntries || touched < span) continue;
+            if (span > window_entries(es) || touched < span) continue;
             for (int w = 0; w < kWavesPerWg; w++) {
                 waves[wg + w].win_base = (int32_t)lo;
                 waves[wg + w].win_span8 = (uint8_t)((span + 7) / 8);

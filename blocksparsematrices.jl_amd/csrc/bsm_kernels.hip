@@ -251,8 +251,13 @@ __device__ __forceinline__ WaveD load_wave(const WaveWork *__restrict__ wp) {
 // ----------------------------------------------------------------------------------------
 // one wave streams its pieces; returns the forward partial sum of row (lane % P)
 // ----------------------------------------------------------------------------------------
-// x slice staged per wave in LDS: 512 columns (256 for complex128), i.e. <= 4 KB
-template <typename T> constexpr int x_chunk_cols() { return sizeof(T) >= 16 ? 256 : 512; }
+// x slice staged per wave in LDS.  Forward-only kernels: 512 columns (256 for complex128), <= 4 KB.
+// Fused kernels: 2 KB (512 fp32 ... 128 complex128 columns) -- with the y window and the emission
+// staging their occupancy is bounded by LDS and by the registers of the unrolled staging loop
+// (fp64: 111 -> 80 VGPRs, 4 -> 6 waves per SIMD; +11 % on 3-28-row BEM panels).
+template <typename T, bool TRN = false> constexpr int x_chunk_cols() {
+    return TRN ? 2048 / (int)sizeof(T) : (sizeof(T) >= 16 ? 256 : 512);
+}
 
 template <typename T, int L, int P, bool FWD, bool TRN>
 __device__ __forceinline__ T run_panel(const WaveD &wd, const uint4 *__restrict__ values,
@@ -264,7 +269,7 @@ __device__ __forceinline__ T run_panel(const WaveD &wd, const uint4 *__restrict_
     constexpr int G = 64 / P;
     constexpr int V = L * E;
     constexpr int NC = G * L * E;                        // columns covered per iteration
-    constexpr int XCH = x_chunk_cols<T>();                 // columns staged per x chunk
+    constexpr int XCH = x_chunk_cols<T, TRN>();            // columns staged per x chunk
     constexpr int BF = (NC >= 64) ? 1 : 64 / NC;           // iterations per transposed emission
     static_assert(XCH % NC == 0, "x chunk must hold whole iterations");
     const bool opT = (flags & FLAG_OPT) != 0;
@@ -427,14 +432,14 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((!TRN 
                  const int *__restrict__ cols, const T *__restrict__ x, T *__restrict__ y, T alpha,
                  T beta, int flags, unsigned wg_base, T *__restrict__ ws, long long ws_fbase) {
     constexpr int E = TT<T>::E;
-    constexpr int XS = x_chunk_cols<T>();              // staged x slice per wave
+    constexpr int XS = x_chunk_cols<T, TRN>();         // staged x slice per wave
     constexpr int VS = 8 * L * E;                      // transposed sums of one iteration
     __shared__ __attribute__((aligned(16))) T xs[kWavesPerWg][FWD ? XS : 1];
     __shared__ __attribute__((aligned(16))) T vs[kWavesPerWg][TRN ? VS : 1];
     __shared__ T red[kWavesPerWg][64];
     // y window of workgroups that pack neighbouring small row groups of a symmetric operator
     constexpr bool WIN = FWD && TRN;
-    __shared__ T win[WIN ? kWindowEntries : 1];
+    __shared__ T win[WIN ? window_entries((int)sizeof(T)) : 1];
 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
