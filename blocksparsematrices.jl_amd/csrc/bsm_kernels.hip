@@ -424,10 +424,14 @@ __device__ __forceinline__ T run_panel(const WaveD &wd, const uint4 *__restrict_
     return a;
 }
 
-// forward-only instances are held to 80 VGPRs (6 waves per SIMD = 1536 resident workgroups:
-// every workgroup of a C2-sized launch is resident at once); the fused instances need ~100.
+// fp64 forward-only instances are held to 80 VGPRs (6 waves per SIMD = 1536 resident workgroups:
+// every workgroup of a C2-sized launch is resident at once), and so are the complex128 ones (the
+// fused instance then parks 8 bytes per lane in scratch and still gains 5 % on BEM-shaped
+// operators: small panels are a chain of dependent round trips, hidden only by resident waves).
+// The same cap on the fp64 fused instance (80 VGPRs as compiled; 72 with 24 bytes of scratch) loses.
 template <typename T, int L, bool FWD, bool TRN>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((!TRN && std::is_same<T, double>::value) ? 6 : 4)))
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(
+    ((!TRN && std::is_same<T, double>::value) || std::is_same<T, c128>::value) ? 6 : 4)))
     panel_kernel(const WaveWork *__restrict__ waves, const uint4 *__restrict__ values, const int *__restrict__ rows,
                  const int *__restrict__ cols, const T *__restrict__ x, T *__restrict__ y, T alpha,
                  T beta, int flags, unsigned wg_base, T *__restrict__ ws, long long ws_fbase) {
