@@ -1,0 +1,78 @@
+# Tests of the ROCm binding, written against the same independent check the reference's own test
+# files use (sparse(A) * x with the COO triples of src/sparse.jl) -- NOT EXECUTED in this
+# repository (no Julia toolchain in the build image); the Python suite tests/test_reference_suite_mirror.py
+# runs the same statements through the same C entry points.
+#
+#   julia --project -e 'include("julia/test/runtests.jl")'      (needs BlockSparseMatrices, LinearMaps,
+#                                                                  BSM_ROCM_LIB=/path/to/libbsmrocm.so)
+using Test, LinearAlgebra, SparseArrays, Random
+using BlockSparseMatrices
+include(joinpath(@__DIR__, "..", "BlockSparseMatricesROCm.jl"))
+using .BlockSparseMatricesROCm: ROCmScheduler
+
+relmax(a, b) = maximum(abs.(a .- b)) / maximum(abs.(b))
+
+@testset "VBCRS on the GPU ($T)" for T in (Float64, Float32, ComplexF64)
+    Random.seed!(1)
+    n = 6_000
+    cuts = sort(unique(vcat(1, rand(2:n, 250), n + 1)))          # consecutive segments
+    segs = [cuts[k]:(cuts[k + 1] - 1) for k in 1:(length(cuts) - 1)]
+    pairs = unique([(rand(1:length(segs)), rand(1:length(segs))) for _ in 1:400])
+    blocks = [randn(T, length(segs[i]), length(segs[j])) for (i, j) in pairs]
+    r0 = [first(segs[i]) for (i, _) in pairs]
+    c0 = [first(segs[j]) for (_, j) in pairs]
+    cpu = VariableBlockCompressedRowStorage(blocks, r0, c0, (n, n))
+    gpu = VariableBlockCompressedRowStorage(blocks, r0, c0, (n, n); scheduler=ROCmScheduler())
+    @test gpu.rowptr == cpu.rowptr && gpu.colindices == cpu.colindices && gpu.rowindices == cpu.rowindices
+    S = sparse(cpu)
+    tol = T === Float32 ? 1f-5 : 1e-12
+    for _ in 1:5
+        x = randn(T, n); y = randn(T, n)
+        @test relmax(gpu * x, S * x) < tol
+        @test relmax(gpu' * x, S' * x) < tol
+        @test relmax(transpose(gpu) * x, transpose(S) * x) < tol
+        α, β = T(0.5), T(-2)
+        @test relmax(mul!(copy(y), gpu, x, α, β), α * (S * x) + β * y) < tol
+        @test relmax(mul!(fill(T(NaN), n), gpu, x, true, false), S * x) < tol   # strong zero
+        X = randn(T, n, 5)
+        @test relmax(gpu * X, S * X) < tol                                       # bsm_mul_multi
+    end
+    @test nnz(gpu) == nnz(cpu)
+end
+
+@testset "BlockSparseMatrix / SymmetricBlockMatrix on the GPU" begin
+    Random.seed!(2)
+    n = 3_000
+    lists() = sort(randperm(n)[1:rand(3:28)])
+    blocks = [randn(ComplexF64, 0, 0) for _ in 1:0]
+    ri = Vector{Vector{Int}}(); ci = Vector{Vector{Int}}()
+    for _ in 1:200
+        r, c = lists(), lists()
+        push!(blocks, randn(ComplexF64, length(r), length(c))); push!(ri, r); push!(ci, c)
+    end
+    A = BlockSparseMatrix(blocks, ri, ci, (n, n); scheduler=ROCmScheduler())
+    S = sparse(BlockSparseMatrix(blocks, ri, ci, (n, n)))
+    for _ in 1:5
+        x = randn(ComplexF64, n); y = randn(ComplexF64, n)
+        @test A * x ≈ S * x
+        @test A' * x ≈ S' * x
+        @test transpose(A) * x ≈ transpose(S) * x
+        @test mul!(copy(y), A, x, im, 2im) ≈ im * (S * x) + 2im * y
+    end
+    # symmetric: disjoint diagonal index sets, off-diagonal blocks between different sets
+    perm = randperm(n); sets = [sort(perm[(20k + 1):(20k + 20)]) for k in 0:(n ÷ 20 - 1)]
+    D = [(d = randn(ComplexF64, 20, 20); (d + transpose(d)) / 2) for _ in sets]
+    offp = unique([(i, j) for (i, j) in ((rand(2:length(sets)), 1) for _ in 1:300) if true])
+    offp = [(i, rand(1:(i - 1))) for (i, _) in offp]
+    O = [randn(ComplexF64, 20, 20) for _ in offp]
+    sym(s) = SymmetricBlockMatrix(D, sets, O, [sets[i] for (i, _) in offp], [sets[j] for (_, j) in offp], (n, n); scheduler=s)
+    G = sym(ROCmScheduler()); Sg = sparse(sym(BlockSparseMatrices.SerialScheduler()))
+    @test issymmetric(Sg)
+    for _ in 1:5
+        x = randn(ComplexF64, n); y = randn(ComplexF64, n)
+        @test G * x ≈ Sg * x
+        @test G' * x ≈ Sg' * x
+        @test mul!(copy(y), G, x, im, 2im) ≈ im * (Sg * x) + 2im * y
+    end
+    @test nnz(G) == nnz(Sg)
+end
