@@ -44,7 +44,7 @@ end
     Random.seed!(2)
     n = 3_000
     lists() = sort(randperm(n)[1:rand(3:28)])
-    blocks = [randn(ComplexF64, 0, 0) for _ in 1:0]
+    blocks = Matrix{ComplexF64}[]
     ri = Vector{Vector{Int}}(); ci = Vector{Vector{Int}}()
     for _ in 1:200
         r, c = lists(), lists()
@@ -62,8 +62,7 @@ end
     # symmetric: disjoint diagonal index sets, off-diagonal blocks between different sets
     perm = randperm(n); sets = [sort(perm[(20k + 1):(20k + 20)]) for k in 0:(n ÷ 20 - 1)]
     D = [(d = randn(ComplexF64, 20, 20); (d + transpose(d)) / 2) for _ in sets]
-    offp = unique([(i, j) for (i, j) in ((rand(2:length(sets)), 1) for _ in 1:300) if true])
-    offp = [(i, rand(1:(i - 1))) for (i, _) in offp]
+    offp = unique([(i, rand(1:(i - 1))) for i in rand(2:length(sets), 300)])
     O = [randn(ComplexF64, 20, 20) for _ in offp]
     sym(s) = SymmetricBlockMatrix(D, sets, O, [sets[i] for (i, _) in offp], [sets[j] for (_, j) in offp], (n, n); scheduler=s)
     G = sym(ROCmScheduler()); Sg = sparse(sym(BlockSparseMatrices.SerialScheduler()))
