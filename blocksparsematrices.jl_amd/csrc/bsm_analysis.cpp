@@ -27,6 +27,7 @@ Tunables Tunables::from_env() {
     t.pack_threads = (int)geti("BSM_PACK_THREADS", t.pack_threads);
     t.wg_order = (int)geti("BSM_ORDER", t.wg_order);
     t.lds_window = (int)geti("BSM_WINDOW", t.lds_window);
+    t.window_bytes = (size_t)geti("BSM_UPLOAD_WINDOW_BYTES", (int64_t)t.window_bytes);
     if (t.pack_threads < 1) t.pack_threads = 1;
     return t;
 }
@@ -470,43 +471,79 @@ std::string Analysis::build(int mtype_, int dtype_, int64_t nrows_, int64_t ncol
 
     lap("exclusivity / fused colours");
     // ---- pack values ---------------------------------------------------------------------
-    values.allocate((size_t)val_units * 16);
-    for (const Group &G : groups) {  // zero the padded tail of every panel's last strip
-        const int64_t padcols = G.strips * E - G.width;
-        if (padcols > 0) {
-            char *last = values.data() + ((size_t)G.val_off + (size_t)(G.strips - 1) * G.mc) * 16;
-            std::memset(last, 0, (size_t)G.mc * 16);
+    value_bytes = (int64_t)val_units * 16;
+    auto pack_one = [&](const Chunk &c, char *dst) {  // dst: first byte of the chunk's row group panel
+        const BlockIn &B = blocks[c.blk];
+        if (group_perm[c.group]) {
+            const int32_t *dp = colpos.data() + groups[c.group].col_off + c.woff;
+            if (es == 4)
+                pack_chunk_perm<uint32_t>((const uint32_t *)B.data, B.ld, c.ra, c.mc, B.n, dp, E, B.trans, (uint32_t *)dst);
+            else if (es == 8)
+                pack_chunk_perm<uint64_t>((const uint64_t *)B.data, B.ld, c.ra, c.mc, B.n, dp, E, B.trans, (uint64_t *)dst);
+            else
+                pack_chunk_perm<U16>((const U16 *)B.data, B.ld, c.ra, c.mc, B.n, dp, E, B.trans, (U16 *)dst);
+            return;
         }
-    }
-    {
-        const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(tun.pack_threads, (int64_t)chunks.size() / 64 + 1));
+        if (es == 4)
+            pack_chunk<uint32_t>((const uint32_t *)B.data, B.ld, c.ra, c.mc, B.n, c.woff, E, B.trans, (uint32_t *)dst);
+        else if (es == 8)
+            pack_chunk<uint64_t>((const uint64_t *)B.data, B.ld, c.ra, c.mc, B.n, c.woff, E, B.trans, (uint64_t *)dst);
+        else
+            pack_chunk<U16>((const U16 *)B.data, B.ld, c.ra, c.mc, B.n, c.woff, E, B.trans, (U16 *)dst);
+    };
+    // packs the chunks `ids` (all of them when null); base = address of stream byte `wbase`
+    auto pack_many = [&](const std::vector<int32_t> *ids, size_t nchunks, char *base, size_t wbase) {
+        const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(tun.pack_threads, (int64_t)nchunks / 64 + 1));
         auto worker = [&](int t) {
-            for (size_t ci = t; ci < chunks.size(); ci += nt) {
-                const Chunk &c = chunks[ci];
-                const BlockIn &B = blocks[c.blk];
-                char *dst = values.data() + (size_t)groups[c.group].val_off * 16;
-                if (group_perm[c.group]) {
-                    const int32_t *dp = colpos.data() + groups[c.group].col_off + c.woff;
-                    if (es == 4)
-                        pack_chunk_perm<uint32_t>((const uint32_t *)B.data, B.ld, c.ra, c.mc, B.n, dp, E, B.trans, (uint32_t *)dst);
-                    else if (es == 8)
-                        pack_chunk_perm<uint64_t>((const uint64_t *)B.data, B.ld, c.ra, c.mc, B.n, dp, E, B.trans, (uint64_t *)dst);
-                    else
-                        pack_chunk_perm<U16>((const U16 *)B.data, B.ld, c.ra, c.mc, B.n, dp, E, B.trans, (U16 *)dst);
-                    continue;
-                }
-                if (es == 4)
-                    pack_chunk<uint32_t>((const uint32_t *)B.data, B.ld, c.ra, c.mc, B.n, c.woff, E, B.trans, (uint32_t *)dst);
-                else if (es == 8)
-                    pack_chunk<uint64_t>((const uint64_t *)B.data, B.ld, c.ra, c.mc, B.n, c.woff, E, B.trans, (uint64_t *)dst);
-                else
-                    pack_chunk<U16>((const U16 *)B.data, B.ld, c.ra, c.mc, B.n, c.woff, E, B.trans, (U16 *)dst);
+            for (size_t k = t; k < nchunks; k += nt) {
+                const Chunk &c = chunks[ids ? (size_t)(*ids)[k] : k];
+                pack_one(c, base + ((size_t)groups[c.group].val_off * 16 - wbase));
             }
         };
         std::vector<std::thread> th;
         for (int t = 1; t < nt; t++) th.emplace_back(worker, t);
         worker(0);
         for (auto &x : th) x.join();
+    };
+    auto zero_tail = [&](const Group &G, char *base, size_t wbase) {  // padded tail of a panel's last strip
+        if (G.strips * E - G.width > 0)
+            std::memset(base + (((size_t)G.val_off + (size_t)(G.strips - 1) * G.mc) * 16 - wbase), 0, (size_t)G.mc * 16);
+    };
+    bool streamed = false;
+    if (opt.sink) {
+        std::string err = opt.sink->begin((size_t)value_bytes, &streamed);
+        if (!err.empty()) return err;
+    }
+    if (streamed) {
+        // row groups are laid out in index order: windows of consecutive groups, packed into the
+        // sink's staging buffer by all threads, shipped while the next window is being packed
+        std::vector<int32_t> ids;
+        size_t g0 = 0;
+        while (g0 < groups.size()) {
+            const size_t wbase = (size_t)groups[g0].val_off * 16;
+            size_t g1 = g0, wbytes = 0;
+            while (g1 < groups.size() && (g1 == g0 || wbytes + (size_t)groups[g1].mc * groups[g1].strips * 16 <= tun.window_bytes)) {
+                wbytes += (size_t)groups[g1].mc * (size_t)groups[g1].strips * 16;
+                g1++;
+            }
+            char *buf = opt.sink->window(wbytes);
+            if (!buf) return "value sink: no staging buffer";
+            ids.clear();
+            for (size_t g = g0; g < g1; g++) {
+                zero_tail(groups[g], buf, wbase);
+                ids.insert(ids.end(), groups[g].chunks.begin(), groups[g].chunks.end());
+            }
+            pack_many(&ids, ids.size(), buf, wbase);
+            std::string err = opt.sink->commit(wbase, wbytes);
+            if (!err.empty()) return err;
+            g0 = g1;
+        }
+        std::string err = opt.sink->end();
+        if (!err.empty()) return err;
+    } else {
+        values.allocate((size_t)val_units * 16);
+        for (const Group &G : groups) zero_tail(G, values.data(), 0);
+        pack_many(nullptr, chunks.size(), values.data(), 0);
     }
 
     lap("pack values");

@@ -56,9 +56,22 @@ struct Tunables {
     int64_t split4_bytes = 24 << 10;    // ... and 4 waves
     int64_t wgitem_max_bytes = 256 << 10;  // non-exclusive groups are cut into items this big
     int pack_threads = 8;
+    size_t window_bytes = 64u << 20;  // staging window of a streamed upload (BSM_UPLOAD_WINDOW_BYTES)
     int lds_window = 1;  // LDS y window for locality-packed small symmetric row groups (BSM_WINDOW)
     int wg_order = 0;  // experimental workgroup dispatch orders (BSM_ORDER)
     static Tunables from_env();
+};
+
+// Receives the packed value stream window by window in ascending offset order, instead of one host
+// buffer holding the whole operator (device handles: pinned staging + asynchronous upload, see
+// bsm_capi.cpp).  Every method returns "" on success, else an error message.
+struct ValueSink {
+    virtual ~ValueSink() = default;
+    // total size of the stream; *use = false declines (the analysis then packs into Analysis::values)
+    virtual std::string begin(size_t total_bytes, bool *use) = 0;
+    virtual char *window(size_t bytes) = 0;  // writable staging for the next window, nullptr on failure
+    virtual std::string commit(size_t offset, size_t bytes) = 0;  // the window is complete: ship it
+    virtual std::string end() = 0;                                // every window has arrived
 };
 
 struct AnalysisOptions {
@@ -66,6 +79,7 @@ struct AnalysisOptions {
     int validate = 1;
     int accumulate = 0;  // 0 auto, 1 atomic, 2 coloured launches, 3 gather (both bitwise reproducible)
     int64_t own_lo = 0, own_hi = 0;  // 1-based inclusive, 0,0 = all rows
+    ValueSink *sink = nullptr;       // not owned; nullptr: pack into Analysis::values
 };
 
 // Deterministic DSATUR colouring of blocks by index-list conflicts (two blocks conflict
@@ -89,7 +103,8 @@ class Analysis {
     int64_t nnz = 0, stored_entries = 0, alg_bytes = 0;
 
     // ---- device image (host copy) ----
-    RawBuffer values;
+    RawBuffer values;          // empty when the stream went to AnalysisOptions::sink
+    int64_t value_bytes = 0;   // size of the packed value stream
     std::vector<int32_t> rows, cols;
     std::vector<WaveWork> waves;
     int64_t nwg_main = 0;   // workgroups holding panel work

@@ -3,6 +3,7 @@
 // packed image and forwards bsm_mul to the HIP launchers.  Never throws across the ABI.
 #include <hip/hip_runtime_api.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -151,6 +152,83 @@ template <typename V> hipError_t upload(const V &v, void **dptr, long long &tota
     return e;
 }
 
+// Streams the packed values to the device while they are being packed: two pinned staging windows
+// (kept for the life of the process: pinning 2 x 64 MiB costs more than packing a C2-sized operator)
+// and asynchronous copies on a private stream.  Small operators decline and take the one-shot path.
+struct PinnedPool {
+    std::mutex mu;  // one streamed create at a time per process
+    char *buf[2] = {nullptr, nullptr};
+    size_t cap[2] = {0, 0};
+};
+PinnedPool g_pool;
+size_t stream_min_bytes() {  // BSM_STREAM_MIN_BYTES: smaller operators take the one-shot upload
+    const char *e = std::getenv("BSM_STREAM_MIN_BYTES");
+    return (e && *e) ? (size_t)std::strtoull(e, nullptr, 10) : ((size_t)128 << 20);
+}
+
+struct DeviceSink : ValueSink {
+    void **dptr;
+    std::unique_lock<std::mutex> lock;
+    hipStream_t st = nullptr;
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    bool pending[2] = {false, false};
+    int k = 0;
+    bool active = false;
+    explicit DeviceSink(void **d) : dptr(d) {}
+    static std::string msg(hipError_t e, const char *what) { return std::string(what) + ": " + hipGetErrorString(e); }
+    std::string begin(size_t total, bool *use) override {
+        *use = false;
+        if (total == 0 || total < stream_min_bytes()) return "";
+        lock = std::unique_lock<std::mutex>(g_pool.mu);
+        hipError_t e = hipMalloc(dptr, total);
+        if (e != hipSuccess) return msg(e, "hipMalloc(values)");
+        e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+        for (int i = 0; i < 2 && e == hipSuccess; i++) e = hipEventCreateWithFlags(&ev[i], hipEventDisableTiming);
+        if (e != hipSuccess) return msg(e, "upload stream");
+        active = *use = true;
+        return "";
+    }
+    char *window(size_t bytes) override {
+        const int i = k & 1;
+        if (pending[i]) {
+            if (hipEventSynchronize(ev[i]) != hipSuccess) return nullptr;
+            pending[i] = false;
+        }
+        if (g_pool.cap[i] < bytes) {
+            if (g_pool.buf[i]) (void)hipHostFree(g_pool.buf[i]);
+            g_pool.buf[i] = nullptr;
+            g_pool.cap[i] = 0;
+            const size_t want = std::max<size_t>(bytes, 64u << 20);
+            if (hipHostMalloc((void **)&g_pool.buf[i], want, hipHostMallocDefault) != hipSuccess) return nullptr;
+            g_pool.cap[i] = want;
+        }
+        return g_pool.buf[i];
+    }
+    std::string commit(size_t offset, size_t bytes) override {
+        const int i = k & 1;
+        hipError_t e = hipMemcpyAsync((char *)*dptr + offset, g_pool.buf[i], bytes, hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) e = hipEventRecord(ev[i], st);
+        if (e != hipSuccess) return msg(e, "streamed upload");
+        pending[i] = true;
+        k++;
+        return "";
+    }
+    std::string end() override {
+        hipError_t e = hipStreamSynchronize(st);
+        pending[0] = pending[1] = false;
+        if (lock.owns_lock()) lock.unlock();  // the staging windows are free for the next create
+        return e == hipSuccess ? "" : msg(e, "streamed upload");
+    }
+    ~DeviceSink() override {
+        if (st) {
+            (void)hipStreamSynchronize(st);  // the staging buffers go back to the pool idle
+            (void)hipStreamDestroy(st);
+        }
+        for (auto &e : ev)
+            if (e) (void)hipEventDestroy(e);
+    }
+};
+
 void free_image(DeviceImage &img) {
     for (void **p : {&img.d_values, &img.d_rows, &img.d_cols, &img.d_waves, &img.d_ws, &img.d_inv_ptr[0],
                      &img.d_inv_ptr[1], &img.d_inv_idx[0], &img.d_inv_idx[1]}) {
@@ -173,7 +251,7 @@ void fill_image(const Analysis &an, const bsm_options &o, bool use_own, DeviceIm
         if (w.work == WORK_PANEL && w.npieces > 0 && (w.first.kind & kKindHasOff)) img.has_off = true;
     if (!img.exclusive_fwd) img.nwg_total = img.nwg_main;
     img.color_wg_ptr.assign(an.color_wg_ptr.begin(), an.color_wg_ptr.end());
-    img.device_bytes = (long long)(an.values.size() + an.rows.size() * 4 + an.cols.size() * 4 +
+    img.device_bytes = (long long)((size_t)an.value_bytes + an.rows.size() * 4 + an.cols.size() * 4 +
                                    an.waves.size() * sizeof(WaveWork));
     if (an.gather)
         img.device_bytes += (long long)((an.ws_slots + 8) * an.es + (an.inv_ptr[0].size() + an.inv_ptr[1].size()) * 8 +
@@ -183,7 +261,11 @@ void fill_image(const Analysis &an, const bsm_options &o, bool use_own, DeviceIm
 hipError_t upload_image(Analysis &an, DeviceImage &img, int dev) {
     img.device = dev;
     long long total = 0;
-    hipError_t e = upload(an.values, &img.d_values, total);
+    hipError_t e = hipSuccess;
+    if (img.d_values)  // the packer streamed them (DeviceSink)
+        total += an.value_bytes;
+    else
+        e = upload(an.values, &img.d_values, total);
     if (e == hipSuccess) e = upload(an.rows, &img.d_rows, total);
     if (e == hipSuccess) e = upload(an.cols, &img.d_cols, total);
     if (e == hipSuccess) e = upload(an.waves, &img.d_waves, total);
@@ -204,42 +286,59 @@ hipError_t upload_image(Analysis &an, DeviceImage &img, int dev) {
     return e;
 }
 
-int finish_create(bsm_matrix_s *A, const bsm_options &o, bsm_matrix_t *out) {
+// Device side of a *_create call: the target device is made current BEFORE the analysis runs, so
+// that the packer can stream the values to it (DeviceSink) instead of building a host copy first.
+struct CreateCtx {
+    bsm_matrix_s *A;  // owned until release(): any early return or exception frees it, device side included
+    int dev = BSM_DEVICE_NONE;
+    DeviceGuard guard;
+    DeviceSink sink, sink_t;
+    CreateCtx() : A(new bsm_matrix_s()), sink(&A->img.d_values), sink_t(&A->img_t.d_values) {}
+    CreateCtx(const CreateCtx &) = delete;
+    ~CreateCtx() {
+        if (!A) return;
+        free_image(A->img);  // the handle's device is still current (guard outlives this body)
+        free_image(A->img_t);
+        delete A;
+    }
+    bsm_matrix_s *release() {
+        bsm_matrix_s *p = A;
+        A = nullptr;
+        return p;
+    }
+    int open(const bsm_options &o) {
+        if (o.device == BSM_DEVICE_NONE) return BSM_OK;
+        dev = o.device;
+        if (dev == BSM_DEVICE_CURRENT) {
+            hipError_t e = hipGetDevice(&dev);
+            if (e != hipSuccess) return hip_fail(e, "hipGetDevice");
+        }
+        hipError_t e = guard.enter(dev);
+        if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
+        return BSM_OK;
+    }
+    ValueSink *values() { return dev == BSM_DEVICE_NONE ? nullptr : &sink; }
+    ValueSink *values_t() { return dev == BSM_DEVICE_NONE ? nullptr : &sink_t; }
+};
+
+int finish_create(CreateCtx &cx, const bsm_options &o, bsm_matrix_t *out) {
+    bsm_matrix_s *A = cx.A;
     fill_image(A->an, o, true, A->img);
     if (A->has_t) fill_image(A->an_t, o, false, A->img_t);
-    if (o.device != BSM_DEVICE_NONE) {
-        int dev = o.device;
-        hipError_t e;
-        if (dev == BSM_DEVICE_CURRENT) {
-            e = hipGetDevice(&dev);
-            if (e != hipSuccess) {
-                delete A;
-                return hip_fail(e, "hipGetDevice");
-            }
-        }
-        DeviceGuard guard;
-        e = guard.enter(dev);
-        if (e != hipSuccess) {
-            delete A;
-            return hip_fail(e, "hipSetDevice");
-        }
-        e = upload_image(A->an, A->img, dev);
-        if (e == hipSuccess && A->has_t) e = upload_image(A->an_t, A->img_t, dev);
-        if (e != hipSuccess) {
-            free_image(A->img);
-            free_image(A->img_t);
-            delete A;
-            return hip_fail(e, "device upload");
-        }
+    if (cx.dev != BSM_DEVICE_NONE) {
+        hipError_t e = upload_image(A->an, A->img, cx.dev);
+        if (e == hipSuccess && A->has_t) e = upload_image(A->an_t, A->img_t, cx.dev);
+        if (e != hipSuccess) return hip_fail(e, "device upload");
         A->on_device = true;
     }
-    *out = A;
+    *out = cx.release();
     return BSM_OK;
 }
 
 // Second ordering: the transposed operator as a forward image (rows <-> columns, blocks read
 // transposed by the packer).  Built from the same caller arrays, before they are released.
-std::string build_transpose_image(bsm_matrix_s *A, const std::vector<BlockIn> &in, const bsm_options &o) {
+std::string build_transpose_image(bsm_matrix_s *A, const std::vector<BlockIn> &in, const bsm_options &o,
+                                  ValueSink *sink) {
     std::vector<BlockIn> t(in.size());
     for (size_t b = 0; b < in.size(); b++) {
         const BlockIn &B = in[b];
@@ -258,13 +357,15 @@ std::string build_transpose_image(bsm_matrix_s *A, const std::vector<BlockIn> &i
     AnalysisOptions a;
     a.scheduler = 0;
     a.accumulate = o.accumulate;
+    a.sink = sink;
     std::string err = A->an_t.build(MT_BLOCKSPARSE, A->an.dtype, A->an.ncols, A->an.nrows, t, a);
     if (err.empty()) A->has_t = true;
     return err;
 }
 
-AnalysisOptions to_aopt(const bsm_options &o) {
+AnalysisOptions to_aopt(const bsm_options &o, ValueSink *sink) {
     AnalysisOptions a;
+    a.sink = sink;
     a.scheduler = o.scheduler;
     a.validate = 1;  // indices are always range-checked: a bad index must never reach a kernel
     a.accumulate = o.accumulate;
@@ -288,9 +389,11 @@ extern "C" int bsm_vbcrs_create(int dtype, int64_t nrows, int64_t ncols, int64_t
         bsm_options o;
         int rc = read_options(opts, o);
         if (rc) return rc;
-        bsm_matrix_s *A = new bsm_matrix_s();
+        CreateCtx cx;
+        if ((rc = cx.open(o)) != BSM_OK) return rc;
+        bsm_matrix_s *A = cx.A;
         std::string err = A->an.build_vbcrs(dtype, nrows, ncols, nblocks, blocks, m, n, ld, rowstart,
-                                            colstart, to_aopt(o));
+                                            colstart, to_aopt(o, cx.values()));
         if (err.empty() && o.transpose_image) {
             std::vector<BlockIn> in((size_t)nblocks);
             for (int64_t b = 0; b < nblocks; b++) {
@@ -304,13 +407,10 @@ extern "C" int bsm_vbcrs_create(int dtype, int64_t nrows, int64_t ncols, int64_t
                 B.c0 = colstart[b];
                 B.kind = KIND_PLAIN;
             }
-            err = build_transpose_image(A, in, o);
+            err = build_transpose_image(A, in, o, cx.values_t());
         }
-        if (!err.empty()) {
-            delete A;
-            return fail(BSM_ERR_INVALID, err);
-        }
-        return finish_create(A, o, out);
+        if (!err.empty()) return fail(BSM_ERR_INVALID, err);
+        return finish_create(cx, o, out);
     } catch (const std::bad_alloc &) {
         return fail(BSM_ERR_ALLOC, "out of host memory");
     } catch (const std::exception &e) {
@@ -335,15 +435,14 @@ extern "C" int bsm_vbcrs_create_from_symmetric(int dtype, int64_t nrows, int64_t
         bsm_options o;
         int rc = read_options(opts, o);
         if (rc) return rc;
-        bsm_matrix_s *A = new bsm_matrix_s();
+        CreateCtx cx;
+        if ((rc = cx.open(o)) != BSM_OK) return rc;
+        bsm_matrix_s *A = cx.A;
         std::string err = A->an.build_vbcrs_symmetric_view(dtype, nrows, ncols, ndiag, diag, dsize, dld,
                                                            diagstart, noff, off, m, n, ld, rowstart,
-                                                           colstart, to_aopt(o));
-        if (!err.empty()) {
-            delete A;
-            return fail(BSM_ERR_INVALID, err);
-        }
-        return finish_create(A, o, out);
+                                                           colstart, to_aopt(o, cx.values()));
+        if (!err.empty()) return fail(BSM_ERR_INVALID, err);
+        return finish_create(cx, o, out);
     } catch (const std::bad_alloc &) {
         return fail(BSM_ERR_ALLOC, "out of host memory");
     } catch (const std::exception &e) {
@@ -379,14 +478,13 @@ extern "C" int bsm_blocksparse_create(int dtype, int64_t nrows, int64_t ncols, i
             if ((B.m > 0 && !B.ridx) || (B.n > 0 && !B.cidx))
                 return fail(BSM_ERR_INVALID, "block " + std::to_string(b + 1) + ": null index list");
         }
-        bsm_matrix_s *A = new bsm_matrix_s();
-        std::string err = A->an.build(MT_BLOCKSPARSE, dtype, nrows, ncols, in, to_aopt(o));
-        if (err.empty() && o.transpose_image) err = build_transpose_image(A, in, o);
-        if (!err.empty()) {
-            delete A;
-            return fail(BSM_ERR_INVALID, err);
-        }
-        return finish_create(A, o, out);
+        CreateCtx cx;
+        if ((rc = cx.open(o)) != BSM_OK) return rc;
+        bsm_matrix_s *A = cx.A;
+        std::string err = A->an.build(MT_BLOCKSPARSE, dtype, nrows, ncols, in, to_aopt(o, cx.values()));
+        if (err.empty() && o.transpose_image) err = build_transpose_image(A, in, o, cx.values_t());
+        if (!err.empty()) return fail(BSM_ERR_INVALID, err);
+        return finish_create(cx, o, out);
     } catch (const std::bad_alloc &) {
         return fail(BSM_ERR_ALLOC, "out of host memory");
     } catch (const std::exception &e) {
@@ -439,13 +537,12 @@ extern "C" int bsm_symmetric_create(int dtype, int64_t nrows, int64_t ncols, int
                 return fail(BSM_ERR_INVALID, "off-diagonal block " + std::to_string(b + 1) + ": null index list");
             in.push_back(B);
         }
-        bsm_matrix_s *A = new bsm_matrix_s();
-        std::string err = A->an.build(MT_SYMMETRIC, dtype, nrows, ncols, in, to_aopt(o));
-        if (!err.empty()) {
-            delete A;
-            return fail(BSM_ERR_INVALID, err);
-        }
-        return finish_create(A, o, out);
+        CreateCtx cx;
+        if ((rc = cx.open(o)) != BSM_OK) return rc;
+        bsm_matrix_s *A = cx.A;
+        std::string err = A->an.build(MT_SYMMETRIC, dtype, nrows, ncols, in, to_aopt(o, cx.values()));
+        if (!err.empty()) return fail(BSM_ERR_INVALID, err);
+        return finish_create(cx, o, out);
     } catch (const std::bad_alloc &) {
         return fail(BSM_ERR_ALLOC, "out of host memory");
     } catch (const std::exception &e) {

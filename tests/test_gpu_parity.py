@@ -599,3 +599,16 @@ def test_gather_mode_two_streams_share_one_workspace(torch_cuda, bsm, oracle):
     torch.cuda.synchronize()
     for k in range(2):
         assert relerr(yd[k].cpu().numpy(), refs[k]) < 1e-12
+
+
+def test_streamed_upload_matches_one_shot_upload(torch_cuda, bsm, oracle, monkeypatch):
+    # large operators are packed window by window into pinned staging and copied while the next
+    # window is packed (bsm_capi.cpp DeviceSink); forced here on small operators with tiny windows
+    monkeypatch.setenv("BSM_STREAM_MIN_BYTES", "1")
+    monkeypatch.setenv("BSM_UPLOAD_WINDOW_BYTES", "20000")
+    for p, dt, kw in ((bsm.synthetic.config2(n=20000, nblocks=900), np.float64, {"transpose_image": True}),
+                      (bsm.synthetic.config5(n=30000, lo=8, hi=90, halfband=3), np.float64, {}),
+                      (fixture_problem("cuboid"), np.complex128, {"accumulate": "gather"}),
+                      (bsm.synthetic.config1(), np.float64, {})):
+        A = bsm.synthetic.build(p, **kw)
+        check_all(torch_cuda, bsm, oracle, p, A, dt, host_too=False)
