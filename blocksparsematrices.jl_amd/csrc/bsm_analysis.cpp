@@ -470,6 +470,65 @@ std::string Analysis::build(int mtype_, int dtype_, int64_t nrows_, int64_t ncol
     }
 
     lap("exclusivity / fused colours");
+    // ---- colouring (reference bookkeeping) ---------------------------------------------------
+    // Independent of everything the GPU path needs (it only reads the caller's index lists and
+    // fills `colors`): runs on its own thread while the values are packed and uploaded.
+    bool colour_oom = false;
+    auto reference_colourings = [&]() {
+        try {
+            for (auto &c : colors) c.clear();
+            auto single = [](int64_t n) {
+                std::vector<std::vector<int64_t>> out(1);
+                out[0].resize(n);
+                std::iota(out[0].begin(), out[0].end(), (int64_t)1);
+                return out;
+            };
+            if (mtype == MT_BLOCKSPARSE) {
+                if (opt.scheduler == 0) {  // reference src/blockmatrix.jl:91-92
+                    colors[0] = single(nb);
+                    colors[1] = single(nb);
+                } else {  // src/blockmatrix.jl:94-98
+                    std::vector<const int64_t *> rl(nb), cl(nb);
+                    std::vector<int64_t> rn(nb), cn(nb);
+                    for (int64_t b = 0; b < nb; b++) {
+                        rl[b] = blocks[b].ridx;
+                        rn[b] = blocks[b].ridx ? blocks[b].m : 0;
+                        cl[b] = blocks[b].cidx;
+                        cn[b] = blocks[b].cidx ? blocks[b].n : 0;
+                    }
+                    colors[0] = color_dsatur(rl, rn);
+                    colors[1] = color_dsatur(cl, cn);
+                }
+            } else if (mtype == MT_SYMMETRIC) {
+                // always three colourings, also for the serial scheduler: src/symmetricblockmatrix.jl:104-110
+                std::vector<const int64_t *> dl, rl, cl;
+                std::vector<int64_t> dn, rn, cn;
+                for (const BlockIn &B : blocks) {
+                    if (B.kind == KIND_DIAG) {
+                        dl.push_back(B.ridx);
+                        dn.push_back(B.ridx ? B.m : 0);
+                    } else {
+                        rl.push_back(B.ridx);
+                        rn.push_back(B.ridx ? B.m : 0);
+                        cl.push_back(B.cidx);
+                        cn.push_back(B.cidx ? B.n : 0);
+                    }
+                }
+                colors[0] = color_dsatur(rl, rn);
+                colors[1] = color_dsatur(cl, cn);
+                colors[2] = color_dsatur(dl, dn);
+            }
+        } catch (const std::bad_alloc &) {
+            colour_oom = true;
+        }
+    };
+    std::thread colour_thread(reference_colourings);
+    struct Joiner {
+        std::thread &t;
+        ~Joiner() {
+            if (t.joinable()) t.join();
+        }
+    } colour_join{colour_thread};  // also on the error returns below
     // ---- pack values ---------------------------------------------------------------------
     value_bytes = (int64_t)val_units * 16;
     auto pack_one = [&](const Chunk &c, char *dst) {  // dst: first byte of the chunk's row group panel
@@ -850,50 +909,9 @@ std::string Analysis::build(int mtype_, int dtype_, int64_t nrows_, int64_t ncol
             for (int64_t q = 0; q < G.width; q++)
                 if (ckind[G.col_off + q] == KIND_DIAG) cols[G.col_off + q] = (int32_t)((uint32_t)cols[G.col_off + q] | kColDiagBit);
     lap("schedule");
-    // ---- colouring (reference bookkeeping) ---------------------------------------------------
-    for (auto &c : colors) c.clear();
-    auto single = [](int64_t n) {
-        std::vector<std::vector<int64_t>> out(1);
-        out[0].resize(n);
-        std::iota(out[0].begin(), out[0].end(), (int64_t)1);
-        return out;
-    };
-    if (mtype == MT_BLOCKSPARSE) {
-        if (opt.scheduler == 0) {  // reference src/blockmatrix.jl:91-92
-            colors[0] = single(nb);
-            colors[1] = single(nb);
-        } else {  // src/blockmatrix.jl:94-98
-            std::vector<const int64_t *> rl(nb), cl(nb);
-            std::vector<int64_t> rn(nb), cn(nb);
-            for (int64_t b = 0; b < nb; b++) {
-                rl[b] = blocks[b].ridx;
-                rn[b] = blocks[b].ridx ? blocks[b].m : 0;
-                cl[b] = blocks[b].cidx;
-                cn[b] = blocks[b].cidx ? blocks[b].n : 0;
-            }
-            colors[0] = color_dsatur(rl, rn);
-            colors[1] = color_dsatur(cl, cn);
-        }
-    } else if (mtype == MT_SYMMETRIC) {
-        // always three colourings, also for the serial scheduler: src/symmetricblockmatrix.jl:104-110
-        std::vector<const int64_t *> dl, rl, cl;
-        std::vector<int64_t> dn, rn, cn;
-        for (const BlockIn &B : blocks) {
-            if (B.kind == KIND_DIAG) {
-                dl.push_back(B.ridx);
-                dn.push_back(B.ridx ? B.m : 0);
-            } else {
-                rl.push_back(B.ridx);
-                rn.push_back(B.ridx ? B.m : 0);
-                cl.push_back(B.cidx);
-                cn.push_back(B.cidx ? B.n : 0);
-            }
-        }
-        colors[0] = color_dsatur(rl, rn);
-        colors[1] = color_dsatur(cl, cn);
-        colors[2] = color_dsatur(dl, dn);
-    }
-    lap("reference colourings");
+    colour_thread.join();
+    lap("reference colourings (tail not hidden by packing)");
+    if (colour_oom) return "out of host memory (colouring)";
     return "";
 }
 
