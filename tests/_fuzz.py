@@ -49,6 +49,13 @@ def random_blocksparse(rng, dtype):
         blocks.append(_block(rng, len(r), len(c), dtype))
         rows.append(r)
         cols.append(c)
+    if rng.random() < 0.2:  # one very wide panel: many x chunks, a row group cut into several work items
+        r = _index_list(rng, int(rng.choice([17, 40, 64])), nr)
+        for _ in range(int(rng.integers(8, 30))):
+            c = _index_list(rng, min(int(rng.integers(60, 130)), nc), nc)
+            blocks.append(_block(rng, len(r), len(c), dtype))
+            rows.append(r)
+            cols.append(c)
     return dict(kind="blocksparse", blocks=blocks, rowindices=rows, colindices=cols, size=(nr, nc))
 
 
@@ -95,6 +102,13 @@ def random_symmetric(rng, dtype):
         offs.append(_block(rng, len(sets[i]), len(sets[j]), dtype))
         ri.append(sets[i])
         ci.append(sets[j])
+    if rng.random() < 0.2 and len(sets) > 3:  # one row set coupled to (almost) every other: a very wide panel
+        i = int(rng.integers(0, len(sets)))
+        for j in range(len(sets)):
+            if j != i and rng.random() < 0.9:
+                offs.append(_block(rng, len(sets[i]), len(sets[j]), dtype))
+                ri.append(sets[i])
+                ci.append(sets[j])
     return dict(kind="symmetric", diagonals=diags, diagonalindices=dsets, offdiagonals=offs, rowindices=ri,
                 colindices=ci, size=(n, n))
 
@@ -105,4 +119,7 @@ GEN = {"blocksparse": random_blocksparse, "vbcrs": random_vbcrs, "symmetric": ra
 
 
 def seed_of(kind, dtype):
-    return (sum(map(ord, kind)) * 1000003 + sum(map(ord, np.dtype(dtype).str))) % (2 ** 32)
+    """deterministic per (type, element type); BSM_FUZZ_OFFSET=k explores other streams"""
+    import os
+    off = int(os.environ.get("BSM_FUZZ_OFFSET", "0"))
+    return (sum(map(ord, kind)) * 1000003 + sum(map(ord, np.dtype(dtype).str)) + 7919 * off) % (2 ** 32)
