@@ -27,6 +27,8 @@ Tunables Tunables::from_env() {
     t.pack_threads = (int)geti("BSM_PACK_THREADS", t.pack_threads);
     t.wg_order = (int)geti("BSM_ORDER", t.wg_order);
     t.lds_window = (int)geti("BSM_WINDOW", t.lds_window);
+    t.chunk_rows = (int)geti("BSM_CHUNK_ROWS", t.chunk_rows);
+    if (t.chunk_rows != 8 && t.chunk_rows != 16 && t.chunk_rows != 32) t.chunk_rows = kMaxRowsPerChunk;
     t.window_bytes = (size_t)geti("BSM_UPLOAD_WINDOW_BYTES", (int64_t)t.window_bytes);
     if (t.pack_threads < 1) t.pack_threads = 1;
     return t;
@@ -272,6 +274,7 @@ std::string Analysis::build(int mtype_, int dtype_, int64_t nrows_, int64_t ncol
 
     lap("validate");
     // ---- chunks (<= 64 rows) and row groups ------------------------------------------
+    const int chunk_rows = tun.chunk_rows;
     std::vector<Chunk> chunks;
     std::vector<Group> groups;
     std::unordered_map<uint64_t, std::vector<int64_t>> gmap;  // hash -> candidate groups
@@ -281,8 +284,8 @@ std::string Analysis::build(int mtype_, int dtype_, int64_t nrows_, int64_t ncol
     for (int64_t b = 0; b < nb; b++) {
         const BlockIn &B = blocks[b];
         if (B.m == 0 || B.n == 0) continue;
-        for (int64_t ra = 0; ra < B.m; ra += kMaxRowsPerChunk) {
-            const int mc = (int)std::min<int64_t>(kMaxRowsPerChunk, B.m - ra);
+        for (int64_t ra = 0; ra < B.m; ra += chunk_rows) {
+            const int mc = (int)std::min<int64_t>(chunk_rows, B.m - ra);
             bool rcontig = true;
             if (B.ridx)
                 for (int i = 1; i < mc; i++)
