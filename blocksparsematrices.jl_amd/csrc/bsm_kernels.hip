@@ -270,7 +270,12 @@ __device__ __forceinline__ T run_panel(const WaveD &wd, const uint4 *__restrict_
     constexpr int V = L * E;
     constexpr int NC = G * L * E;                        // columns covered per iteration
     constexpr int XCH = x_chunk_cols<T, TRN>();            // columns staged per x chunk
-    constexpr int BF = (NC >= 64) ? 1 : 64 / NC;           // iterations per transposed emission
+    // iterations per transposed emission: the column sums of a whole staged chunk leave the wave
+    // together.  Atomics (and the plain stores of the gather mode) sit in the same in-order vmcnt
+    // queue as the loads and take 2-3x as long under load (MI355X_MICROARCH.md: ~3000 cycles with
+    // every CU issuing): emitted every iteration, each one is waited for by the NEXT iteration's
+    // matrix loads; emitted at the chunk end of a small panel, nothing ever waits for them.
+    constexpr int BF = XCH / NC;
     static_assert(XCH % NC == 0, "x chunk must hold whole iterations");
     const bool opT = (flags & FLAG_OPT) != 0;
     const bool cjf = (flags & FLAG_CONJ) != 0;
@@ -372,10 +377,9 @@ __device__ __forceinline__ T run_panel(const WaveD &wd, const uint4 *__restrict_
                     int pos = 0, dup = 0;
                     Butterfly<T, V, P>::run(vals, i, pos, dup);
                     constexpr int CF = (V / P) > 1 ? (V / P) : 1;
-                    // the column sums of BF consecutive iterations are parked in LDS and leave the
-                    // wave together: atomics are priced per wave-instruction, so 64 busy lanes
-                    // instead of NC (16 for 64-row groups) quarter their cost
-                    const int slot = ((s0 - c0 / E) / (G * L)) % BF;
+                    // the column sums of the chunk's iterations are parked in LDS and leave the wave
+                    // together (64 busy lanes per atomic wave-instruction instead of NC)
+                    const int slot = (s0 - c0 / E) / (G * L);
                     if ((i & dup) == 0) {
 #pragma unroll
                         for (int j = 0; j < CF; ++j) {
@@ -387,7 +391,7 @@ __device__ __forceinline__ T run_panel(const WaveD &wd, const uint4 *__restrict_
                     const bool last_it = (s0 + G * L >= s_end);
                     if (slot == BF - 1 || last_it) {
                         const int sb = s0 - slot * (G * L);  // first strip of the batch
-#pragma unroll
+#pragma unroll 1
                         for (int k = 0; k < (BF * NC + 63) / 64; ++k) {
                             const int c = k * 64 + lane;
                             const int w = sb * E + c;
@@ -424,23 +428,25 @@ __device__ __forceinline__ T run_panel(const WaveD &wd, const uint4 *__restrict_
     return a;
 }
 
-// fp64 forward-only instances are held to 80 VGPRs (6 waves per SIMD = 1536 resident workgroups:
-// every workgroup of a C2-sized launch is resident at once), and so are the complex128 ones (the
-// fused instance then parks 8 bytes per lane in scratch and still gains 5 % on BEM-shaped
-// operators: small panels are a chain of dependent round trips, hidden only by resident waves).
-// The same cap on the fp64 fused instance (80 VGPRs as compiled; 72 with 24 bytes of scratch) loses.
+// Occupancy is what the small-panel (BEM-shaped) products live on: a small panel is a chain of
+// dependent memory round trips, hidden only by other resident waves.
+//   fp64 forward-only: capped at 80 VGPRs (>= 6 waves per SIMD = 1536 resident workgroups: every
+//     workgroup of a C2-sized launch is resident at once); compiles to 72.
+//   fp64 fused: capped at 64 VGPRs = 8 waves per SIMD, no scratch; with 20 KB of LDS per workgroup
+//     exactly 8 workgroups fit a CU (+11-13 % on 3-28-row fp64 panels over 6 waves).
+//   complex128: capped at 80 (the fused instance compiles to 71: 7 waves).
 template <typename T, int L, bool FWD, bool TRN>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(
-    ((!TRN && std::is_same<T, double>::value) || std::is_same<T, c128>::value) ? 6 : 4)))
+    (FWD && TRN && std::is_same<T, double>::value) ? 8 :
+    (((!TRN && std::is_same<T, double>::value) || std::is_same<T, c128>::value) ? 6 : 4))))
     panel_kernel(const WaveWork *__restrict__ waves, const uint4 *__restrict__ values, const int *__restrict__ rows,
                  const int *__restrict__ cols, const T *__restrict__ x, T *__restrict__ y, T alpha,
                  T beta, int flags, unsigned wg_base, T *__restrict__ ws, long long ws_fbase) {
-    constexpr int E = TT<T>::E;
     constexpr int XS = x_chunk_cols<T, TRN>();         // staged x slice per wave
-    constexpr int VS = 8 * L * E;                      // transposed sums of one iteration
+    constexpr int VS = XS;                             // transposed column sums of one staged chunk
     __shared__ __attribute__((aligned(16))) T xs[kWavesPerWg][FWD ? XS : 1];
     __shared__ __attribute__((aligned(16))) T vs[kWavesPerWg][TRN ? VS : 1];
-    __shared__ T red[kWavesPerWg][64];
+    // (the cross-wave combine slab of split groups aliases xs: a wave's x slice is dead by then)
     // y window of workgroups that pack neighbouring small row groups of a symmetric operator
     constexpr bool WIN = FWD && TRN;
     __shared__ T win[WIN ? window_entries((int)sizeof(T)) : 1];
@@ -472,11 +478,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(
     const bool sz = (flags & FLAG_STRONG_ZERO) != 0;
     if (FWD) {
         if (wd.wg_sync) {  // workgroup-uniform: only groups split over several waves meet in LDS
-            red[wave][lane] = u;
+            xs[wave][lane] = u;
             __syncthreads();
         }
         if (work == WORK_PANEL && wd.lead) {
-            for (int k = 1; k < wd.grp; ++k) u = add(u, red[wave + k][lane]);
+            for (int k = 1; k < wd.grp; ++k) u = add(u, xs[wave + k][lane]);
             if (flags & FLAG_GATHER) {
                 // forward partial sums of this workgroup item: slots ws_fbase + win_base + row
                 const bool fwd_on = !(flags & FLAG_OPT) || (wd.first.kind & kKindGroupHasOff);

@@ -54,8 +54,9 @@ static_assert(sizeof(Piece) == 32, "Piece must be 32 bytes");
 // Workgroups whose waves work on DIFFERENT small row groups of a symmetric operator are packed by
 // locality; their y contributions (forward rows and transposed columns) largely coincide, so they
 // are accumulated in an LDS window [win_base, win_base + 8*win_span8) and leave the CU once.
-// 8 KB of LDS per workgroup whatever the element type (win_span8 is a byte: <= 2040 entries)
-constexpr int window_entries(int elem_bytes) { return 8192 / elem_bytes < 2040 ? 8192 / elem_bytes : 2040; }
+// 4 KB of LDS per workgroup whatever the element type (512 fp64 entries; win_span8 is a byte, <= 2040):
+// with the 8 KB x slices and 8 KB emission staging a fused workgroup stays at 20 KB = 8 per CU
+constexpr int window_entries(int elem_bytes) { return 4096 / elem_bytes; }
 
 struct WaveWork {
     int32_t seg1_w;       // first piece column of segment 1 (>= ncols when unused)

@@ -318,7 +318,7 @@ def test_second_ordering_transposed_image(bsm, oracle):
 
 def test_lds_window_descriptors_cover_their_workgroup(bsm):
     # workgroups of a symmetric operator that pack neighbouring small row groups carry an LDS
-    # accumulation window: it must be workgroup-uniform and hold at most window_entries(8) = 1024 entries
+    # accumulation window: it must be workgroup-uniform and hold at most window_entries(8) = 512 entries
     from _common import WORK_PANEL, get_image
     p = bsm.synthetic.config5(n=20000, lo=8, hi=28, halfband=6)
     A = bsm.synthetic.build(p, device=NODEV)
@@ -328,7 +328,7 @@ def test_lds_window_descriptors_cover_their_workgroup(bsm):
     for quad in wg:
         assert len(set(quad["win_span8"])) == 1 and len(set(quad["win_base"])) == 1
         span = int(quad["win_span8"][0]) * 8
-        assert span <= 1024
+        assert span <= 512
         if span == 0:
             continue
         nwin += 1
