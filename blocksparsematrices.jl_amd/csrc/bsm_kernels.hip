@@ -435,10 +435,11 @@ __device__ __forceinline__ T run_panel(const WaveD &wd, const uint4 *__restrict_
 //   fp64 fused: capped at 64 VGPRs = 8 waves per SIMD, no scratch; with 20 KB of LDS per workgroup
 //     exactly 8 workgroups fit a CU (+11-13 % on 3-28-row fp64 panels over 6 waves).
 //   complex128: capped at 80 (the fused instance compiles to 71: 7 waves).
+//   fp32 / complex64: capped at 96 = 5 waves (fp32 fused compiles to 80: 6), no scratch anywhere.
 template <typename T, int L, bool FWD, bool TRN>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(
     (FWD && TRN && std::is_same<T, double>::value) ? 8 :
-    (((!TRN && std::is_same<T, double>::value) || std::is_same<T, c128>::value) ? 6 : 4))))
+    (((!TRN && std::is_same<T, double>::value) || std::is_same<T, c128>::value) ? 6 : 5))))
     panel_kernel(const WaveWork *__restrict__ waves, const uint4 *__restrict__ values, const int *__restrict__ rows,
                  const int *__restrict__ cols, const T *__restrict__ x, T *__restrict__ y, T alpha,
                  T beta, int flags, unsigned wg_base, T *__restrict__ ws, long long ws_fbase) {
