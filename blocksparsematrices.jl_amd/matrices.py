@@ -172,13 +172,12 @@ class _LinearMap:
         m, n = size(self)
         dt = eltype(self)
         out = np.zeros((m, n), dtype=dt, order="F")
-        e = np.zeros(n, dtype=dt)
-        y = np.zeros(m, dtype=dt)
-        for j in range(n):
-            e[j] = 1
-            mul(y, self, e)
-            out[:, j] = y
-            e[j] = 0
+        step = 64  # unit vectors go through the multi-RHS entry (A streamed once per 8 of them)
+        for j0 in range(0, n, step):
+            k = min(step, n - j0)
+            e = np.zeros((n, k), dtype=dt, order="F")
+            e[np.arange(j0, j0 + k), np.arange(k)] = 1
+            mul(out[:, j0:j0 + k], self, e)
         return out
 
 
