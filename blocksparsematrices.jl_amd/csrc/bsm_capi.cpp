@@ -335,6 +335,13 @@ int finish_create(CreateCtx &cx, const bsm_options &o, bsm_matrix_t *out) {
     return BSM_OK;
 }
 
+// analysis errors are the caller's (bad arguments); the value sink reports device failures
+int build_error(const std::string &err) {
+    const bool device = err.compare(0, 3, "hip") == 0 || err.find("upload") != std::string::npos ||
+                        err.find("value sink") != std::string::npos;
+    return fail(device ? BSM_ERR_DEVICE : BSM_ERR_INVALID, err);
+}
+
 // Second ordering: the transposed operator as a forward image (rows <-> columns, blocks read
 // transposed by the packer).  Built from the same caller arrays, before they are released.
 std::string build_transpose_image(bsm_matrix_s *A, const std::vector<BlockIn> &in, const bsm_options &o,
@@ -409,7 +416,7 @@ extern "C" int bsm_vbcrs_create(int dtype, int64_t nrows, int64_t ncols, int64_t
             }
             err = build_transpose_image(A, in, o, cx.values_t());
         }
-        if (!err.empty()) return fail(BSM_ERR_INVALID, err);
+        if (!err.empty()) return build_error(err);
         return finish_create(cx, o, out);
     } catch (const std::bad_alloc &) {
         return fail(BSM_ERR_ALLOC, "out of host memory");
@@ -441,7 +448,7 @@ extern "C" int bsm_vbcrs_create_from_symmetric(int dtype, int64_t nrows, int64_t
         std::string err = A->an.build_vbcrs_symmetric_view(dtype, nrows, ncols, ndiag, diag, dsize, dld,
                                                            diagstart, noff, off, m, n, ld, rowstart,
                                                            colstart, to_aopt(o, cx.values()));
-        if (!err.empty()) return fail(BSM_ERR_INVALID, err);
+        if (!err.empty()) return build_error(err);
         return finish_create(cx, o, out);
     } catch (const std::bad_alloc &) {
         return fail(BSM_ERR_ALLOC, "out of host memory");
@@ -483,7 +490,7 @@ extern "C" int bsm_blocksparse_create(int dtype, int64_t nrows, int64_t ncols, i
         bsm_matrix_s *A = cx.A;
         std::string err = A->an.build(MT_BLOCKSPARSE, dtype, nrows, ncols, in, to_aopt(o, cx.values()));
         if (err.empty() && o.transpose_image) err = build_transpose_image(A, in, o, cx.values_t());
-        if (!err.empty()) return fail(BSM_ERR_INVALID, err);
+        if (!err.empty()) return build_error(err);
         return finish_create(cx, o, out);
     } catch (const std::bad_alloc &) {
         return fail(BSM_ERR_ALLOC, "out of host memory");
@@ -541,7 +548,7 @@ extern "C" int bsm_symmetric_create(int dtype, int64_t nrows, int64_t ncols, int
         if ((rc = cx.open(o)) != BSM_OK) return rc;
         bsm_matrix_s *A = cx.A;
         std::string err = A->an.build(MT_SYMMETRIC, dtype, nrows, ncols, in, to_aopt(o, cx.values()));
-        if (!err.empty()) return fail(BSM_ERR_INVALID, err);
+        if (!err.empty()) return build_error(err);
         return finish_create(cx, o, out);
     } catch (const std::bad_alloc &) {
         return fail(BSM_ERR_ALLOC, "out of host memory");
