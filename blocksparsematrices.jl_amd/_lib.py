@@ -54,9 +54,14 @@ def lib():
     if not os.path.exists(LIB_PATH):
         # compile on demand (hipcc --offload-arch=gfx950, in-tree); this is a build step, not a
         # fallback: without the HIP library nothing below works
+        import fcntl
         import subprocess
         try:
-            subprocess.check_call(["make", "-s", "-C", os.path.join(_HERE, "csrc")])
+            # one builder at a time: the ranks of a multi-GPU job may all arrive here together
+            with open(os.path.join(_HERE, "csrc", ".build.lock"), "w") as lk:
+                fcntl.flock(lk, fcntl.LOCK_EX)
+                if not os.path.exists(LIB_PATH):
+                    subprocess.check_call(["make", "-s", "-C", os.path.join(_HERE, "csrc")])
         except Exception:
             pass
     if not os.path.exists(LIB_PATH):
