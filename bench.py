@@ -31,8 +31,8 @@ os.environ.setdefault("OMP_NUM_THREADS", str(min(len(os.sched_getaffinity(0)), 1
 
 HBM_PEAK_GBPS = 8000.0  # MI355X spec (MI355X_MICROARCH.md); measured-copy ceiling 6290
 # HBM-side bytes of one C2 launch from the PMC passes (profiles/r01_c2_pmc_summary.txt):
-# FETCH_SIZE 27442.3 KiB x 2 (gfx950 counts 128-B requests as 64 B) + WRITE_SIZE 838.8 KiB
-TRAFFIC_BYTES_PER_LAUNCH = 57_060_000
+# FETCH_SIZE 27531.5 KiB x 2 (gfx950 counts 128-B requests as 64 B) + WRITE_SIZE 835.9 KiB
+TRAFFIC_BYTES_PER_LAUNCH = 57_240_000
 
 
 def main():
@@ -163,14 +163,14 @@ def main():
     value = total_bytes * args.steps / elapsed / 1e9
 
     # ---- roofline of the dominant kernel --------------------------------------------------------
-    # one step == one launch of bsm::panel_kernel<double,8,true,false>; its average duration is
+    # one step == one launch of bsm::panel_kernel<double,8,true,false,true> (forward-only, non-temporal matrix loads); its average duration is
     # the HIP-event time of the timed region / K (back-to-back launches on one stream; the
     # rocprofv3 --kernel-trace average in profiles/ must agree).
     kdur = dev_elapsed / args.steps
     achieved = alg_bytes / kdur / 1e9
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": TRAFFIC_BYTES_PER_LAUNCH,
-                "kernel": "bsm::panel_kernel<double,8,true,false>",
+                "kernel": "bsm::panel_kernel<double,8,true,false,true>",
                 "alg_bytes_per_launch": int(alg_bytes), "avg_launch_us": round(kdur * 1e6, 3),
                 "note": "warm: the 54 MB operator stays in the 256 MiB Infinity Cache between launches; "
                         "traffic = rocprofv3 FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE per launch, "

@@ -243,6 +243,7 @@ void fill_image(const Analysis &an, const bsm_options &o, bool use_own, DeviceIm
     img.ncols = an.ncols;
     img.own_lo = (use_own && o.own_lo > 0) ? o.own_lo - 1 : 0;
     img.own_hi = (use_own && o.own_hi > 0) ? std::min<long long>(o.own_hi, an.nrows) : an.nrows;
+    img.value_bytes = an.value_bytes;
     img.nwg_main = an.nwg_main;
     img.nwg_total = an.nwg_total;
     img.exclusive_fwd = an.exclusive_fwd && o.accumulate == BSM_ACC_AUTO;

@@ -18,6 +18,7 @@ struct DeviceImage {
     bool exclusive_fwd = false;
     bool has_off = false;  // SymmetricBlockMatrix off-diagonal pieces present
     long long device_bytes = 0;
+    long long value_bytes = 0;  // packed matrix bytes (decides the cache policy of the matrix loads)
     std::vector<long long> color_wg_ptr;  // non-empty: coloured launches, plain read-modify-write
     // gather mode (BSM_ACC_GATHER): workspace + inverted indices for op N [0] and op T / C [1]
     void *d_ws = nullptr;

@@ -31,6 +31,70 @@ __global__ __launch_bounds__(256) void stream_kernel(const v2d *__restrict__ src
     if (acc == 123456.789) out[wave] = acc;
 }
 
+// "panel-shaped" variant: only M of the 64 lanes load (a 36-row panel: 576-byte wave-loads at a
+// 576-byte stride, cache-line-misaligned), optionally after a dependent descriptor fetch (the
+// wave's byte offset comes from a table), optionally followed by an LDS round trip per load
+template <int M, bool DESC, bool LDSRT, bool NT = false>
+__global__ __launch_bounds__(256) void panel_like_kernel(const v2d *__restrict__ src, double *__restrict__ out,
+                                                          const long long *__restrict__ table, long long loads_per_wave,
+                                                          long long total16) {
+    __shared__ double stage[4][64];
+    const int lane = threadIdx.x & 63;
+    const int w4 = threadIdx.x >> 6;
+    const long long wave = (long long)blockIdx.x * 4 + w4;
+    long long base = wave * loads_per_wave * M;  // 16-byte units
+    if (DESC) base = table[wave];
+    double acc = 0.0;
+    for (long long l0 = 0; l0 < loads_per_wave; l0 += 8) {
+        v2d v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const long long q = base + (l0 + k) * M + lane;
+            v[k] = (lane < M && l0 + k < loads_per_wave && q < total16) ? (NT ? __builtin_nontemporal_load(&src[q]) : src[q]) : v2d{0.0, 0.0};
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            double t = v[k].x * 1.0000001 + v[k].y;
+            if (LDSRT) {
+                stage[w4][lane] = t;
+                t = stage[w4][lane ^ 1];
+            }
+            acc += t;
+        }
+    }
+    if (acc == 123456.789) out[wave] = acc;
+}
+
+template <int M, bool DESC, bool LDSRT, bool NT = false>
+void run_panel_like(const v2d *src, double *out, long long *table, long long bytes, long long loads_per_wave) {
+    const long long total16 = bytes / 16;
+    const long long per_wave16 = loads_per_wave * M;
+    const long long nwaves = (total16 + per_wave16 - 1) / per_wave16;
+    const unsigned grid = (unsigned)((nwaves + 3) / 4);
+    if (DESC) {
+        long long *h = (long long *)malloc(sizeof(long long) * grid * 4);
+        for (long long w = 0; w < (long long)grid * 4; w++) h[w] = w * per_wave16;
+        hipMemcpy(table, h, sizeof(long long) * grid * 4, hipMemcpyHostToDevice);
+        free(h);
+    }
+    hipEvent_t a, b;
+    hipEventCreate(&a);
+    hipEventCreate(&b);
+    for (int i = 0; i < 20; i++)
+        hipLaunchKernelGGL((panel_like_kernel<M, DESC, LDSRT, NT>), dim3(grid), dim3(256), 0, 0, src, out, table, loads_per_wave, total16);
+    hipEventRecord(a, 0);
+    for (int i = 0; i < 2000; i++)
+        hipLaunchKernelGGL((panel_like_kernel<M, DESC, LDSRT, NT>), dim3(grid), dim3(256), 0, 0, src, out, table, loads_per_wave, total16);
+    hipEventRecord(b, 0);
+    hipEventSynchronize(b);
+    float ms = 0;
+    hipEventElapsedTime(&ms, a, b);
+    const double us = ms * 1e3 / 2000;
+    printf("panel-like nt=%d M=%2d desc=%d ldsrt=%d loads/wave=%3lld grid=%5u: %7.2f us  %6.0f GB/s\n", (int)NT, M, (int)DESC, (int)LDSRT,
+           loads_per_wave, grid, us, bytes / us / 1e3);
+    fflush(stdout);
+}
+
 // grid-stride variant: a fixed number of waves, wave w takes chunks w, w + nwaves, ... of `chunk16`
 template <int L>
 __global__ __launch_bounds__(256) void stride_kernel(const v2d *__restrict__ src, double *__restrict__ out,
@@ -118,6 +182,23 @@ int main(int argc, char **argv) {
                 run_stride<1>(src, out, bytes, ch, grid);
                 run_stride<4>(src, out, bytes, ch, grid);
             }
+    } else if (mode == 4) {
+        long long *table;
+        hipMalloc(&table, 8 << 20);
+        // steady state first (the first ~100 ms of a process run faster)
+        for (int i = 0; i < 3; i++) run<8>(src, out, bytes, 8192, 256);
+        run_panel_like<64, false, false, false>(src, out, table, bytes, 8);
+        run_panel_like<64, false, false, true>(src, out, table, bytes, 8);
+        run_panel_like<64, true, false, false>(src, out, table, bytes, 8);
+        run_panel_like<64, true, false, true>(src, out, table, bytes, 8);
+        run_panel_like<36, false, false, false>(src, out, table, bytes, 8);
+        run_panel_like<36, false, false, true>(src, out, table, bytes, 8);
+        run_panel_like<36, true, false, true>(src, out, table, bytes, 8);
+        run_panel_like<36, true, false, true>(src, out, table, bytes, 16);
+        run_panel_like<20, true, false, true>(src, out, table, bytes, 8);
+        run_panel_like<64, false, false, false>(src, out, table, bytes, 8);
+        run_panel_like<64, false, false, true>(src, out, table, bytes, 8);
+        run<8>(src, out, bytes, 8192, 256);
     } else if (mode == 3) {
         // cold: a 512 MiB write between launches evicts the operator from L2 / Infinity Cache
         char *flush;
