@@ -832,14 +832,17 @@ template <> bool is_one(c128 v) { return v.re == 1.0 && v.im == 0.0; }
 // runs 6.65 us with the hint and 8.45 us without; operators larger than the 256 MiB Infinity Cache gain
 // 5-12 %, and a launch that finds the caches full of someone else's dirty lines 40 %).  The exception
 // are operators that just fit the Infinity Cache: streamed with the hint they are not retained as
-// well between launches (164-218 MB: 6-10 % slower), so they keep ordinary loads.
+// well between launches (164-218 MB: 6-10 % slower), so they keep ordinary loads; so do tiny ones.
 static bool stream_policy(const DeviceImage &img) {
     static const int forced = [] {
         const char *v = std::getenv("BSM_NT");
         return v ? std::atoi(v) : -1;
     }();
     if (forced >= 0) return forced != 0;
-    return img.value_bytes < (120ll << 20) || img.value_bytes > (250ll << 20);
+    // (operators of a few tens of MB are a single round of resident workgroups bound by one
+    // workgroup's dependency chain, where the hint costs ~5 %: 27 MB 5.8 vs 6.3 us)
+    const long long mb = img.value_bytes >> 20;
+    return (mb >= 40 && mb < 120) || mb > 250;
 }
 
 // one launch of panel_kernel<T, L, FWD, TRN, NT> with NT taken from the run-time policy `nt`
