@@ -27,6 +27,8 @@ Tunables Tunables::from_env() {
     t.pack_threads = (int)geti("BSM_PACK_THREADS", t.pack_threads);
     t.wg_order = (int)geti("BSM_ORDER", t.wg_order);
     t.lds_window = (int)geti("BSM_WINDOW", t.lds_window);
+    t.split_mode = (int)geti("BSM_SPLIT_MODE", t.split_mode);
+    t.split_min_strips = geti("BSM_SPLIT_MIN_STRIPS", t.split_min_strips);
     t.chunk_rows = (int)geti("BSM_CHUNK_ROWS", t.chunk_rows);
     if (t.chunk_rows != 8 && t.chunk_rows != 16 && t.chunk_rows != 32) t.chunk_rows = kMaxRowsPerChunk;
     t.window_bytes = (size_t)geti("BSM_UPLOAD_WINDOW_BYTES", (int64_t)t.window_bytes);
@@ -627,6 +629,27 @@ std::string Analysis::build(int mtype_, int dtype_, int64_t nrows_, int64_t ncol
             it.s_end = std::min(G.strips, s + per_item);
             it.bytes = (it.s_end - it.s_begin) * strip_bytes;
             it.nw = it.bytes >= tun.split4_bytes ? 4 : (it.bytes >= tun.split2_bytes ? 2 : 1);
+            if (tun.split_mode == 1) {
+                // fewest dependent iterations per wave: an iteration covers G*L strips (L = 8 loads per
+                // lane, G = 64/P strips per load); take the smallest wave count that reaches the
+                // minimum, but never split below `split_min_strips` strips per wave
+                int P = 8;
+                while (P < G.mc) P <<= 1;
+                const int64_t per_iter = (64 / P) * 8;
+                const int64_t S = it.s_end - it.s_begin;
+                int best = 1;
+                int64_t best_it = (S + per_iter - 1) / per_iter;
+                for (int nw : {2, 4}) {
+                    const int64_t per_wave = (S + nw - 1) / nw;
+                    if (per_wave < tun.split_min_strips) break;
+                    const int64_t iters = (per_wave + per_iter - 1) / per_iter;
+                    if (iters < best_it) {
+                        best_it = iters;
+                        best = nw;
+                    }
+                }
+                it.nw = best;
+            }
             it.color = group_color[g];
             items.push_back(it);
         }

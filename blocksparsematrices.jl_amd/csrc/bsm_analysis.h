@@ -56,6 +56,8 @@ struct Tunables {
     int64_t split4_bytes = 24 << 10;    // ... and 4 waves
     int64_t wgitem_max_bytes = 256 << 10;  // non-exclusive groups are cut into items this big
     int chunk_rows = kMaxRowsPerChunk;  // blocks taller than this are cut into chunks (BSM_CHUNK_ROWS: 8/16/32/64)
+    int split_mode = 0;            // 1: wave count that minimises the dependent iterations per wave (BSM_SPLIT_MODE)
+    int64_t split_min_strips = 2;  // ... without going below this many strips per wave
     int pack_threads = 8;
     size_t window_bytes = 64u << 20;  // staging window of a streamed upload (BSM_UPLOAD_WINDOW_BYTES)
     int lds_window = 1;  // LDS y window for locality-packed small symmetric row groups (BSM_WINDOW)

@@ -95,6 +95,85 @@ void run_panel_like(const v2d *src, double *out, long long *table, long long byt
     fflush(stdout);
 }
 
+// progressively closer to the product kernel: descriptor hop, M-lane wave-loads, then
+//   XG : gather ncols = 2*loads x entries into LDS before the matrix loads (dependent on the descriptor)
+//   FM : read x back from LDS as 16-byte broadcasts and do the 2 FMAs per load
+//   ST : cross-wave combine through LDS (+ barrier) and a y store of M rows by the lead wave
+template <int M, bool XG, bool FM, bool ST>
+__global__ __launch_bounds__(256) void product_like_kernel(const v2d *__restrict__ src, double *__restrict__ y,
+                                                            const double *__restrict__ x, const long long *__restrict__ table,
+                                                            long long loads_per_wave, long long total16) {
+    __shared__ __attribute__((aligned(16))) double xs[4][512];
+    const int lane = threadIdx.x & 63;
+    const int w4 = threadIdx.x >> 6;
+    const long long wave = (long long)blockIdx.x * 4 + w4;
+    const long long base = table[wave];
+    const int ncols = (int)(2 * loads_per_wave);
+    if (XG) {
+        const long long col0 = (base / M) % 90000;  // "column start" derived from the descriptor
+        for (int c = lane; c < ncols + 16; c += 64) xs[w4][c] = c < ncols ? x[col0 + c] : 0.0;
+    }
+    double acc0 = 0.0, acc1 = 0.0;
+    for (long long l0 = 0; l0 < loads_per_wave; l0 += 8) {
+        v2d v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const long long q = base + (l0 + k) * M + lane;
+            v[k] = (lane < M && l0 + k < loads_per_wave && q < total16) ? __builtin_nontemporal_load(&src[q]) : v2d{0.0, 0.0};
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            if (FM) {
+                const v2d xv = *reinterpret_cast<const v2d *>(&xs[w4][2 * (l0 + k)]);
+                acc0 = __builtin_fma(v[k].x, xv.x, acc0);
+                acc1 = __builtin_fma(v[k].y, xv.y, acc1);
+            } else {
+                acc0 += v[k].x;
+                acc1 += v[k].y;
+            }
+        }
+    }
+    double u = acc0 + acc1;
+    if (ST) {
+        xs[w4][lane] = u;
+        __syncthreads();
+        if (w4 == 0) {
+            u += xs[1][lane] + xs[2][lane] + xs[3][lane];
+            if (lane < M) y[(wave / 4) * 64 % 90000 + lane] = u;
+        }
+    } else if (u == 123456.789) {
+        y[wave] = u;
+    }
+}
+
+template <int M, bool XG, bool FM, bool ST>
+void run_product_like(const v2d *src, double *y, const double *x, long long *table, long long bytes, long long loads_per_wave) {
+    const long long total16 = bytes / 16;
+    const long long per_wave16 = loads_per_wave * M;
+    const long long nwaves = (total16 + per_wave16 - 1) / per_wave16;
+    const unsigned grid = (unsigned)((nwaves + 3) / 4);
+    long long *h = (long long *)malloc(sizeof(long long) * grid * 4);
+    for (long long w = 0; w < (long long)grid * 4; w++) h[w] = w * per_wave16;
+    hipMemcpy(table, h, sizeof(long long) * grid * 4, hipMemcpyHostToDevice);
+    free(h);
+    hipEvent_t a, b;
+    hipEventCreate(&a);
+    hipEventCreate(&b);
+    for (int i = 0; i < 20; i++)
+        hipLaunchKernelGGL((product_like_kernel<M, XG, FM, ST>), dim3(grid), dim3(256), 0, 0, src, y, x, table, loads_per_wave, total16);
+    hipEventRecord(a, 0);
+    for (int i = 0; i < 2000; i++)
+        hipLaunchKernelGGL((product_like_kernel<M, XG, FM, ST>), dim3(grid), dim3(256), 0, 0, src, y, x, table, loads_per_wave, total16);
+    hipEventRecord(b, 0);
+    hipEventSynchronize(b);
+    float ms = 0;
+    hipEventElapsedTime(&ms, a, b);
+    const double us = ms * 1e3 / 2000;
+    printf("product-like M=%2d xgather=%d fma=%d store=%d loads/wave=%3lld grid=%5u: %7.2f us  %6.0f GB/s\n", M, (int)XG, (int)FM,
+           (int)ST, loads_per_wave, grid, us, bytes / us / 1e3);
+    fflush(stdout);
+}
+
 // grid-stride variant: a fixed number of waves, wave w takes chunks w, w + nwaves, ... of `chunk16`
 template <int L>
 __global__ __launch_bounds__(256) void stride_kernel(const v2d *__restrict__ src, double *__restrict__ out,
@@ -182,6 +261,24 @@ int main(int argc, char **argv) {
                 run_stride<1>(src, out, bytes, ch, grid);
                 run_stride<4>(src, out, bytes, ch, grid);
             }
+    } else if (mode == 5) {
+        long long *table;
+        double *xv, *yv;
+        hipMalloc(&table, 8 << 20);
+        hipMalloc(&xv, 1 << 20);
+        hipMalloc(&yv, 1 << 20);
+        hipMemset(xv, 0, 1 << 20);
+        for (int rep = 0; rep < 2; rep++) {
+            run_product_like<64, false, false, false>(src, yv, xv, table, bytes, 8);
+            run_product_like<64, true, false, false>(src, yv, xv, table, bytes, 8);
+            run_product_like<64, true, true, false>(src, yv, xv, table, bytes, 8);
+            run_product_like<64, true, true, true>(src, yv, xv, table, bytes, 8);
+            run_product_like<36, false, false, false>(src, yv, xv, table, bytes, 8);
+            run_product_like<36, true, true, true>(src, yv, xv, table, bytes, 8);
+            run_product_like<36, true, true, true>(src, yv, xv, table, bytes, 16);
+            run_product_like<36, true, true, true>(src, yv, xv, table, bytes, 24);
+            run_product_like<64, true, true, true>(src, yv, xv, table, bytes, 16);
+        }
     } else if (mode == 4) {
         long long *table;
         hipMalloc(&table, 8 << 20);
