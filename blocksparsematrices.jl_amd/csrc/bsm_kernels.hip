@@ -832,7 +832,7 @@ template <> bool is_one(c128 v) { return v.re == 1.0 && v.im == 0.0; }
 // runs 6.65 us with the hint and 8.45 us without; operators larger than the 256 MiB Infinity Cache gain
 // 5-12 %, and a launch that finds the caches full of someone else's dirty lines 40 %).  The exception
 // are operators that just fit the Infinity Cache: streamed with the hint they are not retained as
-// well between launches (164-218 MB: 6-10 % slower), so they keep ordinary loads; so do tiny ones.
+// well between launches (136-298 MB: 2-9 % slower), so they keep ordinary loads; so do tiny ones.
 static bool stream_policy(const DeviceImage &img) {
     static const int forced = [] {
         const char *v = std::getenv("BSM_NT");
@@ -842,7 +842,7 @@ static bool stream_policy(const DeviceImage &img) {
     // (operators of a few tens of MB are a single round of resident workgroups bound by one
     // workgroup's dependency chain, where the hint costs ~5 %: 27 MB 5.8 vs 6.3 us)
     const long long mb = img.value_bytes >> 20;
-    return (mb >= 40 && mb < 120) || mb > 250;
+    return (mb >= 40 && mb < 100) || mb > 300;  // measured crossovers: ~105 MB and ~310 MB of values
 }
 
 // one launch of panel_kernel<T, L, FWD, TRN, NT> with NT taken from the run-time policy `nt`
