@@ -753,21 +753,24 @@ std::string Analysis::build(int mtype_, int dtype_, int64_t nrows_, int64_t ncol
     }
     while (waves.size() % kWavesPerWg) emit_nop();
     nwg_main = (int64_t)waves.size() / kWavesPerWg;
-    if (!colored && tun.wg_order != 0 && nwg_main > 2) {
-        // experimental dispatch orders (default 0 = largest first)
+    // dispatch order: largest first; for exclusive forward images ("auto") every other block of 256
+    // workgroups (one per CU) is reversed, so that the same CUs do not receive the larger workgroup
+    // of every layer (C2-sized operators: +2.5 %; neutral on long launches)
+    const int wg_order = tun.wg_order >= 0 ? tun.wg_order : (exclusive_fwd ? 102 : 0);
+    if (!colored && wg_order != 0 && nwg_main > 2) {
         std::vector<WaveWork> re(waves.size());
         std::vector<int64_t> ord;
-        if (tun.wg_order == 1) {  // big, small, big, small ...
+        if (wg_order == 1) {  // big, small, big, small ...
             for (int64_t a = 0, b = nwg_main - 1; a <= b; a++, b--) {
                 ord.push_back(a);
                 if (b != a) ord.push_back(b);
             }
-        } else if (tun.wg_order == 2) {  // smallest first
+        } else if (wg_order == 2) {  // smallest first
             for (int64_t a = nwg_main - 1; a >= 0; a--) ord.push_back(a);
-        } else if (tun.wg_order == 3) {  // sawtooth: 8 size-sorted passes
+        } else if (wg_order == 3) {  // sawtooth: 8 size-sorted passes
             for (int64_t r = 0; r < 8; r++)
                 for (int64_t a = r; a < nwg_main; a += 8) ord.push_back(a);
-        } else if (tun.wg_order == 4) {  // deterministic pseudo-random shuffle
+        } else if (wg_order == 4) {  // deterministic pseudo-random shuffle
             ord.resize(nwg_main);
             std::iota(ord.begin(), ord.end(), (int64_t)0);
             uint64_t st = 0x9E3779B97F4A7C15ull;
@@ -777,8 +780,20 @@ std::string Analysis::build(int mtype_, int dtype_, int64_t nrows_, int64_t ncol
                 st ^= st << 17;
                 std::swap(ord[a], ord[(int64_t)(st % (uint64_t)(a + 1))]);
             }
+        } else if (wg_order >= 101 && wg_order <= 105) {
+            // snake: largest first, but every other block of 8 (XCDs) / 256 (CUs) / 32 reversed, so
+            // that the same XCD / CU does not receive the larger workgroup of every layer
+            static const int64_t kBlk[5] = {8, 256, 32, 128, 512};
+            const int64_t blk = kBlk[wg_order - 101];
+            for (int64_t a0 = 0; a0 < nwg_main; a0 += blk) {
+                const int64_t a1 = std::min(nwg_main, a0 + blk);
+                if ((a0 / blk) & 1)
+                    for (int64_t a = a1 - 1; a >= a0; a--) ord.push_back(a);
+                else
+                    for (int64_t a = a0; a < a1; a++) ord.push_back(a);
+            }
         } else {  // >= 5: sawtooth with wg_order passes
-            const int64_t np = tun.wg_order;
+            const int64_t np = wg_order;
             for (int64_t r = 0; r < np; r++)
                 for (int64_t a = r; a < nwg_main; a += np) ord.push_back(a);
         }

@@ -61,7 +61,7 @@ struct Tunables {
     int pack_threads = 8;
     size_t window_bytes = 64u << 20;  // staging window of a streamed upload (BSM_UPLOAD_WINDOW_BYTES)
     int lds_window = 1;  // LDS y window for locality-packed small symmetric row groups (BSM_WINDOW)
-    int wg_order = 0;  // experimental workgroup dispatch orders (BSM_ORDER)
+    int wg_order = -1;  // workgroup dispatch order (BSM_ORDER): -1 auto, 0 largest first, 1-4 / 101-105 experimental
     static Tunables from_env();
 };
 
