@@ -792,6 +792,31 @@ std::string Analysis::build(int mtype_, int dtype_, int64_t nrows_, int64_t ncol
                 else
                     for (int64_t a = a0; a < a1; a++) ord.push_back(a);
             }
+        } else if (wg_order == 110 || wg_order == 111) {
+            // layered LPT: the k-th largest workgroup of a layer of NB goes to the k-th least loaded
+            // bin (bin = position inside the layer: the hardware deals workgroups round-robin)
+            const int64_t NB = wg_order == 110 ? 256 : 8;
+            std::vector<int64_t> wgbytes(nwg_main, 0);
+            for (int64_t k = 0; k < nwg_main; k++)
+                for (int w = 0; w < kWavesPerWg; w++) {
+                    const WaveWork &W = waves[k * kWavesPerWg + w];
+                    if (W.work == WORK_PANEL && W.npieces > 0) wgbytes[k] += (int64_t)W.first.nstrips * W.m * 16;
+                }
+            std::vector<int64_t> load(NB, 0), bins(NB);
+            ord.assign(nwg_main, -1);
+            for (int64_t a0 = 0; a0 < nwg_main; a0 += NB) {
+                const int64_t cnt = std::min(NB, nwg_main - a0);
+                std::iota(bins.begin(), bins.end(), (int64_t)0);
+                std::stable_sort(bins.begin(), bins.end(), [&](int64_t x, int64_t y) { return load[x] < load[y]; });
+                if (cnt < NB) {  // last, partial layer: keep positions dense
+                    for (int64_t k = 0; k < cnt; k++) ord[a0 + k] = a0 + k;
+                    break;
+                }
+                for (int64_t k = 0; k < cnt; k++) {
+                    ord[a0 + bins[k]] = a0 + k;
+                    load[bins[k]] += wgbytes[a0 + k];
+                }
+            }
         } else {  // >= 5: sawtooth with wg_order passes
             const int64_t np = wg_order;
             for (int64_t r = 0; r < np; r++)
