@@ -177,6 +177,18 @@ def main():
                         "profiles/r01_c2_pmc_summary.txt"}
 
     extra = {}
+    if rank == 0 and launch == "graph":
+        # the same K steps as individual bsm_mul calls (no graph), for transparency
+        for _ in range(20):
+            step()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(args.steps):
+            step()
+        e1.record()
+        torch.cuda.synchronize()
+        extra["eager_us_per_step"] = round(e0.elapsed_time(e1) * 1e3 / args.steps, 3)
     if args.cold and rank == 0:
         flush = torch.empty(512 << 20, dtype=torch.uint8, device="cuda")
         cold = []
