@@ -13,7 +13,7 @@ BSM_F32, BSM_F64, BSM_C64, BSM_C128 = 0, 1, 2, 3
 BSM_OP_N, BSM_OP_T, BSM_OP_C = 0, 1, 2
 BSM_MEM_HOST, BSM_MEM_DEVICE = 0, 1
 BSM_SCHED_SERIAL, BSM_SCHED_DYNAMIC = 0, 1
-BSM_ACC_AUTO, BSM_ACC_ATOMIC, BSM_ACC_COLORED, BSM_ACC_GATHER = 0, 1, 2, 3
+BSM_ACC_AUTO, BSM_ACC_ATOMIC, BSM_ACC_COLORED, BSM_ACC_GATHER, BSM_ACC_DIRECT = 0, 1, 2, 3, 4
 BSM_DEVICE_CURRENT, BSM_DEVICE_NONE = -1, -2
 (BSM_BK_VBCRS_PERM, BSM_BK_VBCRS_ROWPTR, BSM_BK_VBCRS_COLINDICES, BSM_BK_VBCRS_ROWINDICES,
  BSM_BK_COLORS, BSM_BK_TRANSPOSECOLORS, BSM_BK_DIAGONALCOLORS) = range(7)

@@ -27,6 +27,8 @@ Tunables Tunables::from_env() {
     t.pack_threads = (int)geti("BSM_PACK_THREADS", t.pack_threads);
     t.wg_order = (int)geti("BSM_ORDER", t.wg_order);
     t.lds_window = (int)geti("BSM_WINDOW", t.lds_window);
+    t.deep_group_bytes = geti("BSM_DEEP_GROUP_BYTES", t.deep_group_bytes);
+    t.deep_total_bytes = geti("BSM_DEEP_TOTAL_BYTES", t.deep_total_bytes);
     t.split_mode = (int)geti("BSM_SPLIT_MODE", t.split_mode);
     t.split_min_strips = geti("BSM_SPLIT_MIN_STRIPS", t.split_min_strips);
     t.chunk_rows = (int)geti("BSM_CHUNK_ROWS", t.chunk_rows);
@@ -432,6 +434,18 @@ std::string Analysis::build(int mtype_, int dtype_, int64_t nrows_, int64_t ncol
     // forced atomics: schedule like a non-exclusive matrix (large row groups are cut into several
     // workgroup items; their partial sums meet in y through atomics)
     if (opt.accumulate == 1 || opt.accumulate == 3) exclusive_fwd = false;
+    if (opt.accumulate == 0 && exclusive_fwd) {
+        // auto: a large conflict-free operator made of DEEP row groups (a group has to stay in one
+        // workgroup of 4 waves to keep its rows exclusive: 128 KB per wave for C4's 512 KB groups)
+        // streams 8 % faster as 32 KB work items combined with atomics -- shallow waves, many more
+        // of them; the extra `y .*= beta` launch is noise at this size (C4 slice 328 -> 303 us)
+        int64_t deep_units = 0;
+        for (const Group &G : groups) {
+            const int64_t u = (int64_t)G.mc * G.strips;
+            if (u * 16 > tun.deep_group_bytes) deep_units += u;
+        }
+        if ((int64_t)val_units * 16 >= tun.deep_total_bytes && 2 * deep_units > (int64_t)val_units) exclusive_fwd = false;
+    }
     const bool colored = (opt.accumulate == 2);
     gather = (opt.accumulate == 3);
     std::vector<int32_t> group_color(groups.size(), 0);

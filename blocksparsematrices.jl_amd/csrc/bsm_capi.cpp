@@ -136,7 +136,7 @@ int read_options(const bsm_options *opts, bsm_options &o) {
         o = *opts;
     }
     if (o.accumulate != BSM_ACC_AUTO && o.accumulate != BSM_ACC_ATOMIC && o.accumulate != BSM_ACC_COLORED &&
-        o.accumulate != BSM_ACC_GATHER)
+        o.accumulate != BSM_ACC_GATHER && o.accumulate != BSM_ACC_DIRECT)
         return fail(BSM_ERR_INVALID, "unknown accumulate mode");
     if (o.own_lo < 0 || o.own_hi < 0 || (o.own_hi > 0 && o.own_hi < o.own_lo))
         return fail(BSM_ERR_INVALID, "bad own_lo/own_hi");
@@ -246,7 +246,7 @@ void fill_image(const Analysis &an, const bsm_options &o, bool use_own, DeviceIm
     img.value_bytes = an.value_bytes;
     img.nwg_main = an.nwg_main;
     img.nwg_total = an.nwg_total;
-    img.exclusive_fwd = an.exclusive_fwd && o.accumulate == BSM_ACC_AUTO;
+    img.exclusive_fwd = an.exclusive_fwd && (o.accumulate == BSM_ACC_AUTO || o.accumulate == BSM_ACC_DIRECT);
     img.has_off = false;
     for (const WaveWork &w : an.waves)
         if (w.work == WORK_PANEL && w.npieces > 0 && (w.first.kind & kKindHasOff)) img.has_off = true;

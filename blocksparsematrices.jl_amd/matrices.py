@@ -101,7 +101,8 @@ def _options(scheduler, device, accumulate, own=None, transpose_image=False):
     o.scheduler = L.BSM_SCHED_SERIAL if isserial(scheduler) else L.BSM_SCHED_DYNAMIC
     o.device = device
     o.accumulate = {"auto": L.BSM_ACC_AUTO, "atomic": L.BSM_ACC_ATOMIC,
-                    "colored": L.BSM_ACC_COLORED, "gather": L.BSM_ACC_GATHER}[accumulate]
+                    "colored": L.BSM_ACC_COLORED, "gather": L.BSM_ACC_GATHER,
+                    "direct": L.BSM_ACC_DIRECT}[accumulate]
     if own is not None:
         o.own_lo, o.own_hi = int(own[0]), int(own[1])
     o.transpose_image = 1 if transpose_image else 0

@@ -54,11 +54,15 @@ typedef enum { BSM_SCHED_SERIAL = 0, BSM_SCHED_DYNAMIC = 1 } bsm_scheduler;
 
 /* how contributions of different blocks to the same y entries are combined on the GPU */
 typedef enum {
-    BSM_ACC_AUTO = 0,    /* exclusive direct stores when provably conflict-free, else atomics */
+    BSM_ACC_AUTO = 0,    /* exclusive direct stores when provably conflict-free, else atomics.  Large
+                            conflict-free operators made of deep row groups (most bytes in row groups
+                            above 64 KiB, e.g. 128x128 blocks, 16 per block row) are ALSO scheduled as
+                            32 KiB work items combined with atomics: 8 % faster, but the last bits then
+                            depend on the order of the adds -- BSM_ACC_DIRECT keeps them exclusive */
     BSM_ACC_ATOMIC = 1,  /* hardware fp atomics into y, blocks ordered by colour class */
     BSM_ACC_COLORED = 2, /* one launch per colour class, plain read-modify-write: bitwise
                             reproducible run to run (the reference's own scheme) */
-    BSM_ACC_GATHER = 3   /* no atomics at all: every block contribution is stored once in a
+    BSM_ACC_GATHER = 3,  /* no atomics at all: every block contribution is stored once in a
                             workspace owned by the handle and a second launch sums, per y entry,
                             its contributions in a fixed order (and applies alpha, beta): bitwise
                             reproducible, two launches.  The workspace makes products on ONE handle
@@ -66,6 +70,8 @@ typedef enum {
                             still in flight on a DIFFERENT stream (or being enqueued by another
                             thread) uses the atomic path for that call.  Single right-hand side
                             only. */
+    BSM_ACC_DIRECT = 4   /* like AUTO, but a conflict-free operator always takes the exclusive direct
+                            stores (one launch, no atomics, bitwise reproducible) */
 } bsm_accumulate;
 
 #define BSM_DEVICE_CURRENT (-1)

@@ -242,7 +242,7 @@ float run(const v2d *src, double *out, long long bytes, long long per_wave_bytes
 }
 
 int main(int argc, char **argv) {
-    const long long maxbytes = 220000000LL;
+    const long long maxbytes = 1000000000LL;
     v2d *src;
     double *out;
     hipMalloc(&src, maxbytes + 4096);
@@ -261,6 +261,18 @@ int main(int argc, char **argv) {
                 run_stride<1>(src, out, bytes, ch, grid);
                 run_stride<4>(src, out, bytes, ch, grid);
             }
+    } else if (mode == 6) {
+        // HBM-streaming ceiling: operators far larger than the Infinity Cache
+        long long *table;
+        hipMalloc(&table, 64 << 20);
+        for (long long b : {950000000LL, 500000000LL}) {
+            run<8>(src, out, b, 8192, 256);
+            run<8>(src, out, b, 32768, 256);
+            run<8>(src, out, b, 131072, 256);
+            run_panel_like<64, false, false, false>(src, out, table, b, 8);
+            run_panel_like<64, false, false, true>(src, out, table, b, 8);
+            run_panel_like<64, false, false, true>(src, out, table, b, 64);
+        }
     } else if (mode == 5) {
         long long *table;
         double *xv, *yv;
