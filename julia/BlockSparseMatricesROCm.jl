@@ -17,7 +17,7 @@ const libbsm = get(ENV, "BSM_ROCM_LIB", "libbsmrocm.so")
 "Opt-in scheduler: `BlockSparseMatrix(...; scheduler=ROCmScheduler())`."
 struct ROCmScheduler
     device::Int32            # HIP ordinal, -1 = current device
-    accumulate::Int32        # 0 auto, 1 atomics, 2 coloured launches (bitwise reproducible)
+    accumulate::Int32        # 0 auto, 1 atomics, 2 coloured launches, 3 gather, 4 direct (2-4: bitwise reproducible)
     transpose_image::Int32   # 1: keep a second, transposed ordering for A' / transpose(A)
 end
 ROCmScheduler(; device=-1, accumulate=0, transpose_image=0) = ROCmScheduler(device, accumulate, transpose_image)

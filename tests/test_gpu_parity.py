@@ -178,10 +178,21 @@ def test_config3_symmetric_full_size(torch_cuda, bsm, oracle):
 
 
 def test_config4_vbcrs_f32_one_rank_slice(torch_cuda, bsm, oracle):
-    # 1/64 of C4's block rows (the slice one GPU of eight would own is 8x this)
+    # 1/64 of C4's block rows (the slice one GPU of eight would own is 8x this): 256 MB of deep
+    # (512 KB) row groups.  Auto mode schedules them as 32 KB work items with atomics; "direct" keeps
+    # the exclusive one-launch schedule, which is bitwise reproducible run to run.
     p = bsm.synthetic.config4(ngrid=15625, row_lo=0, row_hi=244)
     A = bsm.synthetic.build(p)
+    assert A.stats()["exclusive"] == 0
     check_all(torch_cuda, bsm, oracle, p, A, np.float32, ops=[N, T], host_too=False)
+    D = bsm.synthetic.build(p, accumulate="direct")
+    assert D.stats()["exclusive"] == 1
+    check_all(torch_cuda, bsm, oracle, p, D, np.float32, ops=[N, T], host_too=False)
+    rng = np.random.default_rng(44)
+    x, y0 = rand_vec(rng, p["size"][1], np.float32), rand_vec(rng, p["size"][0], np.float32)
+    first = gpu_mul(torch_cuda, bsm, D, N, x, y0, 0.5, 2.0, False)
+    for _ in range(3):
+        assert np.array_equal(first, gpu_mul(torch_cuda, bsm, D, N, x, y0, 0.5, 2.0, False))
 
 
 def test_config5_symmetric_reduced(torch_cuda, bsm, oracle):

@@ -447,3 +447,15 @@ def test_c_abi_rejects_bad_arguments(bsm):
     out = np.zeros(1, dtype=np.int64)
     nc = C.c_int64(0)
     assert lib.bsm_color(1, lp, p(two), p(out), C.byref(nc)) == -1
+
+
+def test_auto_mode_splits_only_large_deep_operators(bsm):
+    # conflict-free operators stay exclusive (one launch, direct stores) unless they are large AND
+    # made of deep row groups (include/bsm_rocm.h: BSM_ACC_AUTO / BSM_ACC_DIRECT)
+    small = bsm.synthetic.config4(ngrid=15625, row_lo=0, row_hi=20)      # 21 MB of 512 KB row groups
+    assert bsm.synthetic.build(small, device=NODEV).stats()["exclusive"] == 1
+    big = bsm.synthetic.config4(ngrid=15625, row_lo=0, row_hi=80)        # 84 MB of 512 KB row groups
+    assert bsm.synthetic.build(big, device=NODEV).stats()["exclusive"] == 0
+    assert bsm.synthetic.build(big, device=NODEV, accumulate="direct").stats()["exclusive"] == 1
+    c2 = bsm.synthetic.config2(n=200000, nblocks=10000)                   # 110 MB of ~20 KB row groups
+    assert bsm.synthetic.build(c2, device=NODEV).stats()["exclusive"] == 1
