@@ -56,7 +56,7 @@ typedef enum { BSM_SCHED_SERIAL = 0, BSM_SCHED_DYNAMIC = 1 } bsm_scheduler;
 typedef enum {
     BSM_ACC_AUTO = 0,    /* exclusive direct stores when provably conflict-free, else atomics.  Large
                             conflict-free operators made of deep row groups (most bytes in row groups
-                            above 64 KiB, e.g. 128x128 blocks, 16 per block row) are ALSO scheduled as
+                            above 128 KiB, e.g. 128x128 blocks, 16 per block row) are ALSO scheduled as
                             32 KiB work items combined with atomics: 8 % faster, but the last bits then
                             depend on the order of the adds -- BSM_ACC_DIRECT keeps them exclusive */
     BSM_ACC_ATOMIC = 1,  /* hardware fp atomics into y, blocks ordered by colour class */
