@@ -842,6 +842,9 @@ static bool stream_policy(const DeviceImage &img) {
     // (operators of a few tens of MB are a single round of resident workgroups bound by one
     // workgroup's dependency chain, where the hint costs ~5 %: 27 MB 5.8 vs 6.3 us)
     const long long mb = img.value_bytes >> 20;
+    // the retention effect was only seen on exclusive forward launches; a 242 MB fused symmetric
+    // product runs the same warm either way (39.8 vs 39.5 us) and twice as fast cold with the hint
+    if (!img.exclusive_fwd) return mb >= 40;
     return (mb >= 40 && mb < 100) || mb > 300;  // measured crossovers: ~105 MB and ~310 MB of values
 }
 
