@@ -22,7 +22,14 @@ BSM_DEVICE_CURRENT, BSM_DEVICE_NONE = -1, -2
 class BsmOptions(C.Structure):
     _fields_ = [("struct_size", C.c_int32), ("device", C.c_int32), ("scheduler", C.c_int32),
                 ("accumulate", C.c_int32), ("validate", C.c_int32), ("transpose_image", C.c_int32),
-                ("own_lo", C.c_int64), ("own_hi", C.c_int64), ("reserved", C.c_int64 * 4)]
+                ("own_lo", C.c_int64), ("own_hi", C.c_int64), ("ctx", C.c_void_p),
+                ("blocks_memspace", C.c_int64), ("reserved", C.c_int64 * 2)]
+
+
+class BsmPartInfo(C.Structure):
+    _fields_ = [("device", C.c_int32), ("reserved32", C.c_int32), ("own_lo", C.c_int64), ("own_hi", C.c_int64),
+                ("touched_lo", C.c_int64), ("touched_hi", C.c_int64), ("device_bytes", C.c_int64),
+                ("nblocks", C.c_int64), ("reserved", C.c_int64 * 4)]
 
 
 class BsmStats(C.Structure):
@@ -41,7 +48,8 @@ _lib = None
 
 # every symbol include/bsm_rocm.h declares
 EXPORTS = ["bsm_options_default", "bsm_vbcrs_create", "bsm_vbcrs_create_from_symmetric",
-           "bsm_blocksparse_create",
+           "bsm_vbcrs_create_from_blocksparse", "bsm_ctx_create", "bsm_ctx_destroy", "bsm_ctx_devices",
+           "bsm_partition_rows", "bsm_part_info", "bsm_blocksparse_create",
            "bsm_symmetric_create", "bsm_mul", "bsm_mul_multi", "bsm_get_bookkeeping", "bsm_get_image", "bsm_stats",
            "bsm_color", "bsm_destroy", "bsm_last_error", "bsm_version"]
 
@@ -85,6 +93,16 @@ def lib():
                                                   _I64P, _I64P, C.c_int64, _PP, _I64P, _I64P, _I64P,
                                                   _I64P, _I64P, C.POINTER(BsmOptions),
                                                   C.POINTER(C.c_void_p)]
+    L.bsm_vbcrs_create_from_blocksparse.argtypes = L.bsm_blocksparse_create.argtypes
+    _I32P = C.POINTER(C.c_int32)
+    L.bsm_ctx_create.argtypes = [_I32P, C.c_int32, C.POINTER(C.c_void_p)]
+    L.bsm_ctx_destroy.argtypes = [C.c_void_p]
+    L.bsm_ctx_devices.argtypes = [C.c_void_p, _I32P, _I32P, C.c_int32]
+    L.bsm_partition_rows.argtypes = [C.c_int64, C.c_int64, _I64P, _I64P, C.c_int32, _I32P, _I64P, _I64P]
+    L.bsm_part_info.argtypes = [C.c_void_p, C.c_int32, C.POINTER(BsmPartInfo)]
+    for name in ("bsm_vbcrs_create_from_blocksparse", "bsm_ctx_create", "bsm_ctx_destroy", "bsm_ctx_devices",
+                 "bsm_partition_rows", "bsm_part_info"):
+        getattr(L, name).restype = C.c_int
     L.bsm_mul.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                           C.c_int, C.c_int, C.c_void_p]
     L.bsm_mul_multi.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,

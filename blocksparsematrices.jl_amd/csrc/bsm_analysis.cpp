@@ -277,6 +277,63 @@ std::string Analysis::build(int mtype_, int dtype_, int64_t nrows_, int64_t ncol
     }
 
     lap("validate");
+    // ---- colouring (reference bookkeeping) ---------------------------------------------------
+    // Independent of everything the GPU path needs (it only reads the caller's index lists and
+    // fills `colors`): runs on its own thread while the values are packed and uploaded.
+    bool colour_oom = false;
+    auto reference_colourings = [&]() {
+        try {
+            for (auto &c : colors) c.clear();
+            if (opt.skip_colors) return;
+            auto single = [](int64_t n) {
+                std::vector<std::vector<int64_t>> out(1);
+                out[0].resize(n);
+                std::iota(out[0].begin(), out[0].end(), (int64_t)1);
+                return out;
+            };
+            if (mtype == MT_BLOCKSPARSE) {
+                if (opt.scheduler == 0) {  // reference src/blockmatrix.jl:91-92
+                    colors[0] = single(nb);
+                    colors[1] = single(nb);
+                } else {  // src/blockmatrix.jl:94-98
+                    std::vector<const int64_t *> rl(nb), cl(nb);
+                    std::vector<int64_t> rn(nb), cn(nb);
+                    for (int64_t b = 0; b < nb; b++) {
+                        rl[b] = blocks[b].ridx;
+                        rn[b] = blocks[b].ridx ? blocks[b].m : 0;
+                        cl[b] = blocks[b].cidx;
+                        cn[b] = blocks[b].cidx ? blocks[b].n : 0;
+                    }
+                    colors[0] = color_dsatur(rl, rn);
+                    colors[1] = color_dsatur(cl, cn);
+                }
+            } else if (mtype == MT_SYMMETRIC) {
+                // always three colourings, also for the serial scheduler: src/symmetricblockmatrix.jl:104-110
+                std::vector<const int64_t *> dl, rl, cl;
+                std::vector<int64_t> dn, rn, cn;
+                for (const BlockIn &B : blocks) {
+                    if (B.kind == KIND_DIAG) {
+                        dl.push_back(B.ridx);
+                        dn.push_back(B.ridx ? B.m : 0);
+                    } else {
+                        rl.push_back(B.ridx);
+                        rn.push_back(B.ridx ? B.m : 0);
+                        cl.push_back(B.cidx);
+                        cn.push_back(B.cidx ? B.n : 0);
+                    }
+                }
+                colors[0] = color_dsatur(rl, rn);
+                colors[1] = color_dsatur(cl, cn);
+                colors[2] = color_dsatur(dl, dn);
+            }
+        } catch (const std::bad_alloc &) {
+            colour_oom = true;
+        }
+    };
+    if (opt.meta_only) {  // whole-operator bookkeeping of a multi-device handle: no image
+        reference_colourings();
+        return colour_oom ? "out of host memory (colouring)" : "";
+    }
     // ---- chunks (<= 64 rows) and row groups ------------------------------------------
     const int chunk_rows = tun.chunk_rows;
     std::vector<Chunk> chunks;
@@ -284,7 +341,7 @@ std::string Analysis::build(int mtype_, int dtype_, int64_t nrows_, int64_t ncol
     std::unordered_map<uint64_t, std::vector<int64_t>> gmap;  // hash -> candidate groups
     std::vector<const int64_t *> glist;  // representative index list of indexed groups
     rows.clear();
-    cols.clear();
+    cols.assign(kColsZeroHead, 0);  // 16 zero bytes at the head of the pool (bsm_layout.h)
     for (int64_t b = 0; b < nb; b++) {
         const BlockIn &B = blocks[b];
         if (B.m == 0 || B.n == 0) continue;
@@ -356,7 +413,7 @@ std::string Analysis::build(int mtype_, int dtype_, int64_t nrows_, int64_t ncol
     // merged column lists + value offsets
     uint64_t val_units = 0;
     {
-        int64_t total_cols = 0;
+        int64_t total_cols = kColsZeroHead;
         for (const Group &G : groups) total_cols += G.width + E;
         if (total_cols + 8 > INT32_MAX) return "column index pool exceeds int32";
         cols.reserve((size_t)total_cols);
@@ -370,6 +427,7 @@ std::string Analysis::build(int mtype_, int dtype_, int64_t nrows_, int64_t ncol
     std::vector<uint8_t> group_perm(groups.size(), 0);
     colpos.reserve(cols.capacity());
     ckind.reserve(cols.capacity());
+    ckind.assign(cols.size(), 0);  // the pool's zero head
     {
         std::vector<int32_t> ord;
         size_t gi = 0;
@@ -489,58 +547,6 @@ std::string Analysis::build(int mtype_, int dtype_, int64_t nrows_, int64_t ncol
     }
 
     lap("exclusivity / fused colours");
-    // ---- colouring (reference bookkeeping) ---------------------------------------------------
-    // Independent of everything the GPU path needs (it only reads the caller's index lists and
-    // fills `colors`): runs on its own thread while the values are packed and uploaded.
-    bool colour_oom = false;
-    auto reference_colourings = [&]() {
-        try {
-            for (auto &c : colors) c.clear();
-            auto single = [](int64_t n) {
-                std::vector<std::vector<int64_t>> out(1);
-                out[0].resize(n);
-                std::iota(out[0].begin(), out[0].end(), (int64_t)1);
-                return out;
-            };
-            if (mtype == MT_BLOCKSPARSE) {
-                if (opt.scheduler == 0) {  // reference src/blockmatrix.jl:91-92
-                    colors[0] = single(nb);
-                    colors[1] = single(nb);
-                } else {  // src/blockmatrix.jl:94-98
-                    std::vector<const int64_t *> rl(nb), cl(nb);
-                    std::vector<int64_t> rn(nb), cn(nb);
-                    for (int64_t b = 0; b < nb; b++) {
-                        rl[b] = blocks[b].ridx;
-                        rn[b] = blocks[b].ridx ? blocks[b].m : 0;
-                        cl[b] = blocks[b].cidx;
-                        cn[b] = blocks[b].cidx ? blocks[b].n : 0;
-                    }
-                    colors[0] = color_dsatur(rl, rn);
-                    colors[1] = color_dsatur(cl, cn);
-                }
-            } else if (mtype == MT_SYMMETRIC) {
-                // always three colourings, also for the serial scheduler: src/symmetricblockmatrix.jl:104-110
-                std::vector<const int64_t *> dl, rl, cl;
-                std::vector<int64_t> dn, rn, cn;
-                for (const BlockIn &B : blocks) {
-                    if (B.kind == KIND_DIAG) {
-                        dl.push_back(B.ridx);
-                        dn.push_back(B.ridx ? B.m : 0);
-                    } else {
-                        rl.push_back(B.ridx);
-                        rn.push_back(B.ridx ? B.m : 0);
-                        cl.push_back(B.cidx);
-                        cn.push_back(B.cidx ? B.n : 0);
-                    }
-                }
-                colors[0] = color_dsatur(rl, rn);
-                colors[1] = color_dsatur(cl, cn);
-                colors[2] = color_dsatur(dl, dn);
-            }
-        } catch (const std::bad_alloc &) {
-            colour_oom = true;
-        }
-    };
     std::thread colour_thread(reference_colourings);
     struct Joiner {
         std::thread &t;
@@ -1022,75 +1028,6 @@ std::vector<int64_t> Analysis::vbcrs_bookkeeping(int64_t nblocks, const int64_t 
     }
     rowptr.push_back(nblocks + 1);
     return p;
-}
-
-std::string Analysis::build_vbcrs_symmetric_view(int dtype_, int64_t nrows_, int64_t ncols_, int64_t ndiag,
-                                                 const void *const *diag, const int64_t *dsize,
-                                                 const int64_t *dld, const int64_t *diagstart,
-                                                 int64_t noff, const void *const *off, const int64_t *m,
-                                                 const int64_t *n, const int64_t *ld,
-                                                 const int64_t *rowstart, const int64_t *colstart,
-                                                 const AnalysisOptions &opt_) {
-    const int64_t nv = ndiag + 2 * noff;
-    if (nv < 1) return "VBCRS needs at least one block (reference src/vbcrs.jl:81)";
-    // virtual block list of the reference's functors (src/vbcrs.jl:222-262)
-    std::vector<int64_t> rs(nv), cs(nv);
-    for (int64_t d = 0; d < ndiag; d++) rs[d] = cs[d] = diagstart[d];
-    for (int64_t b = 0; b < noff; b++) {
-        rs[ndiag + b] = rowstart[b];
-        cs[ndiag + b] = colstart[b];
-        rs[ndiag + noff + b] = colstart[b];
-        cs[ndiag + noff + b] = rowstart[b];
-    }
-    vbcrs_bookkeeping(nv, rs.data(), cs.data());
-    std::vector<BlockIn> in;
-    in.reserve((size_t)(ndiag + noff));
-    for (int64_t d = 0; d < ndiag; d++) {
-        BlockIn B;
-        B.data = (const char *)diag[d];
-        B.m = B.n = dsize[d];
-        B.ld = dld[d];
-        B.ridx = B.cidx = nullptr;
-        B.r0 = B.c0 = diagstart[d];
-        B.kind = KIND_DIAG;
-        in.push_back(B);
-    }
-    for (int64_t b = 0; b < noff; b++) {
-        BlockIn B;
-        B.data = (const char *)off[b];
-        B.m = m[b];
-        B.n = n[b];
-        B.ld = ld[b];
-        B.ridx = B.cidx = nullptr;
-        B.r0 = rowstart[b];
-        B.c0 = colstart[b];
-        B.kind = KIND_OFF;
-        in.push_back(B);
-    }
-    return build(MT_VBCRS, dtype_, nrows_, ncols_, in, opt_);
-}
-
-std::string Analysis::build_vbcrs(int dtype_, int64_t nrows_, int64_t ncols_, int64_t nblocks,
-                                  const void *const *blocks, const int64_t *m, const int64_t *n,
-                                  const int64_t *ld, const int64_t *rowstart,
-                                  const int64_t *colstart, const AnalysisOptions &opt_) {
-    if (nblocks < 1) return "VBCRS needs at least one block (reference src/vbcrs.jl:81)";
-    const std::vector<int64_t> p = vbcrs_bookkeeping(nblocks, rowstart, colstart);
-    std::vector<BlockIn> in(nblocks);
-    for (int64_t out = 0; out < nblocks; out++) {
-        const int64_t i = p[out];
-        BlockIn &B = in[out];
-        B.data = (const char *)blocks[i];
-        B.m = m[i];
-        B.n = n[i];
-        B.ld = ld[i];
-        B.ridx = nullptr;
-        B.cidx = nullptr;
-        B.r0 = rowstart[i];
-        B.c0 = colstart[i];
-        B.kind = KIND_PLAIN;
-    }
-    return build(MT_VBCRS, dtype_, nrows_, ncols_, in, opt_);
 }
 
 }  // namespace bsm

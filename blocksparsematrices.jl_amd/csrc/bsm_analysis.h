@@ -85,6 +85,8 @@ struct AnalysisOptions {
     int accumulate = 0;  // 0 auto, 1 atomic, 2 coloured launches, 3 gather (both bitwise reproducible), 4 direct
     int64_t own_lo = 0, own_hi = 0;  // 1-based inclusive, 0,0 = all rows
     ValueSink *sink = nullptr;       // not owned; nullptr: pack into Analysis::values
+    bool meta_only = false;    // validation, statistics and the reference colourings only (no image)
+    bool skip_colors = false;  // leave `colors` empty (the parts of a multi-device handle)
 };
 
 // Deterministic DSATUR colouring of blocks by index-list conflicts (two blocks conflict
@@ -135,23 +137,6 @@ class Analysis {
     // Fills perm / rowptr / colindices / rowindices exactly as src/vbcrs.jl:84-117 and returns the
     // sorted order (0-based input positions).
     std::vector<int64_t> vbcrs_bookkeeping(int64_t nblocks, const int64_t *rowstart, const int64_t *colstart);
-
-    // VBCRS front end: sorts, fills perm/rowptr/..., then calls build with sorted blocks.
-    std::string build_vbcrs(int dtype, int64_t nrows, int64_t ncols, int64_t nblocks,
-                            const void *const *blocks, const int64_t *m, const int64_t *n,
-                            const int64_t *ld, const int64_t *rowstart, const int64_t *colstart,
-                            const AnalysisOptions &opt);
-
-    // VariableBlockCompressedRowStorage(sbm::SymmetricBlockMatrix) WITHOUT materialising the
-    // transposed off-diagonal blocks (reference src/vbcrs.jl:189-264 does, doubling the storage):
-    // bookkeeping is that of the expanded [diag..., off..., transpose(off)...] list, the device
-    // image is the symmetric one (every off-diagonal block stored and streamed once).
-    std::string build_vbcrs_symmetric_view(int dtype, int64_t nrows, int64_t ncols, int64_t ndiag,
-                                           const void *const *diag, const int64_t *dsize,
-                                           const int64_t *dld, const int64_t *diagstart, int64_t noff,
-                                           const void *const *off, const int64_t *m, const int64_t *n,
-                                           const int64_t *ld, const int64_t *rowstart,
-                                           const int64_t *colstart, const AnalysisOptions &opt);
 };
 
 }  // namespace bsm

@@ -10,31 +10,9 @@
 #include <string>
 #include <vector>
 
-#include "../../include/bsm_rocm.h"
-#include "bsm_analysis.h"
-#include "bsm_kernels.h"
+#include "bsm_internal.h"
 
 using namespace bsm;
-
-struct bsm_matrix_s {
-    Analysis an;
-    DeviceImage img;
-    bool on_device = false;
-    // optional second ordering (bsm_options.transpose_image): the transposed operator as its own
-    // forward image
-    bool has_t = false;
-    Analysis an_t;
-    DeviceImage img_t;
-    // device staging buffers of the BSM_MEM_HOST path, kept between calls (grow-only); a second
-    // concurrent host call on the same handle falls back to temporary buffers
-    std::mutex gather_mu;  // the gather workspace admits one product in flight per handle
-    hipEvent_t ws_done = nullptr;    // recorded after the last gather-mode product
-    hipStream_t ws_stream = nullptr;  // ... on this stream
-    bool ws_pending = false;
-    std::mutex host_mu;
-    void *stage_x = nullptr, *stage_y = nullptr;
-    size_t stage_x_bytes = 0, stage_y_bytes = 0;
-};
 
 namespace {
 // RAII staging buffers: cached in the handle when uncontended, temporary otherwise
@@ -85,14 +63,30 @@ struct Staging {
 
 static thread_local std::string g_err;
 
-static int fail(int code, const std::string &msg) {
+namespace bsm {
+int fail(int code, const std::string &msg) {
     g_err = msg;
     return code;
 }
 
-static int hip_fail(hipError_t e, const char *what) {
+int hip_fail(hipError_t e, const char *what) {
     return fail(BSM_ERR_DEVICE, std::string(what) + ": " + hipGetErrorString(e));
 }
+
+hipError_t DeviceGuard::enter(int dev) {
+    hipError_t e = hipGetDevice(&prev);
+    if (e != hipSuccess) return e;
+    if (prev != dev) {
+        e = hipSetDevice(dev);
+        if (e != hipSuccess) return e;
+        active = true;
+    }
+    return hipSuccess;
+}
+DeviceGuard::~DeviceGuard() {
+    if (active) (void)hipSetDevice(prev);
+}
+}  // namespace bsm
 
 extern "C" const char *bsm_last_error(void) { return g_err.c_str(); }
 
@@ -108,25 +102,7 @@ extern "C" void bsm_options_default(bsm_options *o) {
     o->validate = 1;
 }
 
-namespace {
-
-struct DeviceGuard {
-    int prev = -1;
-    bool active = false;
-    hipError_t enter(int dev) {
-        hipError_t e = hipGetDevice(&prev);
-        if (e != hipSuccess) return e;
-        if (prev != dev) {
-            e = hipSetDevice(dev);
-            if (e != hipSuccess) return e;
-            active = true;
-        }
-        return hipSuccess;
-    }
-    ~DeviceGuard() {
-        if (active) (void)hipSetDevice(prev);
-    }
-};
+namespace bsm {
 
 int read_options(const bsm_options *opts, bsm_options &o) {
     bsm_options_default(&o);
@@ -229,6 +205,8 @@ struct DeviceSink : ValueSink {
     }
 };
 
+std::unique_ptr<ValueSink> make_device_sink(void **d_values) { return std::unique_ptr<ValueSink>(new DeviceSink(d_values)); }
+
 void free_image(DeviceImage &img) {
     for (void **p : {&img.d_values, &img.d_rows, &img.d_cols, &img.d_waves, &img.d_ws, &img.d_inv_ptr[0],
                      &img.d_inv_ptr[1], &img.d_inv_idx[0], &img.d_inv_idx[1]}) {
@@ -300,6 +278,7 @@ struct CreateCtx {
         if (!A) return;
         free_image(A->img);  // the handle's device is still current (guard outlives this body)
         free_image(A->img_t);
+        dist_destroy(A);
         delete A;
     }
     bsm_matrix_s *release() {
@@ -382,48 +361,123 @@ AnalysisOptions to_aopt(const bsm_options &o, ValueSink *sink) {
     return a;
 }
 
+}  // namespace bsm
+
+namespace {
+
+// Common tail of every *_create: `in` is the block list in its final order (VBCRS: sorted, with
+// A->an's perm / rowptr / ... already filled).  Single device: analysis + packing + upload; with
+// bsm_options.ctx: whole-operator bookkeeping, then one image per device of the context.
+int create_handle(int mtype, int dtype, int64_t nrows, int64_t ncols, const std::vector<BlockIn> &in,
+                  const bsm_options &o, CreateCtx &cx, bsm_matrix_t *out) {
+    bsm_matrix_s *A = cx.A;
+    if (o.ctx) {
+        AnalysisOptions ao = to_aopt(o, nullptr);
+        ao.meta_only = true;
+        ao.own_lo = ao.own_hi = 0;
+        std::string err = A->an.build(mtype, dtype, nrows, ncols, in, ao);
+        if (!err.empty()) return build_error(err);
+        int rc = dist_create(A, (bsm_ctx_s *)o.ctx, mtype, dtype, nrows, ncols, in, o);
+        if (rc != BSM_OK) return rc;  // ~CreateCtx releases whatever the parts already hold
+        A->on_device = true;
+        *out = cx.release();
+        return BSM_OK;
+    }
+    int rc = cx.open(o);
+    if (rc != BSM_OK) return rc;
+    std::string err = A->an.build(mtype, dtype, nrows, ncols, in, to_aopt(o, cx.values()));
+    if (err.empty() && o.transpose_image && mtype != MT_SYMMETRIC) {
+        bool plain = true;
+        for (const BlockIn &B : in) plain &= (B.kind == KIND_PLAIN);
+        if (plain) err = build_transpose_image(A, in, o, cx.values_t());
+    }
+    if (!err.empty()) return build_error(err);
+    return finish_create(cx, o, out);
+}
+
+// VBCRS front end (reference src/vbcrs.jl:84-117): stable sort by (rowstart, colstart), rowptr, ...
+int create_vbcrs(int dtype, int64_t nrows, int64_t ncols, const std::vector<BlockIn> &unsorted,
+                 const bsm_options &o, bsm_matrix_t *out) {
+    const int64_t nb = (int64_t)unsorted.size();
+    std::vector<int64_t> rs(nb), cs(nb);
+    for (int64_t b = 0; b < nb; b++) {
+        rs[b] = unsorted[b].r0;
+        cs[b] = unsorted[b].c0;
+    }
+    CreateCtx cx;
+    const std::vector<int64_t> p = cx.A->an.vbcrs_bookkeeping(nb, rs.data(), cs.data());
+    std::vector<BlockIn> in(nb);
+    for (int64_t k = 0; k < nb; k++) in[k] = unsorted[p[k]];
+    return create_handle(MT_VBCRS, dtype, nrows, ncols, in, o, cx, out);
+}
+
 }  // namespace
+
+#define BSM_GUARDED(...)                                         \
+    try {                                                        \
+        __VA_ARGS__                                              \
+    } catch (const std::bad_alloc &) {                           \
+        return fail(BSM_ERR_ALLOC, "out of host memory");        \
+    } catch (const std::exception &e) {                          \
+        return fail(BSM_ERR_INVALID, e.what());                  \
+    }
 
 extern "C" int bsm_vbcrs_create(int dtype, int64_t nrows, int64_t ncols, int64_t nblocks,
                                 const void *const *blocks, const int64_t *m, const int64_t *n,
                                 const int64_t *ld, const int64_t *rowstart, const int64_t *colstart,
                                 const bsm_options *opts, bsm_matrix_t *out) {
-    try {
+    BSM_GUARDED(
         if (!out) return fail(BSM_ERR_INVALID, "out is null");
         *out = nullptr;
-        if (nblocks < 1) return fail(BSM_ERR_INVALID, "VBCRS needs at least one block");
-        if (!blocks || !m || !n || !ld || !rowstart || !colstart)
-            return fail(BSM_ERR_INVALID, "null argument");
+        if (nblocks < 1) return fail(BSM_ERR_INVALID, "VBCRS needs at least one block (reference src/vbcrs.jl:81)");
+        if (!blocks || !m || !n || !ld || !rowstart || !colstart) return fail(BSM_ERR_INVALID, "null argument");
         bsm_options o;
         int rc = read_options(opts, o);
         if (rc) return rc;
-        CreateCtx cx;
-        if ((rc = cx.open(o)) != BSM_OK) return rc;
-        bsm_matrix_s *A = cx.A;
-        std::string err = A->an.build_vbcrs(dtype, nrows, ncols, nblocks, blocks, m, n, ld, rowstart,
-                                            colstart, to_aopt(o, cx.values()));
-        if (err.empty() && o.transpose_image) {
-            std::vector<BlockIn> in((size_t)nblocks);
-            for (int64_t b = 0; b < nblocks; b++) {
-                BlockIn &B = in[b];
-                B.data = (const char *)blocks[b];
-                B.m = m[b];
-                B.n = n[b];
-                B.ld = ld[b];
-                B.ridx = B.cidx = nullptr;
-                B.r0 = rowstart[b];
-                B.c0 = colstart[b];
-                B.kind = KIND_PLAIN;
-            }
-            err = build_transpose_image(A, in, o, cx.values_t());
+        std::vector<BlockIn> in((size_t)nblocks);
+        for (int64_t b = 0; b < nblocks; b++) {
+            BlockIn &B = in[b];
+            B.data = (const char *)blocks[b];
+            B.m = m[b];
+            B.n = n[b];
+            B.ld = ld[b];
+            B.ridx = B.cidx = nullptr;
+            B.r0 = rowstart[b];
+            B.c0 = colstart[b];
+            B.kind = KIND_PLAIN;
         }
-        if (!err.empty()) return build_error(err);
-        return finish_create(cx, o, out);
-    } catch (const std::bad_alloc &) {
-        return fail(BSM_ERR_ALLOC, "out of host memory");
-    } catch (const std::exception &e) {
-        return fail(BSM_ERR_INVALID, e.what());
-    }
+        return create_vbcrs(dtype, nrows, ncols, in, o, out);)
+}
+
+extern "C" int bsm_vbcrs_create_from_blocksparse(int dtype, int64_t nrows, int64_t ncols, int64_t nblocks,
+                                                 const void *const *blocks, const int64_t *m,
+                                                 const int64_t *n, const int64_t *ld,
+                                                 const int64_t *const *rowidx, const int64_t *const *colidx,
+                                                 const bsm_options *opts, bsm_matrix_t *out) {
+    BSM_GUARDED(
+        if (!out) return fail(BSM_ERR_INVALID, "out is null");
+        *out = nullptr;
+        if (nblocks < 1) return fail(BSM_ERR_INVALID, "VBCRS needs at least one block (reference src/vbcrs.jl:81)");
+        if (!blocks || !m || !n || !ld || !rowidx || !colidx) return fail(BSM_ERR_INVALID, "null argument");
+        bsm_options o;
+        int rc = read_options(opts, o);
+        if (rc) return rc;
+        std::vector<BlockIn> in((size_t)nblocks);
+        for (int64_t b = 0; b < nblocks; b++) {
+            BlockIn &B = in[b];
+            // first(rowindices(bsm, i)), first(colindices(bsm, i)): reference src/vbcrs.jl:201-215
+            if (m[b] < 1 || n[b] < 1 || !rowidx[b] || !colidx[b])
+                return fail(BSM_ERR_INVALID, "block " + std::to_string(b + 1) + ": empty index list (first() of it is undefined)");
+            B.data = (const char *)blocks[b];
+            B.m = m[b];
+            B.n = n[b];
+            B.ld = ld[b];
+            B.ridx = B.cidx = nullptr;
+            B.r0 = rowidx[b][0];
+            B.c0 = colidx[b][0];
+            B.kind = KIND_PLAIN;
+        }
+        return create_vbcrs(dtype, nrows, ncols, in, o, out);)
 }
 
 extern "C" int bsm_vbcrs_create_from_symmetric(int dtype, int64_t nrows, int64_t ncols, int64_t ndiag,
@@ -433,29 +487,54 @@ extern "C" int bsm_vbcrs_create_from_symmetric(int dtype, int64_t nrows, int64_t
                                                const int64_t *n, const int64_t *ld,
                                                const int64_t *rowstart, const int64_t *colstart,
                                                const bsm_options *opts, bsm_matrix_t *out) {
-    try {
+    BSM_GUARDED(
         if (!out) return fail(BSM_ERR_INVALID, "out is null");
         *out = nullptr;
         if (ndiag < 0 || noff < 0 || ndiag + noff < 1) return fail(BSM_ERR_INVALID, "VBCRS needs at least one block");
         if (ndiag > 0 && (!diag || !dsize || !dld || !diagstart)) return fail(BSM_ERR_INVALID, "null argument");
-        if (noff > 0 && (!off || !m || !n || !ld || !rowstart || !colstart))
-            return fail(BSM_ERR_INVALID, "null argument");
+        if (noff > 0 && (!off || !m || !n || !ld || !rowstart || !colstart)) return fail(BSM_ERR_INVALID, "null argument");
         bsm_options o;
         int rc = read_options(opts, o);
         if (rc) return rc;
+        // bookkeeping over the virtual block list of the reference's functors (src/vbcrs.jl:222-262):
+        // [diagonals..., offdiagonals..., transpose(offdiagonals)...]
+        const int64_t nv = ndiag + 2 * noff;
+        std::vector<int64_t> rs(nv), cs(nv);
+        for (int64_t d = 0; d < ndiag; d++) rs[d] = cs[d] = diagstart[d];
+        for (int64_t b = 0; b < noff; b++) {
+            rs[ndiag + b] = rowstart[b];
+            cs[ndiag + b] = colstart[b];
+            rs[ndiag + noff + b] = colstart[b];
+            cs[ndiag + noff + b] = rowstart[b];
+        }
         CreateCtx cx;
-        if ((rc = cx.open(o)) != BSM_OK) return rc;
-        bsm_matrix_s *A = cx.A;
-        std::string err = A->an.build_vbcrs_symmetric_view(dtype, nrows, ncols, ndiag, diag, dsize, dld,
-                                                           diagstart, noff, off, m, n, ld, rowstart,
-                                                           colstart, to_aopt(o, cx.values()));
-        if (!err.empty()) return build_error(err);
-        return finish_create(cx, o, out);
-    } catch (const std::bad_alloc &) {
-        return fail(BSM_ERR_ALLOC, "out of host memory");
-    } catch (const std::exception &e) {
-        return fail(BSM_ERR_INVALID, e.what());
-    }
+        cx.A->an.vbcrs_bookkeeping(nv, rs.data(), cs.data());
+        // ... the image keeps every off-diagonal block once (the symmetric one)
+        std::vector<BlockIn> in;
+        in.reserve((size_t)(ndiag + noff));
+        for (int64_t d = 0; d < ndiag; d++) {
+            BlockIn B;
+            B.data = (const char *)diag[d];
+            B.m = B.n = dsize[d];
+            B.ld = dld[d];
+            B.ridx = B.cidx = nullptr;
+            B.r0 = B.c0 = diagstart[d];
+            B.kind = KIND_DIAG;
+            in.push_back(B);
+        }
+        for (int64_t b = 0; b < noff; b++) {
+            BlockIn B;
+            B.data = (const char *)off[b];
+            B.m = m[b];
+            B.n = n[b];
+            B.ld = ld[b];
+            B.ridx = B.cidx = nullptr;
+            B.r0 = rowstart[b];
+            B.c0 = colstart[b];
+            B.kind = KIND_OFF;
+            in.push_back(B);
+        }
+        return create_handle(MT_VBCRS, dtype, nrows, ncols, in, o, cx, out);)
 }
 
 extern "C" int bsm_blocksparse_create(int dtype, int64_t nrows, int64_t ncols, int64_t nblocks,
@@ -463,12 +542,11 @@ extern "C" int bsm_blocksparse_create(int dtype, int64_t nrows, int64_t ncols, i
                                       const int64_t *ld, const int64_t *const *rowidx,
                                       const int64_t *const *colidx, const bsm_options *opts,
                                       bsm_matrix_t *out) {
-    try {
+    BSM_GUARDED(
         if (!out) return fail(BSM_ERR_INVALID, "out is null");
         *out = nullptr;
         if (nblocks < 0) return fail(BSM_ERR_INVALID, "negative block count");
-        if (nblocks > 0 && (!blocks || !m || !n || !ld || !rowidx || !colidx))
-            return fail(BSM_ERR_INVALID, "null argument");
+        if (nblocks > 0 && (!blocks || !m || !n || !ld || !rowidx || !colidx)) return fail(BSM_ERR_INVALID, "null argument");
         bsm_options o;
         int rc = read_options(opts, o);
         if (rc) return rc;
@@ -487,17 +565,7 @@ extern "C" int bsm_blocksparse_create(int dtype, int64_t nrows, int64_t ncols, i
                 return fail(BSM_ERR_INVALID, "block " + std::to_string(b + 1) + ": null index list");
         }
         CreateCtx cx;
-        if ((rc = cx.open(o)) != BSM_OK) return rc;
-        bsm_matrix_s *A = cx.A;
-        std::string err = A->an.build(MT_BLOCKSPARSE, dtype, nrows, ncols, in, to_aopt(o, cx.values()));
-        if (err.empty() && o.transpose_image) err = build_transpose_image(A, in, o, cx.values_t());
-        if (!err.empty()) return build_error(err);
-        return finish_create(cx, o, out);
-    } catch (const std::bad_alloc &) {
-        return fail(BSM_ERR_ALLOC, "out of host memory");
-    } catch (const std::exception &e) {
-        return fail(BSM_ERR_INVALID, e.what());
-    }
+        return create_handle(MT_BLOCKSPARSE, dtype, nrows, ncols, in, o, cx, out);)
 }
 
 extern "C" int bsm_symmetric_create(int dtype, int64_t nrows, int64_t ncols, int64_t ndiag,
@@ -507,13 +575,12 @@ extern "C" int bsm_symmetric_create(int dtype, int64_t nrows, int64_t ncols, int
                                     const int64_t *ld, const int64_t *const *rowidx,
                                     const int64_t *const *colidx, const bsm_options *opts,
                                     bsm_matrix_t *out) {
-    try {
+    BSM_GUARDED(
         if (!out) return fail(BSM_ERR_INVALID, "out is null");
         *out = nullptr;
         if (ndiag < 0 || noff < 0) return fail(BSM_ERR_INVALID, "negative block count");
         if (ndiag > 0 && (!diag || !dsize || !dld || !diagidx)) return fail(BSM_ERR_INVALID, "null argument");
-        if (noff > 0 && (!off || !m || !n || !ld || !rowidx || !colidx))
-            return fail(BSM_ERR_INVALID, "null argument");
+        if (noff > 0 && (!off || !m || !n || !ld || !rowidx || !colidx)) return fail(BSM_ERR_INVALID, "null argument");
         bsm_options o;
         int rc = read_options(opts, o);
         if (rc) return rc;
@@ -546,16 +613,80 @@ extern "C" int bsm_symmetric_create(int dtype, int64_t nrows, int64_t ncols, int
             in.push_back(B);
         }
         CreateCtx cx;
-        if ((rc = cx.open(o)) != BSM_OK) return rc;
-        bsm_matrix_s *A = cx.A;
-        std::string err = A->an.build(MT_SYMMETRIC, dtype, nrows, ncols, in, to_aopt(o, cx.values()));
-        if (!err.empty()) return build_error(err);
-        return finish_create(cx, o, out);
-    } catch (const std::bad_alloc &) {
-        return fail(BSM_ERR_ALLOC, "out of host memory");
-    } catch (const std::exception &e) {
-        return fail(BSM_ERR_INVALID, e.what());
+        return create_handle(MT_SYMMETRIC, dtype, nrows, ncols, in, o, cx, out);)
+}
+
+// ---- contexts of devices (multi-GPU handles) -----------------------------------------------------
+extern "C" int bsm_ctx_create(const int32_t *device_ids, int32_t ndevices, bsm_ctx_t *out) {
+    BSM_GUARDED(
+        if (!out) return fail(BSM_ERR_INVALID, "out is null");
+        *out = nullptr;
+        if (ndevices < 1 || ndevices > 64 || !device_ids) return fail(BSM_ERR_INVALID, "a context needs 1..64 devices");
+        int count = 0;
+        hipError_t e = hipGetDeviceCount(&count);
+        if (e != hipSuccess) return hip_fail(e, "hipGetDeviceCount");
+        std::unique_ptr<bsm_ctx_s> ctx(new bsm_ctx_s());
+        for (int32_t i = 0; i < ndevices; i++) {
+            if (device_ids[i] < 0 || device_ids[i] >= count)
+                return fail(BSM_ERR_INVALID, "device ordinal " + std::to_string(device_ids[i]) + " does not exist");
+            ctx->devices.push_back(device_ids[i]);
+        }
+        // direct xGMI access between every pair of distinct devices (the halo copies then run device
+        // to device; without it the runtime stages them through host memory, still correct)
+        for (int a : ctx->devices)
+            for (int b : ctx->devices) {
+                if (a == b) continue;
+                int can = 0;
+                if (hipDeviceCanAccessPeer(&can, a, b) != hipSuccess || !can) {
+                    (void)hipGetLastError();
+                    continue;
+                }
+                DeviceGuard g;
+                if (g.enter(a) != hipSuccess) continue;
+                hipError_t pe = hipDeviceEnablePeerAccess(b, 0);
+                if (pe != hipSuccess) (void)hipGetLastError();  // already enabled
+            }
+        *out = ctx.release();
+        return BSM_OK;)
+}
+
+extern "C" int bsm_ctx_destroy(bsm_ctx_t ctx) {
+    delete ctx;
+    return BSM_OK;
+}
+
+extern "C" int bsm_ctx_devices(bsm_ctx_t ctx, int32_t *ndevices, int32_t *device_ids, int32_t capacity) {
+    if (!ctx || !ndevices) return fail(BSM_ERR_INVALID, "null argument");
+    *ndevices = (int32_t)ctx->devices.size();
+    if (device_ids) {
+        if (capacity < *ndevices) return fail(BSM_ERR_INVALID, "output buffer too small");
+        for (size_t i = 0; i < ctx->devices.size(); i++) device_ids[i] = ctx->devices[i];
     }
+    return BSM_OK;
+}
+
+extern "C" int bsm_partition_rows(int64_t nrows, int64_t nblocks, const int64_t *rowkey, const int64_t *weight,
+                                  int32_t nparts, int32_t *part_of_block, int64_t *own_lo, int64_t *own_hi) {
+    BSM_GUARDED(
+        if (nparts < 1 || nblocks < 0 || nrows < 0 || !own_lo || !own_hi || (nblocks > 0 && (!rowkey || !weight || !part_of_block)))
+            return fail(BSM_ERR_INVALID, "bad argument");
+        std::vector<int64_t> key(rowkey, rowkey + nblocks), w(weight, weight + nblocks), lo, hi;
+        for (int64_t b = 0; b < nblocks; b++)
+            if (key[b] < 1 || key[b] > std::max<int64_t>(nrows, 1)) return fail(BSM_ERR_INVALID, "row key outside the matrix");
+        std::vector<int32_t> part;
+        partition_rows(nrows, key, w, nparts, part, lo, hi);
+        for (int64_t b = 0; b < nblocks; b++) part_of_block[b] = part[b];
+        for (int32_t p = 0; p < nparts; p++) {
+            own_lo[p] = lo[p];
+            own_hi[p] = hi[p];
+        }
+        return BSM_OK;)
+}
+
+extern "C" int bsm_part_info(bsm_matrix_t A, int32_t part, bsm_part_info_t *out) {
+    if (!A || !out) return fail(BSM_ERR_INVALID, "null argument");
+    if (!A->dist) return fail(BSM_ERR_INVALID, "not a multi-device handle");
+    return dist_part_info(A, part, out);
 }
 
 extern "C" int bsm_mul(bsm_matrix_t A, int op, const void *x, void *y, const void *alpha,
@@ -565,6 +696,7 @@ extern "C" int bsm_mul(bsm_matrix_t A, int op, const void *x, void *y, const voi
     if (!x || !y) return fail(BSM_ERR_INVALID, "null vector");
     if (!A->on_device)
         return fail(BSM_ERR_DEVICE, "handle has no device image (created with BSM_DEVICE_NONE)");
+    if (A->dist) return dist_mul(A, op, x, y, alpha, beta, beta_strong_zero, memspace, (hipStream_t)stream);
     // transposed products run forward on the second ordering when the handle has one
     const bool use_t = (op != BSM_OP_N) && A->has_t;
     const DeviceImage &img = use_t ? A->img_t : A->img;
@@ -624,7 +756,10 @@ extern "C" int bsm_mul(bsm_matrix_t A, int op, const void *x, void *y, const voi
     e = sg.acquire(A, xlen * es, ylen * es);
     void *dx = sg.dx, *dy = sg.dy;
     if (e == hipSuccess) e = hipMemcpyAsync(dx, x, xlen * es, hipMemcpyHostToDevice, st);
-    if (e == hipSuccess && !beta_strong_zero)
+    // the incoming y travels when beta uses it -- and whenever the handle owns only a row range: rows
+    // outside it that no block reaches are left untouched by the product and must come back unchanged
+    const bool partial = (op == BSM_OP_N) && (img.own_lo > 0 || img.own_hi < img.nrows);
+    if (e == hipSuccess && (!beta_strong_zero || partial))
         e = hipMemcpyAsync(dy, y, ylen * es, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = launch_mul(img, opT, conj, dx, dy, alpha, beta, beta_strong_zero, st, use_gather);
     if (e == hipSuccess) e = hipMemcpyAsync(y, dy, ylen * es, hipMemcpyDeviceToHost, st);
@@ -647,6 +782,15 @@ extern "C" int bsm_mul_multi(bsm_matrix_t A, int op, int64_t nrhs, const void *X
     const long long ylen = (op == 0 ? A->img.nrows : A->img.ncols);
     if (ldx < std::max<long long>(xlen, 1) || ldy < std::max<long long>(ylen, 1))
         return fail(BSM_ERR_INVALID, "leading dimension smaller than the vector length");
+    if (A->dist) {  // multi-device handles: one fan-out per column
+        const size_t esz = (size_t)A->an.es;
+        for (int64_t k = 0; k < nrhs; k++) {
+            int rc = dist_mul(A, op, (const char *)X + (size_t)k * ldx * esz, (char *)Y + (size_t)k * ldy * esz, alpha,
+                              beta, beta_strong_zero, memspace, (hipStream_t)stream);
+            if (rc != BSM_OK) return rc;
+        }
+        return BSM_OK;
+    }
     const bool use_t = (op != BSM_OP_N) && A->has_t;
     const DeviceImage &img = use_t ? A->img_t : A->img;
     const bool opT = (op != BSM_OP_N) && !use_t;
@@ -668,7 +812,8 @@ extern "C" int bsm_mul_multi(bsm_matrix_t A, int op, int64_t nrhs, const void *X
     if (e == hipSuccess)
         e = hipMemcpy2DAsync(dx, (size_t)xlen * es, X, (size_t)ldx * es, (size_t)xlen * es, (size_t)nrhs,
                              hipMemcpyHostToDevice, st);
-    if (e == hipSuccess && !beta_strong_zero)
+    const bool partial = (op == BSM_OP_N) && (img.own_lo > 0 || img.own_hi < img.nrows);  // see bsm_mul
+    if (e == hipSuccess && (!beta_strong_zero || partial))
         e = hipMemcpy2DAsync(dy, (size_t)ylen * es, Y, (size_t)ldy * es, (size_t)ylen * es, (size_t)nrhs,
                              hipMemcpyHostToDevice, st);
     if (e == hipSuccess)
@@ -727,7 +872,7 @@ extern "C" int bsm_get_bookkeeping(bsm_matrix_t A, int which, int64_t *out, int6
 
 extern "C" int bsm_get_image(bsm_matrix_t A, int which, void *out, int64_t *nbytes) {
     if (!A || !nbytes) return fail(BSM_ERR_INVALID, "null argument");
-    if (A->on_device) return fail(BSM_ERR_UNSUPPORTED, "image dump needs an analysis-only handle");
+    if (A->on_device || A->dist) return fail(BSM_ERR_UNSUPPORTED, "image dump needs an analysis-only handle");
     if (which >= 16 && !A->has_t) return fail(BSM_ERR_INVALID, "handle has no transposed image");
     const Analysis &an = (which >= 16) ? A->an_t : A->an;
     which &= 15;
@@ -758,7 +903,7 @@ extern "C" int bsm_stats(bsm_matrix_t A, bsm_stats_t *out) {
     out->nnz = A->an.nnz;
     out->stored_entries = A->an.stored_entries;
     out->alg_bytes = A->an.alg_bytes;
-    out->device_bytes = A->img.device_bytes + (A->has_t ? A->img_t.device_bytes : 0);
+    out->device_bytes = A->dist ? dist_device_bytes(A) : A->img.device_bytes + (A->has_t ? A->img_t.device_bytes : 0);
     out->npanels = A->an.ngroups;
     out->ntasks = (int64_t)A->an.waves.size();
     out->nworkgroups = A->img.nwg_total;
@@ -792,7 +937,9 @@ extern "C" int bsm_color(int64_t nlists, const int64_t *const *lists, const int6
 
 extern "C" int bsm_destroy(bsm_matrix_t A) {
     if (!A) return BSM_OK;
-    if (A->on_device) {
+    if (A->dist) {
+        dist_destroy(A);
+    } else if (A->on_device) {
         DeviceGuard guard;
         (void)guard.enter(A->img.device);
         free_image(A->img);

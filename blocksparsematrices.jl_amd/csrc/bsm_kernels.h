@@ -32,7 +32,14 @@ struct DeviceImage {
 // use_gather: take the two-launch gather path (only if the image has a workspace).
 hipError_t launch_mul(const DeviceImage &img, bool opT, bool conj, const void *x, void *y,
                       const void *alpha, const void *beta, int strong_zero, hipStream_t stream,
-                      bool use_gather = false);
+                      bool use_gather = false, const long long *zrange = nullptr);
+// zrange = {lo, hi} (0-based, exclusive): the y entries the `y .*= beta` pass of the accumulate path
+// covers instead of the image's own range (multi-device fan-out; ignored by exclusive forward images,
+// whose coverage is part of the image)
+
+// dst[0..n) += src[0..n);   y[0..n) = beta * y + r   (element type `dtype`, beta: pointer to one T)
+hipError_t launch_vec_add(int dtype, void *dst, const void *src, long long n, hipStream_t stream);
+hipError_t launch_vec_axpby(int dtype, void *y, const void *r, long long n, const void *beta, hipStream_t stream);
 
 // nrhs right-hand sides: X (ldx) and Y (ldy) column-major; A is streamed once per batch of <= 8.
 hipError_t launch_mul_multi(const DeviceImage &img, bool opT, bool conj, long long nrhs, const void *x,

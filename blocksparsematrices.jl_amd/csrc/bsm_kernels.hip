@@ -110,6 +110,11 @@ __device__ __forceinline__ c128 shx(c128 a, int d) {
     return c128{__shfl_xor(a.re, d, 64), __shfl_xor(a.im, d, 64)};
 }
 
+__device__ __forceinline__ float shfl_from(float a, int src) { return __shfl(a, src, 64); }
+__device__ __forceinline__ double shfl_from(double a, int src) { return __shfl(a, src, 64); }
+__device__ __forceinline__ c64 shfl_from(c64 a, int src) { return c64{__shfl(a.re, src, 64), __shfl(a.im, src, 64)}; }
+__device__ __forceinline__ c128 shfl_from(c128 a, int src) { return c128{__shfl(a.re, src, 64), __shfl(a.im, src, 64)}; }
+
 // hardware floating-point atomics (global_atomic_add_f32 / _f64; built with
 // -munsafe-fp-atomics so no compare-and-swap loop is emitted)
 __device__ __forceinline__ void atomic_acc(float *p, float v) { atomicAdd(p, v); }
@@ -211,6 +216,9 @@ constexpr int FLAG_CONJ = 4;
 constexpr int FLAG_OPT = 8;
 constexpr int FLAG_RMW = 16;     // coloured launch: conflict-free by construction, plain read-modify-write
 constexpr int FLAG_GATHER = 32;  // contributions are stored in the workspace, gather_kernel sums them
+constexpr int FLAG_FLATATOMIC = 128;  // (A/B switch)
+constexpr int FLAG_ALLFLAT = 256;     // (A/B switch)
+constexpr int FLAG_NOFLAT = 64;  // (A/B switch) keep the power-of-two lane mapping for every row group
 
 // ----------------------------------------------------------------------------------------
 // descriptors: fetched as whole 16-byte words through a wave-uniform address (scalar loads),
@@ -439,24 +447,169 @@ __device__ __forceinline__ T run_panel(const WaveD &wd, const uint4 *__restrict_
     return a;
 }
 
+// ----------------------------------------------------------------------------------------
+// forward product of a row group whose height m is NOT 8 / 16 / 32 / 64 -- FLAT lane mapping.
+// run_panel gives every strip P = nextpow2(m) lanes, so a 36-row group keeps 36 of 64 lanes (and
+// 4.6 of 8 KB per wave) busy.  The strip layout [strip][row][e] is one flat array of 16-byte units
+// (unit u = strip * m + row), so here a wave-load simply takes 64 CONSECUTIVE units whatever m is:
+// slot l of lane `lane` owns unit q = lane + 64 l of every iteration, an iteration advances by
+// ds = floor(64 L / m) whole strips (= ds * m units: a multiple of m, so the row q % m and the strip
+// offset q / m of a slot never change).  >= 88 % of the lanes carry data for every m <= 64.
+// Every slot has its own accumulator (its own row); the 64 L partial sums of a wave meet once, at
+// the end, in a 64-entry LDS row slab (ds_add), from which lane i < m reads row i back.
+// ----------------------------------------------------------------------------------------
+template <typename T, int L, bool NT>
+__device__ __forceinline__ T run_panel_flat(const WaveD &wd, const uint4 *__restrict__ values,
+                                            const int *__restrict__ cols, const T *__restrict__ x,
+                                            int flags, int lane, T *xs) {
+    constexpr int E = TT<T>::E;
+    constexpr int XCH = x_chunk_cols<T, false>();
+    const bool cjf = (flags & FLAG_CONJ) != 0;
+    const int m = wd.m;
+    const int ds = (64 * L) / m;  // strips per iteration (>= L)
+    const int upi = ds * m;       // units per iteration (<= 64 L)
+    // floor(q / m) for q < 64 L = 512 and m <= 64 by one multiplication: the error term
+    // q * (inv * m - 2^16) stays below 2^16
+    const int inv = (65536 + m - 1) / m;
+    int so[L];  // strip offset of slot l inside an iteration (its row, q - so * m, is recomputed at the end)
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+        const int q = lane + 64 * l;
+        so[l] = (q * inv) >> 16;
+    }
+    // upi > 64 L - m >= 64 (L - 1): only lanes of the LAST slot can lie past the last whole strip
+    if (lane + 64 * (L - 1) >= upi) so[L - 1] = 1 << 20;  // never valid
+    T acc[L];
+#pragma unroll
+    for (int l = 0; l < L; ++l) acc[l] = zero_of(T{});
+
+    const PieceD pc = wd.first;
+    if (wd.npieces > 0) {
+        const int xbase = pc.xbase;
+        const int col_off = pc.col_off;
+        const int nstrips = pc.nstrips;
+        const int ncols = pc.ncols;
+        const Vec16<T> *__restrict__ vb = reinterpret_cast<const Vec16<T> *>(
+            values + (((uint64_t)pc.val_hi << 32) | pc.val_lo));
+        const int s1w = wd.seg1_w, s1x = wd.seg1_x - wd.seg1_w;
+        const int s2w = wd.seg2_w, s2x = pc.seg2_x - wd.seg2_w;
+        // xs[XCH .. XCH + E) stays zero, and a masked slot loads the zero unit at the head of the cols
+        // pool instead of matrix bytes:
+        // 0 * 0, never a real x or matrix entry (which may be Inf / NaN).  Every load is
+        // unconditional -- one straight run of L loads, no exec-mask branches between them.
+        if (lane < E) xs[XCH + lane] = zero_of(T{});
+        const Vec16<T> *__restrict__ zu = reinterpret_cast<const Vec16<T> *>(cols);  // cols[0..3] == 0 (bsm_layout.h)
+        for (int c0 = 0; c0 < ncols; c0 += XCH) {
+            // x slice of this chunk (plus the zero-padded tail of the last strip): the loads of up
+            // to 256 columns are in flight together, then the slab is written
+#pragma unroll 1
+            for (int k0 = 0; k0 < XCH / 64 && c0 + k0 * 64 < ncols + E; k0 += 4) {
+                T xv[4];
+                int xi[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) xi[k] = min(c0 + (k0 + k) * 64 + lane, ncols - 1);  // clamped: always a valid column
+                if (xbase < 0) {  // scattered columns: the four index loads go out together
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) xi[k] = cols[col_off + xi[k]];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) xi[k] &= 0x7fffffff;
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) xi[k] += (xi[k] < s1w ? xbase : (xi[k] < s2w ? s1x : s2x));
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) xv[k] = x[xi[k]];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int c = (k0 + k) * 64 + lane;
+                    const int w = c0 + c;
+                    if (w < ncols + E) xs[c] = (w < ncols) ? xv[k] : zero_of(T{});
+                }
+            }
+            const int sc0 = c0 / E;
+            const int s_end = min(nstrips, (c0 + XCH) / E);
+            for (int s0 = sc0; s0 < s_end; s0 += ds) {
+                const int rem = s_end - s0;  // strips left in this chunk
+                const Vec16<T> *__restrict__ vi = vb + ((uint32_t)(s0 * m) + (uint32_t)lane);
+                Vec16<T> b[L];
+#pragma unroll
+                for (int l = 0; l < L; ++l) {
+                    const Vec16<T> *p = (so[l] < rem) ? &vi[64 * l] : zu;
+                    b[l] = NT ? load_stream16(p) : *p;
+                }
+                __builtin_amdgcn_sched_barrier(0);  // all L loads are in flight before the first FMA waits
+                const int cb = (s0 - sc0) * E;
+#pragma unroll
+                for (int l = 0; l < L; ++l) {
+                    const int xo = (so[l] < rem) ? cb + so[l] * E : XCH;
+                    const Vec16<T> xv = *reinterpret_cast<const Vec16<T> *>(&xs[xo]);
+#pragma unroll
+                    for (int e = 0; e < E; ++e) acc[l] = madd(acc[l], cj(b[l].v[e], cjf), xv.v[e]);
+                }
+            }
+        }
+    }
+    // the x slab is dead: it becomes the wave's reduction slab.  LDS instructions of one wave execute
+    // in order; the fences only stop the compiler from moving them across each other.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    T a = zero_of(T{});
+    if ((flags & FLAG_FLATATOMIC) || XCH < 64 * L) {
+        xs[lane] = zero_of(T{});
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+#pragma unroll
+        for (int l = 0; l < L; ++l) {
+            const int q = lane + 64 * l;
+            if (l < L - 1 || q < upi) lds_acc(&xs[q - ((q * inv) >> 16) * m], acc[l]);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        a = xs[lane];
+    } else {
+        // partial sum of unit q at slab[q] (contiguous, conflict-free stores); lane (r, h), h < H =
+        // 64 / m, then adds up the units r + m (h + H j) of row r, and the H lanes of a row meet by
+        // shuffles
+#pragma unroll
+        for (int l = 0; l < L; ++l) xs[lane + 64 * l] = acc[l];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        const int H = 64 / m;
+        const int h = (lane * inv) >> 16, r = lane - h * m;
+        // (at most 64 L / (m H) <= 2 L - 1 units per lane; all reads are issued before the first add)
+        T part[2 * L];
+#pragma unroll
+        for (int j = 0; j < 2 * L; ++j) {
+            const int q = r + m * (h + H * j);
+            part[j] = (h < H && q < upi) ? xs[min(q, 64 * L - 1)] : zero_of(T{});
+        }
+#pragma unroll
+        for (int j = 0; j < 2 * L; ++j) a = add(a, part[j]);
+        for (int k = 1; k < H; ++k) {
+            const T o = shfl_from(a, lane + m * k);
+            if (lane < m) a = add(a, o);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    return a;
+}
+
 // Occupancy is what the small-panel (BEM-shaped) products live on: a small panel is a chain of
 // dependent memory round trips, hidden only by other resident waves.
 //   fp64 forward-only: capped at 80 VGPRs (>= 6 waves per SIMD = 1536 resident workgroups: every
 //     workgroup of a C2-sized launch is resident at once); compiles to 72.
 //   fp64 fused: capped at 64 VGPRs = 8 waves per SIMD, no scratch; with 20 KB of LDS per workgroup
 //     exactly 8 workgroups fit a CU (+11-13 % on 3-28-row fp64 panels over 6 waves).
-//   complex128: capped at 80 (the fused instance compiles to 71: 7 waves).
+//   complex128 with a transposed half: capped at 80 (the fused instance compiles to 71: 7 waves);
+//     forward-only (8 complex accumulators of the flat mapping): 96.
 //   fp32 / complex64: capped at 96 = 5 waves (fp32 fused compiles to 80: 6), no scratch anywhere.
 template <typename T, int L, bool FWD, bool TRN, bool NT>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(
     (FWD && TRN && std::is_same<T, double>::value) ? 8 :
-    (((!TRN && std::is_same<T, double>::value) || std::is_same<T, c128>::value) ? 6 : 5))))
+    (((!TRN && std::is_same<T, double>::value) || (TRN && std::is_same<T, c128>::value)) ? 6 : 5))))
     panel_kernel(const WaveWork *__restrict__ waves, const uint4 *__restrict__ values, const int *__restrict__ rows,
                  const int *__restrict__ cols, const T *__restrict__ x, T *__restrict__ y, T alpha,
                  T beta, int flags, unsigned wg_base, T *__restrict__ ws, long long ws_fbase) {
     constexpr int XS = x_chunk_cols<T, TRN>();         // staged x slice per wave
     constexpr int VS = XS;                             // transposed column sums of one staged chunk
-    __shared__ __attribute__((aligned(16))) T xs[kWavesPerWg][FWD ? XS : 1];
+    // (forward-only kernels: + one zero strip for the masked slots of run_panel_flat)
+    __shared__ __attribute__((aligned(16))) T xs[kWavesPerWg][FWD ? XS + (TRN ? 0 : TT<T>::E) : 1];
     __shared__ __attribute__((aligned(16))) T vs[kWavesPerWg][TRN ? VS : 1];
     // (the cross-wave combine slab of split groups aliases xs: a wave's x slice is dead by then)
     // y window of workgroups that pack neighbouring small row groups of a symmetric operator
@@ -477,7 +630,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(
 
     T u = zero_of(T{});
     if (work == WORK_PANEL) {
-        if (m <= 8)
+        if (FWD && !TRN && !(flags & FLAG_NOFLAT) && ((flags & FLAG_ALLFLAT) || (m != 8 && m != 16 && m != 32 && m != 64)))
+            u = run_panel_flat<T, L, NT>(wd, values, cols, x, flags, lane, xs[wave]);
+        else if (m <= 8)
             u = run_panel<T, L, 8, FWD, TRN, NT>(wd, values, rows, cols, x, y, alpha, flags, lane, xs[wave], vs[wave], win, win_n, ws);
         else if (m <= 16)
             u = run_panel<T, L, 16, FWD, TRN, NT>(wd, values, rows, cols, x, y, alpha, flags, lane, xs[wave], vs[wave], win, win_n, ws);
@@ -860,7 +1015,7 @@ static bool stream_policy(const DeviceImage &img) {
 template <typename T, int L>
 static hipError_t launch_typed(const DeviceImage &img, bool opT, bool conj, const void *x, void *y,
                                const void *alpha_p, const void *beta_p, int strong_zero,
-                               hipStream_t stream, bool use_gather = false) {
+                               hipStream_t stream, bool use_gather = false, const long long *zrange = nullptr) {
     const T alpha = load_scalar<T>(alpha_p, 1.0);
     const T beta = load_scalar<T>(beta_p, 0.0);
     int flags = 0;
@@ -876,6 +1031,11 @@ static hipError_t launch_typed(const DeviceImage &img, bool opT, bool conj, cons
     const dim3 block(256);
     const bool nt = stream_policy(img);
 
+    static const bool noflat = std::getenv("BSM_NOFLAT") != nullptr;
+    if (noflat) flags |= FLAG_NOFLAT;
+    static const bool allflat = std::getenv("BSM_ALLFLAT") != nullptr, flatatomic = std::getenv("BSM_FLATATOMIC") != nullptr;
+    if (allflat) flags |= FLAG_ALLFLAT;
+    if (flatatomic) flags |= FLAG_FLATATOMIC;
     if (!opT && img.exclusive_fwd) {
         // one launch: every y row has exactly one producer; beta is fused into its store and
         // the rows no block covers are scaled by WORK_SCALE waves of the same grid.
@@ -891,6 +1051,10 @@ static hipError_t launch_typed(const DeviceImage &img, bool opT, bool conj, cons
     if (!opT) {
         lo = img.own_lo;
         hi = img.own_hi;
+    }
+    if (zrange) {  // the caller (multi-device fan-out) knows which y entries this image must define
+        lo = zrange[0];
+        hi = zrange[1];
     }
     const bool gather = use_gather && img.d_ws != nullptr;
     T *ws = gather ? (T *)img.d_ws : (T *)nullptr;
@@ -1045,12 +1209,58 @@ hipError_t launch_mul_multi(const DeviceImage &img, bool opT, bool conj, long lo
 
 hipError_t launch_mul(const DeviceImage &img, bool opT, bool conj, const void *x, void *y,
                       const void *alpha, const void *beta, int strong_zero, hipStream_t stream,
-                      bool use_gather) {
+                      bool use_gather, const long long *zrange) {
     switch (img.dtype) {
-        case 0: return launch_typed<float, 8>(img, opT, conj, x, y, alpha, beta, strong_zero, stream, use_gather);
-        case 1: return launch_typed<double, 8>(img, opT, conj, x, y, alpha, beta, strong_zero, stream, use_gather);
-        case 2: return launch_typed<c64, 8>(img, opT, conj, x, y, alpha, beta, strong_zero, stream, use_gather);
-        case 3: return launch_typed<c128, 8>(img, opT, conj, x, y, alpha, beta, strong_zero, stream, use_gather);
+        case 0: return launch_typed<float, 8>(img, opT, conj, x, y, alpha, beta, strong_zero, stream, use_gather, zrange);
+        case 1: return launch_typed<double, 8>(img, opT, conj, x, y, alpha, beta, strong_zero, stream, use_gather, zrange);
+        case 2: return launch_typed<c64, 8>(img, opT, conj, x, y, alpha, beta, strong_zero, stream, use_gather, zrange);
+        case 3: return launch_typed<c128, 8>(img, opT, conj, x, y, alpha, beta, strong_zero, stream, use_gather, zrange);
+    }
+    return hipErrorInvalidValue;
+}
+
+// ---- vector helpers of the multi-device fan-out (bsm_dist.cpp) ---------------------------------
+// dst[i] += src[i]: a halo segment received from a peer is added to the local result
+template <typename T>
+__global__ void __launch_bounds__(256) vec_add_kernel(T *__restrict__ dst, const T *__restrict__ src, long long n) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) dst[i] = add(dst[i], src[i]);
+}
+// y[i] = beta * y[i] + r[i]: the delivered segment meets the caller's y (numeric beta)
+template <typename T>
+__global__ void __launch_bounds__(256) vec_axpby_kernel(T *__restrict__ y, const T *__restrict__ r, long long n, T beta) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) y[i] = madd(r[i], beta, y[i]);
+}
+template <typename T>
+static hipError_t vec_launch(int which, void *dst, const void *src, long long n, const void *beta_p, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    long long nblk = (n + 255) / 256;
+    if (nblk > 4096) nblk = 4096;
+    if (which == 0)
+        hipLaunchKernelGGL((vec_add_kernel<T>), dim3((unsigned)nblk), dim3(256), 0, stream, (T *)dst, (const T *)src, n);
+    else
+        hipLaunchKernelGGL((vec_axpby_kernel<T>), dim3((unsigned)nblk), dim3(256), 0, stream, (T *)dst, (const T *)src, n,
+                           load_scalar<T>(beta_p, 0.0));
+    return hipGetLastError();
+}
+hipError_t launch_vec_add(int dtype, void *dst, const void *src, long long n, hipStream_t stream) {
+    switch (dtype) {
+        case 0: return vec_launch<float>(0, dst, src, n, nullptr, stream);
+        case 1: return vec_launch<double>(0, dst, src, n, nullptr, stream);
+        case 2: return vec_launch<c64>(0, dst, src, n, nullptr, stream);
+        case 3: return vec_launch<c128>(0, dst, src, n, nullptr, stream);
+    }
+    return hipErrorInvalidValue;
+}
+hipError_t launch_vec_axpby(int dtype, void *y, const void *r, long long n, const void *beta, hipStream_t stream) {
+    switch (dtype) {
+        case 0: return vec_launch<float>(1, y, r, n, beta, stream);
+        case 1: return vec_launch<double>(1, y, r, n, beta, stream);
+        case 2: return vec_launch<c64>(1, y, r, n, beta, stream);
+        case 3: return vec_launch<c128>(1, y, r, n, beta, stream);
     }
     return hipErrorInvalidValue;
 }

@@ -36,7 +36,7 @@ __all__ = [
     "rowindices", "colindices", "colors", "transposecolors", "diagonal", "offdiagonal",
     "eachdiagonalindex", "eachoffdiagonalindex", "diagonalindices", "diagonalcolors",
     "offdiagonalcolors", "transposeoffdiagonalcolors", "rowcolvals", "sparse", "ColorInfo", "conflicts",
-    "color", "coloringalgorithm",
+    "color", "coloringalgorithm", "Context", "partition_rows",
 ]
 
 _DT = {np.dtype(np.float32): L.BSM_F32, np.dtype(np.float64): L.BSM_F64,
@@ -95,7 +95,45 @@ def _fblocks(blocks, dt):
     return out
 
 
-def _options(scheduler, device, accumulate, own=None, transpose_image=False):
+class Context:
+    """bsm_ctx_t: the GPUs of one node ONE handle is spread over (`devices=[0, 1, ...]` on any
+    constructor).  The MI355X counterpart of the reference's `@tasks` fan-out over block rows /
+    colour classes (src/vbcrs.jl:275-276, src/symmetricblockmatrix.jl:395-432).  The same ordinal may
+    be listed several times (virtual devices)."""
+    _cache = {}
+
+    def __init__(self, devices):
+        self.devices = tuple(int(d) for d in devices)
+        ids = (C.c_int32 * len(self.devices))(*self.devices)
+        h = C.c_void_p()
+        L.check(L.lib().bsm_ctx_create(ids, len(self.devices), C.byref(h)))
+        self.ptr = h
+
+    @classmethod
+    def get(cls, devices):
+        """One context per device tuple for the life of the process (handles keep a pointer to it)."""
+        key = tuple(int(d) for d in devices)
+        if key not in cls._cache:
+            cls._cache[key] = cls(key)
+        return cls._cache[key]
+
+
+def partition_rows(nrows, rowkeys, weights, nparts):
+    """bsm_partition_rows: the row partition both multi-GPU layers use.  rowkeys[b] = smallest row
+    index of block b (1-based), weights[b] = its stored entries.
+    Returns (part_of_block, own) with own[p] = (lo, hi), 1-based inclusive (hi = lo - 1: empty)."""
+    key, w = _i64(rowkeys), _i64(weights)
+    nb = len(key)
+    part = np.zeros(max(nb, 1), dtype=np.int32)
+    lo, hi = np.zeros(nparts, dtype=np.int64), np.zeros(nparts, dtype=np.int64)
+    I = C.POINTER(C.c_int64)
+    L.check(L.lib().bsm_partition_rows(int(nrows), nb, key.ctypes.data_as(I), w.ctypes.data_as(I), int(nparts),
+                                       part.ctypes.data_as(C.POINTER(C.c_int32)), lo.ctypes.data_as(I),
+                                       hi.ctypes.data_as(I)))
+    return part[:nb], [(int(a), int(b)) for a, b in zip(lo, hi)]
+
+
+def _options(scheduler, device, accumulate, own=None, transpose_image=False, devices=None):
     o = L.BsmOptions()
     L.lib().bsm_options_default(C.byref(o))
     o.scheduler = L.BSM_SCHED_SERIAL if isserial(scheduler) else L.BSM_SCHED_DYNAMIC
@@ -106,6 +144,10 @@ def _options(scheduler, device, accumulate, own=None, transpose_image=False):
     if own is not None:
         o.own_lo, o.own_hi = int(own[0]), int(own[1])
     o.transpose_image = 1 if transpose_image else 0
+    if devices is not None:
+        if own is not None or transpose_image:
+            raise ValueError("devices= does not combine with own= / transpose_image=")
+        o.ctx = Context.get(devices).ptr
     return o
 
 
@@ -185,11 +227,25 @@ class _LinearMap:
 class AbstractBlockMatrix(_LinearMap):
     """reference src/abstractblockmatrix.jl:13-62"""
 
-    def _finish(self, handle, dt, sz, sched):
+    def _finish(self, handle, dt, sz, sched, device=None, devices=None):
         self._h = _Handle(handle)
         self.dtype = dt
         self.size = (int(sz[0]), int(sz[1]))
         self.scheduler = sched
+        self.devices = None if devices is None else tuple(int(d) for d in devices)
+        self.device = None if (devices is not None or device == L.BSM_DEVICE_NONE) else int(device)
+
+    def parts(self):
+        """Per-device view of a multi-device handle: list of dicts (device, own, touched, ...)."""
+        if self.devices is None:
+            raise ValueError("not a multi-device handle")
+        out = []
+        for p in range(len(self.devices)):
+            pi = L.BsmPartInfo()
+            L.check(L.lib().bsm_part_info(self._h.ptr, p, C.byref(pi)))
+            out.append(dict(device=pi.device, own=(pi.own_lo, pi.own_hi), touched=(pi.touched_lo, pi.touched_hi),
+                            device_bytes=pi.device_bytes, nblocks=pi.nblocks))
+        return out
 
     def stats(self):
         st = L.BsmStats()
@@ -289,7 +345,7 @@ class BlockSparseMatrix(AbstractBlockMatrix):
 
     def __init__(self, blocks, rowindices, colindices, size, cols=None, *, scheduler=None,
                  coloringalgorithm=None, device=None, accumulate="auto", own=None,
-                 transpose_image=False):
+                 transpose_image=False, devices=None):
         if cols is not None:  # (blocks, rowindices, colindices, rows, cols) form, :81-89
             size = (size, cols)
         scheduler = SerialScheduler() if scheduler is None else scheduler
@@ -307,14 +363,14 @@ class BlockSparseMatrix(AbstractBlockMatrix):
         n = _i64([b.shape[1] for b in self.blocks])
         ld = _i64([max(b.shape[0], 1) for b in self.blocks])
         dev = _default_device() if device is None else device
-        o = _options(scheduler, dev, accumulate, own, transpose_image)
+        o = _options(scheduler, dev, accumulate, own, transpose_image, devices)
         h = C.c_void_p()
         I = C.POINTER(C.c_int64)
         L.check(L.lib().bsm_blocksparse_create(
             _DT[dt], int(size[0]), int(size[1]), nb, _ptrs(self.blocks), m.ctypes.data_as(I),
             n.ctypes.data_as(I), ld.ctypes.data_as(I), _ptrs(self.rowindices),
             _ptrs(self.colindices), C.byref(o), C.byref(h)))
-        self._finish(h, dt, size, scheduler)
+        self._finish(h, dt, size, scheduler, dev, devices)
         self.colors = _classes(self._bookkeeping(L.BSM_BK_COLORS))
         self.transposecolors = _classes(self._bookkeeping(L.BSM_BK_TRANSPOSECOLORS))
 
@@ -324,7 +380,7 @@ class SymmetricBlockMatrix(AbstractBlockMatrix):
     DynamicScheduler() (:80)."""
 
     def __init__(self, diagonals, diagonalindices, offdiagonals, rowindices, colindices, size,
-                 cols=None, *, scheduler=None, device=None, accumulate="auto", own=None):
+                 cols=None, *, scheduler=None, device=None, accumulate="auto", own=None, devices=None):
         if cols is not None:  # rows, cols form defaults to SerialScheduler() (:102)
             size = (size, cols)
             scheduler = SerialScheduler() if scheduler is None else scheduler
@@ -350,7 +406,7 @@ class SymmetricBlockMatrix(AbstractBlockMatrix):
         n = _i64([b.shape[1] for b in self.offdiagonals])
         ld = _i64([max(b.shape[0], 1) for b in self.offdiagonals])
         dev = _default_device() if device is None else device
-        o = _options(scheduler, dev, accumulate, own)
+        o = _options(scheduler, dev, accumulate, own, False, devices)
         h = C.c_void_p()
         I = C.POINTER(C.c_int64)
         L.check(L.lib().bsm_symmetric_create(
@@ -358,7 +414,7 @@ class SymmetricBlockMatrix(AbstractBlockMatrix):
             dld.ctypes.data_as(I), _ptrs(self.diagonalindices), no, _ptrs(self.offdiagonals),
             m.ctypes.data_as(I), n.ctypes.data_as(I), ld.ctypes.data_as(I),
             _ptrs(self.rowindices), _ptrs(self.colindices), C.byref(o), C.byref(h)))
-        self._finish(h, dt, size, scheduler)
+        self._finish(h, dt, size, scheduler, dev, devices)
         self.offdiagonalcolors = _classes(self._bookkeeping(L.BSM_BK_COLORS))
         self.transposeoffdiagonalcolors = _classes(self._bookkeeping(L.BSM_BK_TRANSPOSECOLORS))
         self.diagonalcolors = _classes(self._bookkeeping(L.BSM_BK_DIAGONALCOLORS))
@@ -370,7 +426,7 @@ class VariableBlockCompressedRowStorage(AbstractBlockMatrix):
 
     def __init__(self, matrices, rowindices=None, colindices=None, matrixsize=None, *,
                  scheduler=None, device=None, accumulate="auto", own=None, materialize=False,
-                 transpose_image=False):
+                 transpose_image=False, devices=None):
         I = C.POINTER(C.c_int64)
         h = C.c_void_p()
         dev = _default_device() if device is None else device
@@ -390,7 +446,7 @@ class VariableBlockCompressedRowStorage(AbstractBlockMatrix):
             ld = _i64([max(b.shape[0], 1) for b in s.offdiagonals])
             r0 = _i64([int(r[0]) for r in s.rowindices])
             c0 = _i64([int(c[0]) for c in s.colindices])
-            o = _options(scheduler, dev, accumulate, own)
+            o = _options(scheduler, dev, accumulate, own, False, devices)
             L.check(L.lib().bsm_vbcrs_create_from_symmetric(
                 _DT[dt], int(s.size[0]), int(s.size[1]), len(s.diagonals), _ptrs(s.diagonals),
                 ds.ctypes.data_as(I), dld.ctypes.data_as(I), d0.ctypes.data_as(I), len(s.offdiagonals),
@@ -400,12 +456,24 @@ class VariableBlockCompressedRowStorage(AbstractBlockMatrix):
             fb = mats
         else:
             if isinstance(matrices, BlockSparseMatrix):  # src/vbcrs.jl:150-160
+                # bsm_vbcrs_create_from_blocksparse: first(rowindices(b, i)) / first(colindices(b, i))
+                # are taken inside the library (src/vbcrs.jl:201-215)
                 b = matrices
                 scheduler = b.scheduler if scheduler is None else scheduler
-                mats = b.blocks
-                rowindices = [int(r[0]) for r in b.rowindices]  # first(rowindices(b, i)), :203
-                colindices = [int(c[0]) for c in b.colindices]
+                if len(b.blocks) < 1:
+                    raise IndexError("VariableBlockCompressedRowStorage needs at least one block")  # :81
+                dt = b.dtype
+                fb = b.blocks
+                m = _i64([k.shape[0] for k in fb])
+                n = _i64([k.shape[1] for k in fb])
+                ld = _i64([max(k.shape[0], 1) for k in fb])
+                o = _options(scheduler, dev, accumulate, own, transpose_image, devices)
+                L.check(L.lib().bsm_vbcrs_create_from_blocksparse(
+                    _DT[dt], int(b.size[0]), int(b.size[1]), len(fb), _ptrs(fb), m.ctypes.data_as(I),
+                    n.ctypes.data_as(I), ld.ctypes.data_as(I), _ptrs(b.rowindices), _ptrs(b.colindices),
+                    C.byref(o), C.byref(h)))
                 matrixsize = b.size
+                mats = None
             elif isinstance(matrices, SymmetricBlockMatrix):  # reference behaviour: materialise
                 s = matrices
                 scheduler = s.scheduler if scheduler is None else scheduler
@@ -418,22 +486,23 @@ class VariableBlockCompressedRowStorage(AbstractBlockMatrix):
             else:
                 mats = matrices
             scheduler = SerialScheduler() if scheduler is None else scheduler
-            if len(mats) < 1:
-                raise IndexError("VariableBlockCompressedRowStorage needs at least one block")  # :81
-            dt = _blocks_dtype(mats)
-            fb = _fblocks(mats, dt)
-            rs, cs = _i64(rowindices), _i64(colindices)
-            if len(rs) != len(fb) or len(cs) != len(fb):
-                raise ValueError("matrices, rowindices and colindices must have equal lengths")
-            m = _i64([b.shape[0] for b in fb])
-            n = _i64([b.shape[1] for b in fb])
-            ld = _i64([max(b.shape[0], 1) for b in fb])
-            o = _options(scheduler, dev, accumulate, own, transpose_image)
-            L.check(L.lib().bsm_vbcrs_create(
-                _DT[dt], int(matrixsize[0]), int(matrixsize[1]), len(fb), _ptrs(fb),
-                m.ctypes.data_as(I), n.ctypes.data_as(I), ld.ctypes.data_as(I), rs.ctypes.data_as(I),
-                cs.ctypes.data_as(I), C.byref(o), C.byref(h)))
-        self._finish(h, dt, matrixsize, scheduler)
+            if mats is not None:
+                if len(mats) < 1:
+                    raise IndexError("VariableBlockCompressedRowStorage needs at least one block")  # :81
+                dt = _blocks_dtype(mats)
+                fb = _fblocks(mats, dt)
+                rs, cs = _i64(rowindices), _i64(colindices)
+                if len(rs) != len(fb) or len(cs) != len(fb):
+                    raise ValueError("matrices, rowindices and colindices must have equal lengths")
+                m = _i64([b.shape[0] for b in fb])
+                n = _i64([b.shape[1] for b in fb])
+                ld = _i64([max(b.shape[0], 1) for b in fb])
+                o = _options(scheduler, dev, accumulate, own, transpose_image, devices)
+                L.check(L.lib().bsm_vbcrs_create(
+                    _DT[dt], int(matrixsize[0]), int(matrixsize[1]), len(fb), _ptrs(fb),
+                    m.ctypes.data_as(I), n.ctypes.data_as(I), ld.ctypes.data_as(I), rs.ctypes.data_as(I),
+                    cs.ctypes.data_as(I), C.byref(o), C.byref(h)))
+        self._finish(h, dt, matrixsize, scheduler, dev, devices)
         self.perm = self._bookkeeping(L.BSM_BK_VBCRS_PERM).copy()
         self.rowptr = self._bookkeeping(L.BSM_BK_VBCRS_ROWPTR).copy()
         self.colindices = self._bookkeeping(L.BSM_BK_VBCRS_COLINDICES).copy()
@@ -442,8 +511,19 @@ class VariableBlockCompressedRowStorage(AbstractBlockMatrix):
 
 
 # ---- mul! ------------------------------------------------------------------------------------------------
-def _vec_info(v, dt, n, name):
+def _check_device(v, base, name):
+    """A tensor on another GPU than the handle's would be dereferenced by kernels of the handle's
+    device: a device memory fault that aborts the process.  Raise instead."""
+    if base.devices is not None:  # multi-device handle: x / y may live on any device (peer copies)
+        return
+    if base.device is not None and v.device.index != base.device:
+        raise ValueError(f"{name} lives on cuda:{v.device.index} but the matrix was created on cuda:{base.device}")
+
+
+def _vec_info(v, dt, n, name, base=None):
     """-> (pointer, memspace, stream, keepalive)"""
+    if torch is not None and isinstance(v, torch.Tensor) and v.is_cuda and base is not None:
+        _check_device(v, base, name)
     if torch is not None and isinstance(v, torch.Tensor):
         if v.dim() != 1 or v.numel() != n:
             raise ValueError(f"DimensionMismatch: {name} has length {tuple(v.shape)}, expected {n}")
@@ -464,8 +544,10 @@ def _vec_info(v, dt, n, name):
     return v.ctypes.data, L.BSM_MEM_HOST, None, v
 
 
-def _mat_info(v, dt, n, name):
+def _mat_info(v, dt, n, name, base=None):
     """2-D column-major operand -> (pointer, ld, ncols, memspace, stream, keepalive)"""
+    if torch is not None and isinstance(v, torch.Tensor) and v.is_cuda and base is not None:
+        _check_device(v, base, name)
     if torch is not None and isinstance(v, torch.Tensor):
         tdt = {np.dtype(np.float32): torch.float32, np.dtype(np.float64): torch.float64,
                np.dtype(np.complex64): torch.complex64, np.dtype(np.complex128): torch.complex128}[dt]
@@ -493,8 +575,8 @@ def _mul_matrix(Y, A, X, alpha, beta):
     dt = base.dtype
     nr, nc = base.size
     ylen, xlen = (nr, nc) if op == L.BSM_OP_N else (nc, nr)
-    xp, ldx, kx, xms, _, _kx = _mat_info(X, dt, xlen, "X")
-    yp, ldy, ky, yms, yst, _ky = _mat_info(Y, dt, ylen, "Y")
+    xp, ldx, kx, xms, _, _kx = _mat_info(X, dt, xlen, "X", base)
+    yp, ldy, ky, yms, yst, _ky = _mat_info(Y, dt, ylen, "Y", base)
     if kx != ky:
         raise ValueError("DimensionMismatch: X and Y have different numbers of columns")
     if xms != yms:
@@ -526,8 +608,8 @@ def mul(y, A, x, alpha=True, beta=False):
         return _mul_matrix(y, A, x, alpha, beta)
     if dt.kind != "c" and (np.iscomplexobj(alpha) or np.iscomplexobj(beta)):
         raise TypeError("complex alpha/beta with a real matrix is not supported on the GPU path")
-    xp, xms, xst, _kx = _vec_info(x, dt, xlen, "x")
-    yp, yms, yst, _ky = _vec_info(y, dt, ylen, "y")
+    xp, xms, xst, _kx = _vec_info(x, dt, xlen, "x", base)
+    yp, yms, yst, _ky = _vec_info(y, dt, ylen, "y", base)
     if xms != yms:
         raise ValueError("x and y must live in the same memory space")
     strong = beta is False
@@ -548,8 +630,8 @@ class MulPlan:
         dt = base.dtype
         nr, nc = base.size
         ylen, xlen = (nr, nc) if op == L.BSM_OP_N else (nc, nr)
-        xp, xms, _, self._kx = _vec_info(x, dt, xlen, "x")
-        yp, yms, _, self._ky = _vec_info(y, dt, ylen, "y")
+        xp, xms, _, self._kx = _vec_info(x, dt, xlen, "x", base)
+        yp, yms, _, self._ky = _vec_info(y, dt, ylen, "y", base)
         if xms != L.BSM_MEM_DEVICE or yms != L.BSM_MEM_DEVICE:
             raise ValueError("MulPlan needs device-resident x and y")
         strong = beta is False

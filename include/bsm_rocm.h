@@ -92,8 +92,60 @@ typedef struct {
     /* rows of y this handle is responsible for scaling by beta (1-based, inclusive);
      * 0,0 = all rows.  Used when block rows are partitioned over several GPUs. */
     int64_t own_lo, own_hi;
-    int64_t reserved[4];
+    /* non-NULL: a bsm_ctx_t (below).  The handle is then spread over the context's devices -- the
+     * block rows are partitioned among them, bsm_mul fans out to one stream per device and exchanges
+     * the overlapping y segments over xGMI -- exactly where the reference has its `@tasks` fan-out
+     * (src/vbcrs.jl:275-276, src/blockmatrix.jl:233-245, src/symmetricblockmatrix.jl:395-432).
+     * `device`, own_lo/own_hi and transpose_image are ignored for such a handle. */
+    void *ctx;
+    /* where the BLOCK arrays passed to *_create live: BSM_MEM_HOST (0, default) or BSM_MEM_DEVICE:
+     * device pointers valid on the handle's device (e.g. AMDGPU.jl ROCArrays); the repacking then
+     * runs as a kernel on that device and no matrix byte crosses PCIe.  Index lists, sizes and the
+     * pointer arrays themselves are always host memory. */
+    int64_t blocks_memspace;
+    int64_t reserved[2];
 } bsm_options;
+
+/* ---- several GPUs of one node behind ONE handle -------------------------------------------------
+ * The reference runs its block rows / colour classes as tasks of one process (OhMyThreads `@tasks`
+ * with the scheduler stored in the matrix).  The MI355X counterpart of that fan-out is a context of
+ * devices: a handle created with bsm_options.ctx set keeps one packed image per device (contiguous
+ * ranges of block rows, balanced by stored bytes) and bsm_mul / bsm_mul_multi
+ *   1. make x available on every device (host memory: one H2D copy per device over its own PCIe
+ *      link; device memory: peer copies from the device that holds x),
+ *   2. run the local products concurrently, one stream per device,
+ *   3. exchange ONLY the y segments a device produced for rows another device owns (symmetric /
+ *      index-list operators: the halo; transposed products of a row partition: a reduce-scatter
+ *      onto equal column chunks) as direct peer-to-peer copies over the xGMI links + a local add,
+ *   4. deliver the owned y ranges to the caller's y (host memory or the device that holds y).
+ * VBCRS forward products need no step 3 (block rows own disjoint y ranges, src/vbcrs.jl:275-283).
+ * The same device may be listed several times (virtual devices: how the exchange is tested on a
+ * one-GPU machine).  One process per GPU with RCCL collectives is the OTHER way to use several GPUs
+ * (blocksparsematrices.jl_amd/distributed.py: every rank creates an ordinary single-device handle
+ * with own_lo/own_hi from bsm_partition_rows). */
+typedef struct bsm_ctx_s *bsm_ctx_t;
+int bsm_ctx_create(const int32_t *device_ids, int32_t ndevices, bsm_ctx_t *out);
+int bsm_ctx_destroy(bsm_ctx_t ctx); /* after every handle created with it has been destroyed */
+/* devices of the context (device_ids may be NULL); returns the count through *ndevices */
+int bsm_ctx_devices(bsm_ctx_t ctx, int32_t *ndevices, int32_t *device_ids, int32_t capacity);
+
+/* The row partition both multi-GPU layers use.  Block b has row key rowkey[b] (its smallest row
+ * index, 1-based) and weight[b] (stored entries).  The distinct keys, ascending, are cut into
+ * nparts contiguous ranges of about equal weight; part_of_block[b] receives the part of block b,
+ * own_lo[p] / own_hi[p] (1-based, inclusive; own_hi = own_lo - 1 for an empty part) the rows part p
+ * owns: from its first key up to the next part's first key - 1 (part 0 from row 1, the last one to
+ * nrows).  Deterministic; blocks with equal keys always land in the same part. */
+int bsm_partition_rows(int64_t nrows, int64_t nblocks, const int64_t *rowkey, const int64_t *weight,
+                       int32_t nparts, int32_t *part_of_block, int64_t *own_lo, int64_t *own_hi);
+
+/* Per-device view of a multi-device handle (tests, reports): rows owned / touched by part p
+ * (1-based inclusive), its device ordinal and the bytes of its packed image. */
+typedef struct {
+    int32_t device, reserved32;
+    int64_t own_lo, own_hi, touched_lo, touched_hi, device_bytes, nblocks;
+    int64_t reserved[4];
+} bsm_part_info_t;
+int bsm_part_info(bsm_matrix_t A, int32_t part, bsm_part_info_t *out);
 
 /* fills *o with defaults (device = current, serial scheduler, auto accumulate, validate) */
 void bsm_options_default(bsm_options *o);
@@ -121,6 +173,17 @@ int bsm_vbcrs_create_from_symmetric(int dtype, int64_t nrows, int64_t ncols, int
                                     const int64_t *ld, const int64_t *rowstart,
                                     const int64_t *colstart, const bsm_options *opts,
                                     bsm_matrix_t *out);
+
+/* VariableBlockCompressedRowStorage(bsm::BlockSparseMatrix; scheduler) -- reference
+ * src/vbcrs.jl:150-160 with the functors of :201-215: block i is placed at
+ * (first(rowindices(bsm, i)), first(colindices(bsm, i))), i.e. only the FIRST entry of every index
+ * list is used (contiguous ranges are assumed, like the reference's "no sanity checks", :146).
+ * Arguments as bsm_blocksparse_create; blocks with an empty list are rejected. */
+int bsm_vbcrs_create_from_blocksparse(int dtype, int64_t nrows, int64_t ncols, int64_t nblocks,
+                                      const void *const *blocks, const int64_t *m, const int64_t *n,
+                                      const int64_t *ld, const int64_t *const *rowidx,
+                                      const int64_t *const *colidx, const bsm_options *opts,
+                                      bsm_matrix_t *out);
 
 /* BlockSparseMatrix(blocks, rowindices, colindices, size; scheduler, coloringalgorithm)
  * -- reference src/blockmatrix.jl:62-109.  rowidx[b] has m[b] entries, colidx[b] n[b]. */

@@ -1,0 +1,165 @@
+"""GPU suite (-m gpu): ONE handle spread over the devices of a bsm_ctx_t (include/bsm_rocm.h,
+csrc/bsm_dist.cpp) -- the multi-GPU fan-out behind the C ABI, where the reference has its `@tasks`
+loop (src/vbcrs.jl:275-276, src/symmetricblockmatrix.jl:395-432).
+
+The GPU box has one MI355X, so the context lists device 0 several times (virtual devices): every
+part gets its own packed image, stream, work vector and receive buffer, and the halo / reduce-scatter
+/ delivery copies run exactly as between distinct GPUs (hipMemcpyPeerAsync degenerates to a
+device-to-device copy).  Every product is compared with the CPU oracle on the WHOLE operator.
+"""
+import numpy as np
+import pytest
+
+from _common import Cc, N, T, fixture_as_blocksparse, fixture_problem, oracle_mul, rand_vec, relerr
+
+pytestmark = pytest.mark.gpu
+TOL = {np.dtype(np.float64): 1e-12, np.dtype(np.complex128): 1e-12,
+       np.dtype(np.float32): 2e-5, np.dtype(np.complex64): 2e-5}
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "GPU suite needs a GPU"
+    from bsm_amd import _lib as L
+    L.lib()
+    return torch
+
+
+def wrap(bsm, A, op):
+    return A if op == N else (bsm.transpose(A) if op == T else bsm.adjoint(A))
+
+
+def check(torch, bsm, oracle, problem, A, ops=(N, T, Cc)):
+    dt = np.dtype(A.dtype)
+    nr, nc = problem["size"]
+    rng = np.random.default_rng(5)
+    for op in ops:
+        if op == Cc and dt.kind != "c":
+            continue
+        xl, yl = (nc, nr) if op == N else (nr, nc)
+        x, y0 = rand_vec(rng, xl, dt), rand_vec(rng, yl, dt)
+        y0[::7] = np.nan  # the strong zero must not let them through
+        combos = [(1, 0, True), (0.75, -1.5, False)]
+        if dt.kind == "c":
+            combos.append((1j, 2j, False))
+        for alpha, beta, strong in combos:
+            yin = y0 if strong else np.nan_to_num(y0, nan=0.25)
+            ref = oracle_mul(oracle, problem, op, x, yin, alpha, beta, strong)
+            # host vectors: the library moves x / y over PCIe itself
+            yh = np.array(yin, copy=True)
+            bsm.mul(yh, wrap(bsm, A, op), x, alpha, False if strong else beta)
+            assert relerr(yh, ref) < TOL[dt], ("host", op, alpha, beta)
+            # device vectors on cuda:0
+            xd, yd = torch.from_numpy(x).cuda(), torch.from_numpy(np.array(yin, copy=True)).cuda()
+            bsm.mul(yd, wrap(bsm, A, op), xd, alpha, False if strong else beta)
+            torch.cuda.synchronize()
+            assert relerr(yd.cpu().numpy(), ref) < TOL[dt], ("device", op, alpha, beta)
+
+
+def check_parts(A, nparts):
+    parts = A.parts()
+    assert len(parts) == nparts
+    nrows = A.size[0]
+    covered = np.zeros(nrows, dtype=np.int32)
+    for p in parts:
+        lo, hi = p["own"]
+        if hi >= lo:
+            covered[lo - 1:hi] += 1
+            assert p["touched"][0] <= lo and p["touched"][1] >= hi
+    assert np.all(covered == 1), "own ranges must tile the rows"
+
+
+@pytest.mark.parametrize("ndev", [2, 3])
+def test_vbcrs_over_virtual_devices(torch_cuda, bsm, oracle, ndev):
+    prob = bsm.synthetic.config2(n=9000, nblocks=420)
+    A = bsm.synthetic.build(prob, devices=[0] * ndev)
+    check_parts(A, ndev)
+    assert sum(p["nblocks"] for p in A.parts()) == len(prob["blocks"])
+    # bookkeeping of the WHOLE operator is what the handle reports (bit-exact, src/vbcrs.jl:84-117)
+    perm, rowptr, colind, rowind = oracle.vbcrs_build(prob["rowstart"], prob["colstart"])
+    assert np.array_equal(A.perm, perm) and np.array_equal(A.rowptr, rowptr)
+    assert np.array_equal(A.colindices, colind) and np.array_equal(A.rowindices, rowind)
+    check(torch_cuda, bsm, oracle, prob, A, ops=(N, T))
+
+
+@pytest.mark.parametrize("ndev", [2, 4])
+def test_symmetric_halo_over_virtual_devices(torch_cuda, bsm, oracle, ndev):
+    prob = bsm.synthetic.config5(n=40_000, lo=16, hi=96, halfband=3)
+    A = bsm.synthetic.build(prob, devices=[0] * ndev)
+    check_parts(A, ndev)
+    # banded structure: a part touches rows of the part below it (the halo) and nothing else
+    parts = A.parts()
+    assert any(p["touched"][0] < p["own"][0] for p in parts[1:])
+    check(torch_cuda, bsm, oracle, prob, A, ops=(N, T))
+
+
+@pytest.mark.parametrize("key", ["cuboid", "sphere"])
+def test_reference_fixture_over_virtual_devices(torch_cuda, bsm, oracle, key):
+    """The reference's own fixture (ComplexF64, scattered index lists): SymmetricBlockMatrix and, from
+    its off-diagonal panels, a BlockSparseMatrix -- every part reaches rows all over the matrix."""
+    prob = fixture_problem(key)
+    A = bsm.synthetic.build(prob, devices=[0, 0, 0])
+    check_parts(A, 3)
+    check(torch_cuda, bsm, oracle, prob, A)
+    pb = fixture_as_blocksparse(key)
+    B = bsm.synthetic.build(pb, devices=[0, 0])
+    check(torch_cuda, bsm, oracle, pb, B)
+
+
+def test_blocksparse_config1_and_more_devices_than_block_rows(torch_cuda, bsm, oracle):
+    prob = bsm.synthetic.config1()
+    A = bsm.synthetic.build(prob, devices=[0, 0, 0])
+    check(torch_cuda, bsm, oracle, prob, A, ops=(N, T))
+    # 2 block rows on 4 devices: two parts stay empty (no image) and the product is still complete
+    rng = np.random.default_rng(2)
+    blocks = [np.asfortranarray(rng.standard_normal((5, 7))), np.asfortranarray(rng.standard_normal((6, 4)))]
+    small = dict(kind="vbcrs", blocks=blocks, rowstart=np.array([3, 20]), colstart=np.array([1, 9]), size=(30, 16))
+    V = bsm.synthetic.build(small, devices=[0, 0, 0, 0])
+    assert sorted(p["nblocks"] for p in V.parts()) == [0, 0, 1, 1]
+    check(torch_cuda, bsm, oracle, small, V, ops=(N, T))
+
+
+def test_vbcrs_view_of_symmetric_and_multi_rhs(torch_cuda, bsm, oracle):
+    torch = torch_cuda
+    prob = bsm.synthetic.config3(nseg=40, bs=24, halfband=3)
+    S = bsm.synthetic.build(prob)
+    V = bsm.VariableBlockCompressedRowStorage(S, devices=[0, 0])
+    check(torch, bsm, oracle, prob, V, ops=(N, T))
+    # A * X through the multi-device handle (one fan-out per column)
+    n = prob["size"][0]
+    rng = np.random.default_rng(3)
+    X = np.asfortranarray(rng.standard_normal((n, 3)))
+    Y = np.asarray(V @ X)
+    for k in range(3):
+        ref = oracle_mul(oracle, prob, N, X[:, k].copy(), np.zeros(n))
+        assert relerr(Y[:, k], ref) < 1e-12
+
+
+def test_single_device_host_path_keeps_rows_outside_the_owned_range(torch_cuda, bsm, oracle):
+    """host vectors + own=(lo, hi) + beta = false must hand back the caller's y outside the
+    owned range (rows no block reaches are left untouched, include/bsm_rocm.h)."""
+    prob = bsm.synthetic.config2(n=4000, nblocks=150)
+    keep = [b for b, r in enumerate(prob["rowstart"]) if 1000 <= r < 2500]
+    sub = dict(kind="vbcrs", blocks=[prob["blocks"][b] for b in keep], rowstart=prob["rowstart"][keep],
+               colstart=prob["colstart"][keep], size=prob["size"])
+    lo = int(min(sub["rowstart"]))
+    hi = int(max(r + b.shape[0] - 1 for r, b in zip(sub["rowstart"], sub["blocks"])))
+    A = bsm.synthetic.build(sub, own=(lo, hi))
+    x = prob["x"]
+    ref = oracle_mul(oracle, sub, N, x, np.zeros(4000))
+    for first in (3.5, -7.25):  # twice with different sentinels: stale staging memory would show
+        y = np.full(4000, first)
+        bsm.mul(y, A, x)
+        assert np.all(y[:lo - 1] == first) and np.all(y[hi:] == first)
+        assert relerr(y[lo - 1:hi], ref[lo - 1:hi]) < 1e-12
+
+
+def test_tensor_on_the_wrong_device_is_an_error_not_a_fault(torch_cuda, bsm):
+    prob = bsm.synthetic.config2(n=2000, nblocks=40)
+    A = bsm.synthetic.build(prob)
+    assert A.device == torch_cuda.cuda.current_device()
+    A.device = A.device + 1  # pretend the handle lives elsewhere
+    x = torch_cuda.from_numpy(prob["x"]).cuda()
+    with pytest.raises(ValueError, match="lives on cuda"):
+        bsm.mul(torch_cuda.zeros_like(x), A, x)
