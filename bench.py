@@ -4,15 +4,25 @@
     python bench.py --gpus N --steps K --warmup W
 
 A "step" is ONE mul!(y, A, x) (3-argument form, alpha = 1, beta = Bool false) through the C ABI
-(libbsmrocm.so: bsm_mul) with A, x and y resident in HBM.  Workload at N = 1 is BASELINE.json
-configs[1]: VBCRS 100 000 x 100 000, 5 000 variable 8-64 sized fp64 blocks (SplitMix64 seed
-0xB5A2).  For N > 1 (one process per GPU, launched by torch.distributed.run) the
-GLOBAL operator is (N * 100 000)^2 with N * 5 000 blocks, row-partitioned: every rank owns the
-block rows of its 1/N slice of the rows (weak scaling).  Block rows are independent units
-(reference src/vbcrs.jl:275-283), y slices are disjoint, so the timed region contains NO collective
-(`--allgather` adds the RCCL all-gather of the y slices a Krylov iteration would need).
+(libbsmrocm.so: bsm_mul) with A, x and y resident in HBM.
 
-metric value = algorithmic bytes of all ranks (every stored entry once + block
+N = 1 (default): BASELINE.json configs[1] = C2, VBCRS 100 000 x 100 000, 5 000 variable 8-64 sized
+    fp64 blocks (SplitMix64 seed 0xB5A2); the K timed steps are one hipGraph replay of
+    K bsm_mul launches.  `roofline` describes that kernel; `extra` adds driver-timed HBM-resident
+    legs (a 1.1 GB C2-shaped VBCRS operator, the C3 fused symmetric product), a cold-cache figure and
+    the CPU baselines.
+
+N > 1 (one process per GPU, launched by torch.distributed.run, RCCL): the 8-GPU configuration the
+    metric is quoted on in fp64 -- C5, SymmetricBlockMatrix 5M x 5M, mixed 16-256 block sizes (28.6 GB)
+    -- STRONG-scaled: the diagonal segments are row-partitioned over the ranks (bsm_partition_rows),
+    every rank generates its share in HBM (include/bsm_synth.h) and a step is the complete
+    distributed product: fused A + A^T local product, point-to-point halo exchange of the partial-y
+    segments that belong to the neighbouring rank (ncclSend/Recv over xGMI), all-gather of the owned y
+    slices so that every GPU holds the whole y (the next x of a Krylov iteration).  All of it is
+    inside the timed region.  `extra.c4` reports the same for C4 (VBCRS 2M x 2M, 128x128 fp32 blocks,
+    16.4 GB, row partition + y all-gather).  --workload c2 keeps the old weak-scaling C2 run.
+
+metric value = algorithmic bytes of the whole job (every stored entry once + block
 metadata + x once + y once) * K / max-over-ranks time.
 
 Prints ONE JSON line on rank 0 with the `roofline` and `cpu_baseline` objects.
@@ -30,9 +40,45 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("OMP_NUM_THREADS", str(min(len(os.sched_getaffinity(0)), 16)))
 
 HBM_PEAK_GBPS = 8000.0  # MI355X spec (MI355X_MICROARCH.md); measured-copy ceiling 6290
-# HBM-side bytes of one C2 launch from the PMC passes (profiles/r01_c2_pmc_summary.txt):
-# FETCH_SIZE 27531.5 KiB x 2 (gfx950 counts 128-B requests as 64 B) + WRITE_SIZE 835.9 KiB
-TRAFFIC_BYTES_PER_LAUNCH = 57_240_000
+PMC_FILE = os.path.join(ROOT, "profiles", "r02_c2_pmc.json")  # written by tools/pmc_summary.py
+MFMA_FILE = os.path.join(ROOT, "profiles", "r02_c4_mfma.json")
+
+
+def read_json(path):
+    try:
+        with open(path) as f:
+            return json.load(f)
+    except Exception:
+        return None
+
+
+def timed(fn, reps, torch):
+    """HIP-event time per call of `fn` over `reps` back-to-back calls on the current stream."""
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) * 1e-3 / reps
+
+
+def leg(bsm, torch, prob, reps, **kw):
+    """One driver-timed single-GPU leg: warm device-event time of mul!(y, A, x)."""
+    A = bsm.synthetic.build(prob, **kw)
+    st = A.stats()
+    x = prob["x"]
+    y = torch.full((prob["size"][0],), float("nan"), dtype=x.dtype, device="cuda")
+    plan = bsm.MulPlan(y, A, x)
+    for _ in range(5):
+        plan()
+    torch.cuda.synchronize()
+    t = timed(plan, reps, torch)
+    out = {"us": round(t * 1e6, 2), "GBps": round(st["alg_bytes"] / t / 1e9, 1),
+           "frac_of_hbm_peak": round(st["alg_bytes"] / t / 1e9 / HBM_PEAK_GBPS, 4),
+           "alg_MB": round(st["alg_bytes"] / 1e6, 1), "device_MB": round(st["device_bytes"] / 1e6, 1)}
+    del plan, A
+    return out, y
 
 
 def main():
@@ -40,17 +86,16 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=500)
     ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--workload", choices=["auto", "c2", "c5"], default="auto",
+                    help="auto: C2 at N = 1, strong-scaled C5 (+ C4 in `extra`) at N > 1")
     ap.add_argument("--launch", choices=["graph", "eager"], default="graph",
-                    help="graph: the K timed steps are one hipGraph replay of K bsm_mul launches")
-    ap.add_argument("--allgather", action="store_true",
-                    help="include an RCCL all-gather of the y slices in every step (N > 1)")
+                    help="graph (N = 1): the K timed steps are one hipGraph replay of K bsm_mul launches")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the additional legs in `extra`")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to "
                     "rehearse the N > 1 code path on a single GPU)")
     ap.add_argument("--device", type=int, default=None, help="override LOCAL_RANK as the HIP device (rehearsal)")
-    ap.add_argument("--cold", action="store_true", default=True,
-                    help="also report a cold-cache figure (512 MiB flush before every launch); default on")
-    ap.add_argument("--no-cold", dest="cold", action="store_false")
+    ap.add_argument("--scale", type=float, default=1.0, help="shrink the N > 1 operators (rehearsal on one GPU)")
     args = ap.parse_args()
 
     import numpy as np
@@ -77,15 +122,163 @@ def main():
         else:
             dist.init_process_group(args.backend)
             red_dev = "cpu"
+    workload = args.workload
+    if workload == "auto":
+        workload = "c2" if world == 1 else "c5"
 
-    # ---- workload -------------------------------------------------------------------------------
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def reduce_scalars(elapsed, nbytes):
+        if dist is None:
+            return elapsed, float(nbytes)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        b = torch.tensor([float(nbytes)], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(b, op=dist.ReduceOp.SUM)
+        return float(t.item()), float(b.item())
+
+    if workload == "c5":
+        out = run_partitioned(args, bsm, torch, dist, np, rank, world, barrier, reduce_scalars)
+    else:
+        out = run_c2(args, bsm, torch, dist, np, rank, world, barrier, reduce_scalars)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------------------------------------
+# N > 1: strong-scaled C5 (fused symmetric + halo + all-gather), C4 in `extra`
+# ------------------------------------------------------------------------------------------------
+def run_partitioned(args, bsm, torch, dist, np, rank, world, barrier, reduce_scalars):
+    from bsm_amd import distributed as D
+    S = bsm.synthetic
+
+    def c5_share():
+        n = int(5_000_000 * args.scale)
+        start, sz = S.config5_segments(n=n)
+        halfband = 4
+        # stored entries per diagonal segment: its diagonal block + the off-diagonal blocks of its rows.
+        # All blocks of a segment share one row key, so this is bsm_partition_rows on the block list.
+        w = sz.astype(np.float64) ** 2
+        for k in range(1, halfband + 1):
+            w[k:] += sz[k:] * sz[:-k]
+        part, own = bsm.partition_rows(n, start + 1, w.astype(np.int64), world)
+        segs = np.nonzero(part == rank)[0]
+        lo, hi = (int(segs[0]), int(segs[-1]) + 1) if len(segs) else (0, 0)
+        prob = S.config5(n=n, on_device=True, seg_lo=lo, seg_hi=hi)
+        olo, ohi = own[rank]
+        # rows this rank writes: its own segments plus the columns of its off-diagonal blocks (y_J of
+        # block (I, J) -- the halo that belongs to the rank below); all lists are contiguous ranges
+        tlo = min([olo] + [int(c[0]) for c in prob["colindices"]])
+        touched = (tlo, ohi) if ohi >= olo else (olo, olo - 1)
+        return prob, own[rank], touched, True, "C5: SymmetricBlockMatrix %dx%d, segments U{16..256}, off-diagonal (I,J) J=I-1..I-4, fp64" % (n, n)
+
+    def c4_share():
+        ngrid = max(world, int(15625 * args.scale))
+        lo, hi = rank * ngrid // world, (rank + 1) * ngrid // world  # uniform blocks: equal row counts == equal bytes
+        prob = S.config4(ngrid=ngrid, on_device=True, row_lo=lo, row_hi=hi)
+        own = (lo * 128 + 1, hi * 128)
+        return prob, own, own, False, "C4: VBCRS %dx%d, %d 128x128 fp32 blocks (16 per block row)" % (ngrid * 128, ngrid * 128, ngrid * 16)
+
+    def run(share, steps, warmup):
+        t0 = time.perf_counter()
+        prob, own, touched, sym, desc = share()
+        A = D.build_local(prob, touched)
+        t_setup = time.perf_counter() - t0
+        if A is None:
+            raise SystemExit("bench: a rank received no block (more ranks than block rows)")
+        st = A.stats()
+        n = prob["size"][0]
+        es = prob["x"].element_size()
+        # this rank's part of the algorithmic bytes: stored entries + index metadata (x and y are
+        # counted once for the whole job below)
+        rank_bytes = st["alg_bytes"] - 2 * n * es
+        x = prob["x"]
+        del prob
+        torch.cuda.empty_cache()
+        y = torch.full((n,), float("nan"), dtype=x.dtype, device="cuda")
+        P = D.RowPartitioned(A, own, touched, gather=True, symmetric=sym)
+
+        def step():
+            P.mul(y, x)  # local product + halo exchange + all-gather: y complete on every rank
+
+        for _ in range(warmup):
+            step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        # the local kernel alone (device events), for the roofline object
+        plan = bsm.MulPlan(P._workvec(y) if sym else y, A, x)
+        for _ in range(3):
+            plan()
+        torch.cuda.synchronize()
+        kdur = timed(plan, max(5, steps // 4), torch)
+        elapsed, total = reduce_scalars(elapsed, rank_bytes)
+        total += 2 * n * es
+        kmax, _ = reduce_scalars(kdur, 0)
+        chk = float(torch.nan_to_num(y, nan=1e300).abs().max().item())
+        return dict(desc=desc, elapsed=elapsed, total_bytes=total, kdur=kmax, rank_alg=rank_bytes + 2 * n * es // world,
+                    setup_s=t_setup, ymax=chk, n=n, own=own, touched=touched, st=st)
+
+    steps, warmup = args.steps, args.warmup
+    r5 = run(c5_share, steps, warmup)
+    value = r5["total_bytes"] * steps / r5["elapsed"] / 1e9
+    extra = {}
+    if not args.no_extra:
+        torch.cuda.empty_cache()
+        r4 = run(c4_share, steps, warmup)
+        extra["c4"] = {"workload": r4["desc"] + ", row-partitioned over %d GPUs, RCCL all-gather of the y slices" % world,
+                       "dtype": "f32", "value": round(r4["total_bytes"] * steps / r4["elapsed"] / 1e9, 1), "unit": "GB/s",
+                       "ms_per_step": round(r4["elapsed"] / steps * 1e3, 4),
+                       "local_kernel_us_max": round(r4["kdur"] * 1e6, 1),
+                       "frac_of_hbm_peak": round(r4["total_bytes"] * steps / r4["elapsed"] / 1e9 / (HBM_PEAK_GBPS * world), 4),
+                       "setup_s": round(r4["setup_s"], 2)}
+    mf = read_json(MFMA_FILE)
+    if mf:
+        extra["c4_mfma"] = mf
+    kb = r5["rank_alg"]
+    roofline = {"bound": "hbm", "achieved": round(kb / r5["kdur"] / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": round(kb / r5["kdur"] / 1e9 / HBM_PEAK_GBPS, 4), "traffic": None,
+                "kernel": "bsm::panel_kernel<double,8,true,true,true> (fused A + A^T, one rank's share)",
+                "alg_bytes_per_launch": int(kb), "avg_launch_us": round(r5["kdur"] * 1e6, 2),
+                "note": "slowest rank's local product alone (HIP events); the step adds the halo exchange and the all-gather"}
+    out = {
+        "metric": "fp64 block-SpMV GB/s (SymmetricBlockMatrix mul!, algorithmic bytes / time)",
+        "value": round(value, 1), "unit": "GB/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+        "ms_per_step": round(r5["elapsed"] / steps * 1e3, 6), "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": r5["desc"] + ": mul!(y, A, x) row-partitioned over %d GPUs; fused A + A^T local "
+                               "product, RCCL send/recv of the partial-y halo, RCCL all-gather of y, all in the "
+                               "timed region; operator generated in HBM (SplitMix64 seed 0xB5A5)" % world,
+                   "global_rows": r5["n"], "alg_bytes_total": int(r5["total_bytes"]),
+                   "partition": "diagonal segments by stored bytes (bsm_partition_rows)",
+                   "collectives": "ncclSend/ncclRecv halo + ncclAllGather of y" if args.backend == "nccl" else args.backend,
+                   "frac_of_hbm_peak": round(value / (HBM_PEAK_GBPS * world), 4)},
+        "roofline": roofline,
+    }
+    if extra:
+        out["extra"] = extra
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# N = 1 (and --workload c2 at N > 1: weak scaling, no collective): C2
+# ------------------------------------------------------------------------------------------------
+def run_c2(args, bsm, torch, dist, np, rank, world, barrier, reduce_scalars):
     prob = bsm.synthetic.config2(part=(rank, world) if world > 1 else None)
     A = bsm.VariableBlockCompressedRowStorage(prob["blocks"], prob["rowstart"], prob["colstart"],
                                               prob["size"], own=prob.get("own"))
     st = A.stats()
     assert st["exclusive"] == 1
     n = prob["size"][0]
-    # algorithmic bytes of THIS rank: its stored entries + metadata + x once + its y rows once
     own = prob.get("own", (1, n))
     own_rows = own[1] - own[0] + 1
     if world > 1:
@@ -99,27 +292,13 @@ def main():
     x = torch.from_numpy(prob["x"]).cuda()
     y = torch.full((n,), float("nan"), dtype=torch.float64, device="cuda")
     plan = bsm.MulPlan(y, A, x)
-    gather_out = None
-    if args.allgather and world > 1:
-        gather_out = [torch.empty(n // world, dtype=torch.float64, device="cuda") for _ in range(world)]
 
-    def step():
-        plan()
-        if gather_out is not None:
-            dist.all_gather(gather_out, y[rank * (n // world):(rank + 1) * (n // world)])
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    # ---- warm-up + (optional) graph capture ---------------------------------------------------------
     for _ in range(args.warmup):
-        step()
+        plan()
     torch.cuda.synchronize()
     graph = None
     launch = args.launch
-    if launch == "graph" and gather_out is None:
+    if launch == "graph":
         try:
             s = torch.cuda.Stream()
             s.wait_stream(torch.cuda.current_stream())
@@ -146,50 +325,37 @@ def main():
         graph.replay()
     else:
         for _ in range(args.steps):
-            step()
+            plan()
     ev1.record()
     barrier()
     elapsed = time.perf_counter() - t0
     dev_elapsed = ev0.elapsed_time(ev1) * 1e-3
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        b = torch.tensor([float(alg_bytes)], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(b, op=dist.ReduceOp.SUM)
-        total_bytes = float(b.item())
-    else:
-        total_bytes = float(alg_bytes)
+    elapsed, total_bytes = reduce_scalars(elapsed, alg_bytes)
     value = total_bytes * args.steps / elapsed / 1e9
 
     # ---- roofline of the dominant kernel --------------------------------------------------------
-    # one step == one launch of bsm::panel_kernel<double,8,true,false,true> (forward-only, non-temporal matrix loads); its average duration is
-    # the HIP-event time of the timed region / K (back-to-back launches on one stream; the
-    # rocprofv3 --kernel-trace average in profiles/ must agree).
+    # one step == one launch of bsm::panel_kernel<double,8,true,false,true> (forward-only, non-temporal
+    # matrix loads); its average duration is the HIP-event time of the timed region / K (back-to-back
+    # launches on one stream; the rocprofv3 --kernel-trace average in profiles/ must agree).
     kdur = dev_elapsed / args.steps
     achieved = alg_bytes / kdur / 1e9
+    pmc = read_json(PMC_FILE) or {}
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": TRAFFIC_BYTES_PER_LAUNCH,
+                "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": pmc.get("traffic_bytes_per_launch"),
                 "kernel": "bsm::panel_kernel<double,8,true,false,true>",
                 "alg_bytes_per_launch": int(alg_bytes), "avg_launch_us": round(kdur * 1e6, 3),
-                "note": "warm: the 54 MB operator stays in the 256 MiB Infinity Cache between launches; "
-                        "traffic = rocprofv3 FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE per launch, "
-                        "profiles/r01_c2_pmc_summary.txt"}
+                "note": "warm: the 54 MB operator stays in the 256 MiB Infinity Cache between launches (see "
+                        "extra.hbm_vbcrs_fp64 / extra.c3_fused for HBM-streaming legs); traffic = rocprofv3 "
+                        "FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE per launch, read from "
+                        + os.path.relpath(PMC_FILE, ROOT)}
 
     extra = {}
     if rank == 0 and launch == "graph":
-        # the same K steps as individual bsm_mul calls (no graph), for transparency
         for _ in range(20):
-            step()
+            plan()
         torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(args.steps):
-            step()
-        e1.record()
-        torch.cuda.synchronize()
-        extra["eager_us_per_step"] = round(e0.elapsed_time(e1) * 1e3 / args.steps, 3)
-    if args.cold and rank == 0:
+        extra["eager_us_per_step"] = round(timed(plan, args.steps, torch) * 1e6, 3)
+    if rank == 0 and world == 1 and not args.no_extra:
         flush = torch.empty(512 << 20, dtype=torch.uint8, device="cuda")
         cold = []
         for _ in range(20):
@@ -204,74 +370,66 @@ def main():
         extra["cold_median_us"] = round(cold[len(cold) // 2] * 1e6, 2)
         extra["cold_GBps"] = round(alg_bytes / cold[len(cold) // 2] / 1e9, 1)
         del flush
+        # driver-timed HBM-streaming legs (operators far larger than the 256 MiB Infinity Cache),
+        # generated in HBM and packed by the device-side packer
+        S = bsm.synthetic
+        extra["hbm_vbcrs_fp64"], _ = leg(bsm, torch, S.config2(n=2_000_000, nblocks=100_000, on_device=True), 50)
+        extra["hbm_vbcrs_fp64"]["workload"] = "C2-shaped VBCRS 2M x 2M, 100 000 fp64 blocks 8-64 (20 x C2), forward mul!"
+        extra["c3_fused"], _ = leg(bsm, torch, S.config3(on_device=True), 50)
+        extra["c3_fused"]["workload"] = "C3: SymmetricBlockMatrix 200k x 200k, 64x64 fp64 blocks, half-bandwidth 8, fused A + A^T mul!"
+        torch.cuda.empty_cache()
+    mf = read_json(MFMA_FILE)
+    if mf and rank == 0:
+        extra["c4_mfma"] = mf
 
-    # ---- CPU baseline: the oracle (reference loop structure, scalar C port), rank 0, N = 1 only -----
+    # ---- CPU baseline: the oracle (reference loop structure, C port), rank 0, N = 1 only -------------
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from oracle import load_oracle
-        orc = load_oracle()
+        from oracle.oracle import load_oracle_native
+        orc = load_oracle_native()  # -O3 -march=native build of oracle/bsm_oracle.c, compiled on this box
         perm, rowptr, colind, rowind = orc.vbcrs_build(prob["rowstart"], prob["colstart"])
         blocks = [prob["blocks"][p - 1] for p in perm]
         xh = prob["x"]
         yh = np.zeros(n)
-        orc.vbcrs_mul(0, blocks, rowptr, colind, rowind, xh, yh)  # warm
-        reps, t0 = 0, time.perf_counter()
-        while True:
-            orc.vbcrs_mul(0, blocks, rowptr, colind, rowind, xh, yh)
-            reps += 1
-            dt = time.perf_counter() - t0
-            if dt > 10.0 or reps >= 2000:
-                break
-        # all host cores: one OpenMP task per block row == the reference's `@tasks for browidx`
-        # with DynamicScheduler() (src/vbcrs.jl:275-276); reported beside, not as the baseline
+        # everything is marshalled once; the repetitions and the clock are inside C (orc_vbcrs_bench_f64)
+        reps, dt = orc.vbcrs_bench(blocks, rowptr, colind, rowind, xh, yh, seconds=10.0)
+        err = float(np.max(np.abs(y.cpu().numpy() - yh)) / np.max(np.abs(yh)))
+        cpu = {"value": round(st["alg_bytes"] * reps / dt / 1e9, 3), "unit": "GB/s", "cores": 1, "kind": "port",
+               "sample": f"{reps} full C2 mul! calls of oracle/bsm_oracle.c (orc_vbcrs_mul_f64, gcc -O3 "
+                         f"-march=native, loop timed in C, no marshalling) in {dt:.1f} s on one host core",
+               "gpu_vs_oracle_relerr": err}
+        # all host cores: one OpenMP task per block row == the reference's `@tasks for browidx` with
+        # DynamicScheduler() (src/vbcrs.jl:275-276); reported beside, not as the baseline
         try:
             ncores = int(os.environ.get("OMP_NUM_THREADS", "1"))
             yp = np.zeros(n)
-            orc.vbcrs_mul(0, blocks, rowptr, colind, rowind, xh, yp, parallel=True)
-            preps, tp0 = 0, time.perf_counter()
-            while True:
-                orc.vbcrs_mul(0, blocks, rowptr, colind, rowind, xh, yp, parallel=True)
-                preps += 1
-                dtp = time.perf_counter() - tp0
-                if dtp > 5.0 or preps >= 2000:
-                    break
+            preps, dtp = orc.vbcrs_bench(blocks, rowptr, colind, rowind, xh, yp, seconds=5.0, parallel=True)
             extra["cpu_allcores"] = {"value": round(st["alg_bytes"] * preps / dtp / 1e9, 3), "unit": "GB/s",
                                      "cores": ncores, "kind": "port (OpenMP over block rows)",
-                                     "sample": f"{preps} C2 mul! calls in {dtp:.1f} s"}
+                                     "sample": f"{preps} C2 mul! calls in {dtp:.1f} s, timed in C",
+                                     "relerr_vs_1core": float(np.max(np.abs(yp - yh)) / np.max(np.abs(yh)))}
         except Exception as e:  # pragma: no cover
             extra["cpu_allcores"] = {"error": str(e)}
-        # parity of the measured GPU result against this same oracle run
-        err = float(np.max(np.abs(y.cpu().numpy() - yh)) / np.max(np.abs(yh)))
-        cpu = {"value": round(st["alg_bytes"] * reps / dt / 1e9, 3), "unit": "GB/s", "cores": 1,
-               "kind": "port",
-               "sample": f"{reps} full C2 mul! calls of oracle/bsm_oracle.c (orc_vbcrs_mul_f64, ctypes "
-                         f"marshalling included) in {dt:.1f} s on one host core",
-               "gpu_vs_oracle_relerr": err}
 
-    if rank == 0:
-        out = {
-            "metric": "fp64 block-SpMV GB/s (VBCRS mul!, algorithmic bytes / time)",
-            "value": round(value, 1), "unit": "GB/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 6),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
-            "data": "synthetic",
-            "config": {"workload": "C2: VBCRS 100000x100000 per GPU, 5000 variable 8-64 fp64 blocks per GPU "
-                                   "(SplitMix64 seed 0xB5A2), mul!(y, A, x), x/y/A resident in HBM",
-                       "global_rows": n, "blocks_per_gpu": len(prob["blocks"]),
-                       "alg_bytes_per_gpu": int(alg_bytes), "launch": launch,
-                       "partition": "block rows, no data-path collective" if not gather_out else
-                                    "block rows + RCCL all-gather of y slices",
-                       "frac_of_hbm_peak": round(value / (HBM_PEAK_GBPS * world), 4)},
-            "roofline": roofline,
-        }
-        if cpu is not None:
-            out["cpu_baseline"] = cpu
-        if extra:
-            out["extra"] = extra
-        print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    out = {
+        "metric": "fp64 block-SpMV GB/s (VBCRS mul!, algorithmic bytes / time)",
+        "value": round(value, 1), "unit": "GB/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 6),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": "C2: VBCRS 100000x100000 per GPU, 5000 variable 8-64 fp64 blocks per GPU "
+                               "(SplitMix64 seed 0xB5A2), mul!(y, A, x), x/y/A resident in HBM",
+                   "global_rows": n, "blocks_per_gpu": len(prob["blocks"]),
+                   "alg_bytes_per_gpu": int(alg_bytes), "launch": launch,
+                   "partition": "block rows, no data-path collective",
+                   "frac_of_hbm_peak": round(value / (HBM_PEAK_GBPS * world), 4)},
+        "roofline": roofline,
+    }
+    if cpu is not None:
+        out["cpu_baseline"] = cpu
+    if extra:
+        out["extra"] = extra
+    return out
 
 
 if __name__ == "__main__":

@@ -49,9 +49,14 @@ _lib = None
 # every symbol include/bsm_rocm.h declares
 EXPORTS = ["bsm_options_default", "bsm_vbcrs_create", "bsm_vbcrs_create_from_symmetric",
            "bsm_vbcrs_create_from_blocksparse", "bsm_ctx_create", "bsm_ctx_destroy", "bsm_ctx_devices",
-           "bsm_partition_rows", "bsm_part_info", "bsm_blocksparse_create",
+           "bsm_partition_rows", "bsm_part_info", "bsm_host_register", "bsm_host_unregister",
+           "bsm_blocksparse_create",
            "bsm_symmetric_create", "bsm_mul", "bsm_mul_multi", "bsm_get_bookkeeping", "bsm_get_image", "bsm_stats",
            "bsm_color", "bsm_destroy", "bsm_last_error", "bsm_version"]
+
+
+# include/bsm_synth.h (bench / test utility: synthetic operators generated in HBM)
+SYNTH_EXPORTS = ["bsm_synth_blocks", "bsm_synth_vector"]
 
 
 def lib():
@@ -103,6 +108,12 @@ def lib():
     for name in ("bsm_vbcrs_create_from_blocksparse", "bsm_ctx_create", "bsm_ctx_destroy", "bsm_ctx_devices",
                  "bsm_partition_rows", "bsm_part_info"):
         getattr(L, name).restype = C.c_int
+    L.bsm_host_register.argtypes = [C.c_void_p, C.c_int64]
+    L.bsm_host_unregister.argtypes = [C.c_void_p]
+    L.bsm_host_register.restype = L.bsm_host_unregister.restype = C.c_int
+    L.bsm_synth_blocks.argtypes = [C.c_int, C.c_uint64, C.c_int64, _I64P, _I64P, _I64P, _I32P, _PP, C.c_void_p]
+    L.bsm_synth_vector.argtypes = [C.c_int, C.c_uint64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]
+    L.bsm_synth_blocks.restype = L.bsm_synth_vector.restype = C.c_int
     L.bsm_mul.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                           C.c_int, C.c_int, C.c_void_p]
     L.bsm_mul_multi.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,

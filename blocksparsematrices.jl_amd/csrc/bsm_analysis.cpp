@@ -341,7 +341,7 @@ std::string Analysis::build(int mtype_, int dtype_, int64_t nrows_, int64_t ncol
     std::unordered_map<uint64_t, std::vector<int64_t>> gmap;  // hash -> candidate groups
     std::vector<const int64_t *> glist;  // representative index list of indexed groups
     rows.clear();
-    cols.assign(kColsZeroHead, 0);  // 16 zero bytes at the head of the pool (bsm_layout.h)
+    cols.clear();
     for (int64_t b = 0; b < nb; b++) {
         const BlockIn &B = blocks[b];
         if (B.m == 0 || B.n == 0) continue;
@@ -413,7 +413,7 @@ std::string Analysis::build(int mtype_, int dtype_, int64_t nrows_, int64_t ncol
     // merged column lists + value offsets
     uint64_t val_units = 0;
     {
-        int64_t total_cols = kColsZeroHead;
+        int64_t total_cols = 0;
         for (const Group &G : groups) total_cols += G.width + E;
         if (total_cols + 8 > INT32_MAX) return "column index pool exceeds int32";
         cols.reserve((size_t)total_cols);
@@ -427,7 +427,6 @@ std::string Analysis::build(int mtype_, int dtype_, int64_t nrows_, int64_t ncol
     std::vector<uint8_t> group_perm(groups.size(), 0);
     colpos.reserve(cols.capacity());
     ckind.reserve(cols.capacity());
-    ckind.assign(cols.size(), 0);  // the pool's zero head
     {
         std::vector<int32_t> ord;
         size_t gi = 0;
@@ -594,11 +593,35 @@ std::string Analysis::build(int mtype_, int dtype_, int64_t nrows_, int64_t ncol
             std::memset(base + (((size_t)G.val_off + (size_t)(G.strips - 1) * G.mc) * 16 - wbase), 0, (size_t)G.mc * 16);
     };
     bool streamed = false;
-    if (opt.sink) {
+    pack_plan.clear();
+    pack_colpos.clear();
+    if (opt.blocks_on_device) {
+        // the blocks live on the device: leave a plan, the caller runs the pack kernel
+        pack_plan.reserve(chunks.size());
+        bool any_perm = false;
+        for (const Chunk &c : chunks) {
+            const BlockIn &B = blocks[c.blk];
+            PackChunk pc;
+            pc.src = (uint64_t)(uintptr_t)B.data;
+            pc.dst_unit = groups[c.group].val_off;
+            pc.ld = B.ld;
+            pc.ra = c.ra;
+            pc.mc = c.mc;
+            pc.n = (int32_t)B.n;
+            pc.woff = (int32_t)c.woff;
+            pc.perm_off = group_perm[c.group] ? (int32_t)(groups[c.group].col_off + c.woff) : -1;
+            pc.trans = B.trans ? 1 : 0;
+            any_perm |= pc.perm_off >= 0;
+            pack_plan.push_back(pc);
+        }
+        if (any_perm) pack_colpos = colpos;
+    } else if (opt.sink) {
         std::string err = opt.sink->begin((size_t)value_bytes, &streamed);
         if (!err.empty()) return err;
     }
-    if (streamed) {
+    if (opt.blocks_on_device) {
+        // nothing to pack here
+    } else if (streamed) {
         // row groups are laid out in index order: windows of consecutive groups, packed into the
         // sink's staging buffer by all threads, shipped while the next window is being packed
         std::vector<int32_t> ids;

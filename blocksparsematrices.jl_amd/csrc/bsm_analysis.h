@@ -85,6 +85,10 @@ struct AnalysisOptions {
     int accumulate = 0;  // 0 auto, 1 atomic, 2 coloured launches, 3 gather (both bitwise reproducible), 4 direct
     int64_t own_lo = 0, own_hi = 0;  // 1-based inclusive, 0,0 = all rows
     ValueSink *sink = nullptr;       // not owned; nullptr: pack into Analysis::values
+    // the block arrays are DEVICE memory (bsm_options.blocks_memspace): the analysis never reads them;
+    // instead of packed values it leaves a pack plan (Analysis::pack_plan / pack_colpos) that a kernel
+    // executes on the device
+    bool blocks_on_device = false;
     bool meta_only = false;    // validation, statistics and the reference colourings only (no image)
     bool skip_colors = false;  // leave `colors` empty (the parts of a multi-device handle)
 };
@@ -94,6 +98,20 @@ struct AnalysisOptions {
 // identical to oracle/bsm_oracle.c:orc_color_dsatur.  Returns classes of 1-based ids.
 std::vector<std::vector<int64_t>> color_dsatur(const std::vector<const int64_t *> &lists,
                                                const std::vector<int64_t> &lens);
+
+// One chunk (<= 64 rows of one input block) of the device-side repacking: element (i, w) of the
+// chunk goes to merged panel column q = perm_off < 0 ? woff + w : colpos[perm_off + w] of the row
+// group whose panel starts at 16-byte unit dst_unit:  unit (q / E) * mc + i, slot q % E.
+struct PackChunk {
+    uint64_t src;       // device address of the block (column-major, leading dimension ld)
+    uint64_t dst_unit;  // first 16-byte unit of the row group's panel in the value stream
+    int64_t ld;
+    int32_t ra, mc;     // first row of the chunk inside the block, rows
+    int32_t n, woff;    // columns of the block, first merged panel column (identity placement)
+    int32_t perm_off;   // >= 0: offset into pack_colpos (scattered placement)
+    int32_t trans;      // 1: the logical block is the transpose of the stored array
+};
+static_assert(sizeof(PackChunk) == 48, "PackChunk must be 48 bytes");
 
 class Analysis {
   public:
@@ -111,6 +129,8 @@ class Analysis {
 
     // ---- device image (host copy) ----
     RawBuffer values;          // empty when the stream went to AnalysisOptions::sink
+    std::vector<PackChunk> pack_plan;   // blocks_on_device: what the pack kernel executes
+    std::vector<int32_t> pack_colpos;   // ... and the scattered column placements it refers to
     int64_t value_bytes = 0;   // size of the packed value stream
     std::vector<int32_t> rows, cols;
     std::vector<WaveWork> waves;

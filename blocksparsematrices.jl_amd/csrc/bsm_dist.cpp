@@ -307,11 +307,17 @@ int dist_create(bsm_matrix_s *A, bsm_ctx_s *ctx, int mtype, int dtype, int64_t n
             // the image defines (scales / overwrites) every row it touches plus the rows it owns
             po.own_lo = D.plan_n.zr[p].lo + 1;
             po.own_hi = D.plan_n.zr[p].hi;
-            std::unique_ptr<ValueSink> sink = make_device_sink(&pt.img.d_values);
+            const bool devblocks = (o.blocks_memspace == BSM_MEM_DEVICE);
+            std::unique_ptr<ValueSink> sink;
+            if (!devblocks) sink = make_device_sink(&pt.img.d_values);
             AnalysisOptions ao = to_aopt(po, sink.get());
             ao.skip_colors = true;
             std::string err = pt.an.build(mtype, dtype, nrows, ncols, subs[p], ao);
             if (!err.empty()) return build_error("device part " + std::to_string(p) + ": " + err);
+            if (devblocks) {  // the blocks may live on another device of the context: read over xGMI
+                e = device_pack(pt.an, &pt.img.d_values);
+                if (e != hipSuccess) return hip_fail(e, "device-side packing");
+            }
             fill_image(pt.an, po, true, pt.img);
             e = upload_image(pt.an, pt.img, pt.device);
             if (e != hipSuccess) return hip_fail(e, "device upload");

@@ -38,10 +38,6 @@ struct bsm_matrix_s {
     std::mutex host_mu;
     void *stage_x = nullptr, *stage_y = nullptr;
     size_t stage_x_bytes = 0, stage_y_bytes = 0;
-    // pinned host mirrors of the staging buffers (x up, y down): pageable user vectors are copied
-    // through them so that both PCIe transfers are true asynchronous DMA
-    void *pin_x = nullptr, *pin_y = nullptr;
-    size_t pin_x_bytes = 0, pin_y_bytes = 0;
     // handle spread over the devices of a context (bsm_options.ctx)
     std::unique_ptr<bsm::DistState> dist;
     bsm_matrix_s();
@@ -65,6 +61,7 @@ AnalysisOptions to_aopt(const bsm_options &o, ValueSink *sink);
 void fill_image(const Analysis &an, const bsm_options &o, bool use_own, DeviceImage &img);
 hipError_t upload_image(Analysis &an, DeviceImage &img, int dev);
 void free_image(DeviceImage &img);
+hipError_t device_pack(Analysis &an, void **d_values);  // blocks_on_device: run the pack plan on the current device
 // the value sink of a device handle (pinned staging windows + asynchronous upload); nullptr for none
 std::unique_ptr<ValueSink> make_device_sink(void **d_values);
 

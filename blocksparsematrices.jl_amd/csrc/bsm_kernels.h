@@ -46,4 +46,17 @@ hipError_t launch_mul_multi(const DeviceImage &img, bool opT, bool conj, long lo
                             long long ldx, void *y, long long ldy, const void *alpha, const void *beta,
                             int strong_zero, hipStream_t stream);
 
+// executes Analysis::pack_plan on the device (blocks already in HBM): d_plan = PackChunk[nchunks],
+// d_colpos = int32 placements (may be null when no chunk is scattered), es = element bytes
+hipError_t launch_pack(int es, const void *d_plan, long long nchunks, const void *d_colpos, void *d_values,
+                       hipStream_t stream);
+
+// synthetic operators generated in HBM (include/bsm_synth.h); d_desc = SynthBlock[nblocks]
+struct SynthBlockDesc {
+    uint64_t dst, stream;
+    int32_t m, n, symmetrise, pad;
+};
+hipError_t launch_synth_blocks(int dtype, const void *d_desc, long long nblocks, int tiles, hipStream_t stream);
+hipError_t launch_synth_vector(int dtype, void *dst, long long n, unsigned long long stream_seed, hipStream_t stream);
+
 }  // namespace bsm

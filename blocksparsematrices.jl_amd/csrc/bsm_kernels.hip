@@ -15,6 +15,7 @@
 #include <cstdlib>
 #include <type_traits>
 
+#include "bsm_analysis.h"
 #include "bsm_kernels.h"
 #include "bsm_layout.h"
 
@@ -109,11 +110,6 @@ __device__ __forceinline__ c64 shx(c64 a, int d) {
 __device__ __forceinline__ c128 shx(c128 a, int d) {
     return c128{__shfl_xor(a.re, d, 64), __shfl_xor(a.im, d, 64)};
 }
-
-__device__ __forceinline__ float shfl_from(float a, int src) { return __shfl(a, src, 64); }
-__device__ __forceinline__ double shfl_from(double a, int src) { return __shfl(a, src, 64); }
-__device__ __forceinline__ c64 shfl_from(c64 a, int src) { return c64{__shfl(a.re, src, 64), __shfl(a.im, src, 64)}; }
-__device__ __forceinline__ c128 shfl_from(c128 a, int src) { return c128{__shfl(a.re, src, 64), __shfl(a.im, src, 64)}; }
 
 // hardware floating-point atomics (global_atomic_add_f32 / _f64; built with
 // -munsafe-fp-atomics so no compare-and-swap loop is emitted)
@@ -216,9 +212,6 @@ constexpr int FLAG_CONJ = 4;
 constexpr int FLAG_OPT = 8;
 constexpr int FLAG_RMW = 16;     // coloured launch: conflict-free by construction, plain read-modify-write
 constexpr int FLAG_GATHER = 32;  // contributions are stored in the workspace, gather_kernel sums them
-constexpr int FLAG_FLATATOMIC = 128;  // (A/B switch)
-constexpr int FLAG_ALLFLAT = 256;     // (A/B switch)
-constexpr int FLAG_NOFLAT = 64;  // (A/B switch) keep the power-of-two lane mapping for every row group
 
 // ----------------------------------------------------------------------------------------
 // descriptors: fetched as whole 16-byte words through a wave-uniform address (scalar loads),
@@ -447,169 +440,24 @@ __device__ __forceinline__ T run_panel(const WaveD &wd, const uint4 *__restrict_
     return a;
 }
 
-// ----------------------------------------------------------------------------------------
-// forward product of a row group whose height m is NOT 8 / 16 / 32 / 64 -- FLAT lane mapping.
-// run_panel gives every strip P = nextpow2(m) lanes, so a 36-row group keeps 36 of 64 lanes (and
-// 4.6 of 8 KB per wave) busy.  The strip layout [strip][row][e] is one flat array of 16-byte units
-// (unit u = strip * m + row), so here a wave-load simply takes 64 CONSECUTIVE units whatever m is:
-// slot l of lane `lane` owns unit q = lane + 64 l of every iteration, an iteration advances by
-// ds = floor(64 L / m) whole strips (= ds * m units: a multiple of m, so the row q % m and the strip
-// offset q / m of a slot never change).  >= 88 % of the lanes carry data for every m <= 64.
-// Every slot has its own accumulator (its own row); the 64 L partial sums of a wave meet once, at
-// the end, in a 64-entry LDS row slab (ds_add), from which lane i < m reads row i back.
-// ----------------------------------------------------------------------------------------
-template <typename T, int L, bool NT>
-__device__ __forceinline__ T run_panel_flat(const WaveD &wd, const uint4 *__restrict__ values,
-                                            const int *__restrict__ cols, const T *__restrict__ x,
-                                            int flags, int lane, T *xs) {
-    constexpr int E = TT<T>::E;
-    constexpr int XCH = x_chunk_cols<T, false>();
-    const bool cjf = (flags & FLAG_CONJ) != 0;
-    const int m = wd.m;
-    const int ds = (64 * L) / m;  // strips per iteration (>= L)
-    const int upi = ds * m;       // units per iteration (<= 64 L)
-    // floor(q / m) for q < 64 L = 512 and m <= 64 by one multiplication: the error term
-    // q * (inv * m - 2^16) stays below 2^16
-    const int inv = (65536 + m - 1) / m;
-    int so[L];  // strip offset of slot l inside an iteration (its row, q - so * m, is recomputed at the end)
-#pragma unroll
-    for (int l = 0; l < L; ++l) {
-        const int q = lane + 64 * l;
-        so[l] = (q * inv) >> 16;
-    }
-    // upi > 64 L - m >= 64 (L - 1): only lanes of the LAST slot can lie past the last whole strip
-    if (lane + 64 * (L - 1) >= upi) so[L - 1] = 1 << 20;  // never valid
-    T acc[L];
-#pragma unroll
-    for (int l = 0; l < L; ++l) acc[l] = zero_of(T{});
-
-    const PieceD pc = wd.first;
-    if (wd.npieces > 0) {
-        const int xbase = pc.xbase;
-        const int col_off = pc.col_off;
-        const int nstrips = pc.nstrips;
-        const int ncols = pc.ncols;
-        const Vec16<T> *__restrict__ vb = reinterpret_cast<const Vec16<T> *>(
-            values + (((uint64_t)pc.val_hi << 32) | pc.val_lo));
-        const int s1w = wd.seg1_w, s1x = wd.seg1_x - wd.seg1_w;
-        const int s2w = wd.seg2_w, s2x = pc.seg2_x - wd.seg2_w;
-        // xs[XCH .. XCH + E) stays zero, and a masked slot loads the zero unit at the head of the cols
-        // pool instead of matrix bytes:
-        // 0 * 0, never a real x or matrix entry (which may be Inf / NaN).  Every load is
-        // unconditional -- one straight run of L loads, no exec-mask branches between them.
-        if (lane < E) xs[XCH + lane] = zero_of(T{});
-        const Vec16<T> *__restrict__ zu = reinterpret_cast<const Vec16<T> *>(cols);  // cols[0..3] == 0 (bsm_layout.h)
-        for (int c0 = 0; c0 < ncols; c0 += XCH) {
-            // x slice of this chunk (plus the zero-padded tail of the last strip): the loads of up
-            // to 256 columns are in flight together, then the slab is written
-#pragma unroll 1
-            for (int k0 = 0; k0 < XCH / 64 && c0 + k0 * 64 < ncols + E; k0 += 4) {
-                T xv[4];
-                int xi[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) xi[k] = min(c0 + (k0 + k) * 64 + lane, ncols - 1);  // clamped: always a valid column
-                if (xbase < 0) {  // scattered columns: the four index loads go out together
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) xi[k] = cols[col_off + xi[k]];
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) xi[k] &= 0x7fffffff;
-                } else {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) xi[k] += (xi[k] < s1w ? xbase : (xi[k] < s2w ? s1x : s2x));
-                }
-#pragma unroll
-                for (int k = 0; k < 4; ++k) xv[k] = x[xi[k]];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int c = (k0 + k) * 64 + lane;
-                    const int w = c0 + c;
-                    if (w < ncols + E) xs[c] = (w < ncols) ? xv[k] : zero_of(T{});
-                }
-            }
-            const int sc0 = c0 / E;
-            const int s_end = min(nstrips, (c0 + XCH) / E);
-            for (int s0 = sc0; s0 < s_end; s0 += ds) {
-                const int rem = s_end - s0;  // strips left in this chunk
-                const Vec16<T> *__restrict__ vi = vb + ((uint32_t)(s0 * m) + (uint32_t)lane);
-                Vec16<T> b[L];
-#pragma unroll
-                for (int l = 0; l < L; ++l) {
-                    const Vec16<T> *p = (so[l] < rem) ? &vi[64 * l] : zu;
-                    b[l] = NT ? load_stream16(p) : *p;
-                }
-                __builtin_amdgcn_sched_barrier(0);  // all L loads are in flight before the first FMA waits
-                const int cb = (s0 - sc0) * E;
-#pragma unroll
-                for (int l = 0; l < L; ++l) {
-                    const int xo = (so[l] < rem) ? cb + so[l] * E : XCH;
-                    const Vec16<T> xv = *reinterpret_cast<const Vec16<T> *>(&xs[xo]);
-#pragma unroll
-                    for (int e = 0; e < E; ++e) acc[l] = madd(acc[l], cj(b[l].v[e], cjf), xv.v[e]);
-                }
-            }
-        }
-    }
-    // the x slab is dead: it becomes the wave's reduction slab.  LDS instructions of one wave execute
-    // in order; the fences only stop the compiler from moving them across each other.
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    T a = zero_of(T{});
-    if ((flags & FLAG_FLATATOMIC) || XCH < 64 * L) {
-        xs[lane] = zero_of(T{});
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-#pragma unroll
-        for (int l = 0; l < L; ++l) {
-            const int q = lane + 64 * l;
-            if (l < L - 1 || q < upi) lds_acc(&xs[q - ((q * inv) >> 16) * m], acc[l]);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        a = xs[lane];
-    } else {
-        // partial sum of unit q at slab[q] (contiguous, conflict-free stores); lane (r, h), h < H =
-        // 64 / m, then adds up the units r + m (h + H j) of row r, and the H lanes of a row meet by
-        // shuffles
-#pragma unroll
-        for (int l = 0; l < L; ++l) xs[lane + 64 * l] = acc[l];
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        const int H = 64 / m;
-        const int h = (lane * inv) >> 16, r = lane - h * m;
-        // (at most 64 L / (m H) <= 2 L - 1 units per lane; all reads are issued before the first add)
-        T part[2 * L];
-#pragma unroll
-        for (int j = 0; j < 2 * L; ++j) {
-            const int q = r + m * (h + H * j);
-            part[j] = (h < H && q < upi) ? xs[min(q, 64 * L - 1)] : zero_of(T{});
-        }
-#pragma unroll
-        for (int j = 0; j < 2 * L; ++j) a = add(a, part[j]);
-        for (int k = 1; k < H; ++k) {
-            const T o = shfl_from(a, lane + m * k);
-            if (lane < m) a = add(a, o);
-        }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    return a;
-}
-
 // Occupancy is what the small-panel (BEM-shaped) products live on: a small panel is a chain of
 // dependent memory round trips, hidden only by other resident waves.
 //   fp64 forward-only: capped at 80 VGPRs (>= 6 waves per SIMD = 1536 resident workgroups: every
 //     workgroup of a C2-sized launch is resident at once); compiles to 72.
 //   fp64 fused: capped at 64 VGPRs = 8 waves per SIMD, no scratch; with 20 KB of LDS per workgroup
 //     exactly 8 workgroups fit a CU (+11-13 % on 3-28-row fp64 panels over 6 waves).
-//   complex128 with a transposed half: capped at 80 (the fused instance compiles to 71: 7 waves);
-//     forward-only (8 complex accumulators of the flat mapping): 96.
+//   complex128: capped at 80 (the fused instance compiles to 71: 7 waves).
 //   fp32 / complex64: capped at 96 = 5 waves (fp32 fused compiles to 80: 6), no scratch anywhere.
 template <typename T, int L, bool FWD, bool TRN, bool NT>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(
     (FWD && TRN && std::is_same<T, double>::value) ? 8 :
-    (((!TRN && std::is_same<T, double>::value) || (TRN && std::is_same<T, c128>::value)) ? 6 : 5))))
+    (((!TRN && std::is_same<T, double>::value) || std::is_same<T, c128>::value) ? 6 : 5))))
     panel_kernel(const WaveWork *__restrict__ waves, const uint4 *__restrict__ values, const int *__restrict__ rows,
                  const int *__restrict__ cols, const T *__restrict__ x, T *__restrict__ y, T alpha,
                  T beta, int flags, unsigned wg_base, T *__restrict__ ws, long long ws_fbase) {
     constexpr int XS = x_chunk_cols<T, TRN>();         // staged x slice per wave
     constexpr int VS = XS;                             // transposed column sums of one staged chunk
-    // (forward-only kernels: + one zero strip for the masked slots of run_panel_flat)
-    __shared__ __attribute__((aligned(16))) T xs[kWavesPerWg][FWD ? XS + (TRN ? 0 : TT<T>::E) : 1];
+    __shared__ __attribute__((aligned(16))) T xs[kWavesPerWg][FWD ? XS : 1];
     __shared__ __attribute__((aligned(16))) T vs[kWavesPerWg][TRN ? VS : 1];
     // (the cross-wave combine slab of split groups aliases xs: a wave's x slice is dead by then)
     // y window of workgroups that pack neighbouring small row groups of a symmetric operator
@@ -630,9 +478,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(
 
     T u = zero_of(T{});
     if (work == WORK_PANEL) {
-        if (FWD && !TRN && !(flags & FLAG_NOFLAT) && ((flags & FLAG_ALLFLAT) || (m != 8 && m != 16 && m != 32 && m != 64)))
-            u = run_panel_flat<T, L, NT>(wd, values, cols, x, flags, lane, xs[wave]);
-        else if (m <= 8)
+        if (m <= 8)
             u = run_panel<T, L, 8, FWD, TRN, NT>(wd, values, rows, cols, x, y, alpha, flags, lane, xs[wave], vs[wave], win, win_n, ws);
         else if (m <= 16)
             u = run_panel<T, L, 16, FWD, TRN, NT>(wd, values, rows, cols, x, y, alpha, flags, lane, xs[wave], vs[wave], win, win_n, ws);
@@ -1031,11 +877,6 @@ static hipError_t launch_typed(const DeviceImage &img, bool opT, bool conj, cons
     const dim3 block(256);
     const bool nt = stream_policy(img);
 
-    static const bool noflat = std::getenv("BSM_NOFLAT") != nullptr;
-    if (noflat) flags |= FLAG_NOFLAT;
-    static const bool allflat = std::getenv("BSM_ALLFLAT") != nullptr, flatatomic = std::getenv("BSM_FLATATOMIC") != nullptr;
-    if (allflat) flags |= FLAG_ALLFLAT;
-    if (flatatomic) flags |= FLAG_FLATATOMIC;
     if (!opT && img.exclusive_fwd) {
         // one launch: every y row has exactly one producer; beta is fused into its store and
         // the rows no block covers are scaled by WORK_SCALE waves of the same grid.
@@ -1263,6 +1104,123 @@ hipError_t launch_vec_axpby(int dtype, void *y, const void *r, long long n, cons
         case 3: return vec_launch<c128>(1, y, r, n, beta, stream);
     }
     return hipErrorInvalidValue;
+}
+
+// ========================================================================================
+// device-side repacking (bsm_options.blocks_memspace = BSM_MEM_DEVICE): the caller's blocks already
+// live in HBM (e.g. ROCArrays), so the strip layout is written by a kernel instead of the host
+// packer -- no matrix byte crosses PCIe.  One workgroup per chunk (<= 64 rows of one block);
+// consecutive lanes read consecutive rows of a column (coalesced) and write the same slot of
+// consecutive 16-byte units.  HBM-bound, runs once per operator.
+// ========================================================================================
+template <typename U>
+__global__ void __launch_bounds__(256) pack_kernel(const PackChunk *__restrict__ plan, const int *__restrict__ colpos,
+                                                   U *__restrict__ values, int E) {
+    const PackChunk c = plan[blockIdx.x];
+    const U *__restrict__ src = reinterpret_cast<const U *>(c.src);
+    U *__restrict__ dst = values + c.dst_unit * (uint64_t)E;
+    const int mc = c.mc;
+    // lanes run over the rows of the chunk, rounded up to a power of two <= 64 so that a wave covers
+    // whole columns
+    int rp = 1;
+    while (rp < mc) rp <<= 1;
+    const int i = threadIdx.x & (rp - 1);
+    const int cpw = 256 / rp;  // columns per pass
+    if (i >= mc) return;
+    for (int w = threadIdx.x / rp; w < c.n; w += cpw) {
+        const int q = c.perm_off < 0 ? c.woff + w : colpos[c.perm_off + w];
+        const U v = c.trans ? src[(int64_t)w + (int64_t)(c.ra + i) * c.ld] : src[(int64_t)(c.ra + i) + (int64_t)w * c.ld];
+        dst[((int64_t)(q / E) * mc + i) * E + (q % E)] = v;
+    }
+}
+
+hipError_t launch_pack(int es, const void *d_plan, long long nchunks, const void *d_colpos, void *d_values,
+                       hipStream_t stream) {
+    if (nchunks <= 0) return hipSuccess;
+    const PackChunk *plan = (const PackChunk *)d_plan;
+    const int *cp = (const int *)d_colpos;
+    const dim3 grid((unsigned)nchunks), block(256);
+    if (es == 4)
+        hipLaunchKernelGGL((pack_kernel<uint32_t>), grid, block, 0, stream, plan, cp, (uint32_t *)d_values, 4);
+    else if (es == 8)
+        hipLaunchKernelGGL((pack_kernel<uint64_t>), grid, block, 0, stream, plan, cp, (uint64_t *)d_values, 2);
+    else
+        hipLaunchKernelGGL((pack_kernel<uint4>), grid, block, 0, stream, plan, cp, (uint4 *)d_values, 1);
+    return hipGetLastError();
+}
+
+// ========================================================================================
+// synthetic operators of BASELINE.json generated IN HBM (include/bsm_synth.h): the counter-based
+// SplitMix64 streams of blocksparsematrices.jl_amd/synthetic.py, bit-identical to the numpy code.
+//   u(s, k) = mix(s + GOLDEN * (k + 1)),  value = (u >> 11) * 2^-53 * 2 - 1  (fp64, then cast)
+// ========================================================================================
+__host__ __device__ __forceinline__ uint64_t synth_mix(uint64_t z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__device__ __forceinline__ double synth_unit(uint64_t stream, uint64_t k) {
+    const uint64_t u = synth_mix(stream + 0x9E3779B97F4A7C15ull * (k + 1));
+    return (double)(u >> 11) * 0x1.0p-53 * 2.0 - 1.0;
+}
+__device__ __forceinline__ void synth_store(float *p, double v) { *p = (float)v; }
+__device__ __forceinline__ void synth_store(double *p, double v) { *p = v; }
+
+struct SynthBlock {
+    uint64_t dst;     // device address, column-major m x n, leading dimension m
+    uint64_t stream;  // mix(seed ^ mix(b + 1))
+    int32_t m, n;
+    int32_t symmetrise, pad;  // 1: (D + D^T) / 2 of the m x m draw (diagonal blocks, docs/src/symmetric.md:49-50)
+};
+
+template <typename T>
+__global__ void __launch_bounds__(256) synth_blocks_kernel(const SynthBlock *__restrict__ blocks) {
+    const SynthBlock b = blocks[blockIdx.x];
+    T *__restrict__ dst = reinterpret_cast<T *>(b.dst);
+    const long long cnt = (long long)b.m * b.n;
+    for (long long k = (long long)blockIdx.y * 256 + threadIdx.x; k < cnt; k += (long long)gridDim.y * 256) {
+        double v = synth_unit(b.stream, (uint64_t)k);
+        if (b.symmetrise) {
+            const long long i = k % b.m, j = k / b.m;
+            // the reference recipe rounds the draw to T first, then averages in T
+            const T a = (T)v, c = (T)synth_unit(b.stream, (uint64_t)(j + i * b.m));
+            dst[k] = (a + c) / (T)2;
+        } else {
+            synth_store(&dst[k], v);
+        }
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) synth_vector_kernel(T *__restrict__ dst, long long n, uint64_t stream) {
+    long long k = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long stride = (long long)gridDim.x * 256;
+    for (; k < n; k += stride) synth_store(&dst[k], synth_unit(stream, (uint64_t)k));
+}
+
+hipError_t launch_synth_blocks(int dtype, const void *d_desc, long long nblocks, int tiles, hipStream_t stream) {
+    if (nblocks <= 0) return hipSuccess;
+    const dim3 grid((unsigned)nblocks, (unsigned)tiles), block(256);
+    if (dtype == 0)
+        hipLaunchKernelGGL((synth_blocks_kernel<float>), grid, block, 0, stream, (const SynthBlock *)d_desc);
+    else if (dtype == 1)
+        hipLaunchKernelGGL((synth_blocks_kernel<double>), grid, block, 0, stream, (const SynthBlock *)d_desc);
+    else
+        return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+hipError_t launch_synth_vector(int dtype, void *dst, long long n, unsigned long long stream_seed, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    long long nblk = (n + 255) / 256;
+    if (nblk > 8192) nblk = 8192;
+    if (dtype == 0)
+        hipLaunchKernelGGL((synth_vector_kernel<float>), dim3((unsigned)nblk), dim3(256), 0, stream, (float *)dst, n, (uint64_t)stream_seed);
+    else if (dtype == 1)
+        hipLaunchKernelGGL((synth_vector_kernel<double>), dim3((unsigned)nblk), dim3(256), 0, stream, (double *)dst, n, (uint64_t)stream_seed);
+    else
+        return hipErrorInvalidValue;
+    return hipGetLastError();
 }
 
 }  // namespace bsm

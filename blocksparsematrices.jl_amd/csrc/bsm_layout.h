@@ -12,8 +12,6 @@
 //   rows   : int32 0-based y/x index lists of row groups whose rows are not a contiguous
 //            range.
 //   cols   : int32 0-based merged column list of every row group (x index per panel column).
-//            The pool starts with kColsZeroHead zero entries = one 16-byte ZERO UNIT: what a masked
-//            load slot of the flat lane mapping reads instead of matrix bytes.
 //   waves  : WaveWork descriptors (64 B), 4 per workgroup.  A wave streams ONE piece = a
 //            strip range of one merged panel, described inline, so it reaches its matrix
 //            bytes after ONE dependent (scalar) load.
@@ -82,7 +80,6 @@ constexpr int kKindHasOff = 1 << 8;
 constexpr int kKindGroupHasOff = 1 << 9;
 constexpr uint32_t kColDiagBit = 0x80000000u;
 
-constexpr int kColsZeroHead = 4;
 constexpr int kWavesPerWg = 4;
 constexpr int kMaxRowsPerChunk = 64;
 constexpr int kScaleRowsPerWave = 1024;

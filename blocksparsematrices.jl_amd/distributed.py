@@ -1,17 +1,19 @@
-"""Single-node multi-GPU layer: one process per GPU (torch.distributed, backend "nccl" == RCCL
-over xGMI), block rows partitioned over the ranks.
+"""One process per GPU (torch.distributed, backend "nccl" == RCCL over xGMI): the block rows of an
+operator partitioned over the ranks of a single 8 x MI355X node.
 
-The reference has no distributed code at all (one process, shared-memory tasks); this layer is the
-MI355X-first counterpart of its `@tasks` fan-out over block rows / colour classes.
+The reference has no distributed code (one process, shared-memory tasks); this layer and the
+in-library multi-device handles (bsm_ctx_t, csrc/bsm_dist.cpp) are the two MI355X counterparts of its
+`@tasks` fan-out over block rows / colour classes.  Both use the SAME row partition
+(`bsm_partition_rows` in the C ABI) and the same exchange pattern:
 
   * VBCRS forward: block rows own disjoint y ranges (reference src/vbcrs.jl:275-283), so every
     rank multiplies its own rows and NO collective is needed; `gather=True` adds one all-gather of
-    the y slices for callers that need the whole y on every GPU (a Krylov iteration).
+    the y slices for callers that need the whole y on every GPU (a Krylov iteration: y is the next x).
   * SymmetricBlockMatrix: the off-diagonal block (I, J) lives with the owner of row set I but also
     contributes B^T x_I to y_J, which may belong to another rank (for banded operators: the
     previous rank only).  Each rank accumulates into a work vector over the rows it TOUCHES and the
-    overlaps are exchanged point-to-point (isend/irecv == ncclSend/ncclRecv over the direct xGMI
-    links) and added -- never a ring all-reduce of the full y, which would be bound by one link.
+    overlaps are exchanged point-to-point (batched isend/irecv == ncclSend/ncclRecv over the direct
+    xGMI links) and added -- never a ring all-reduce of the full y, which would be bound by one link.
   * BlockSparseMatrix (index lists): blocks go with the rank that owns their smallest row index;
     rows a block reaches outside its rank's range travel through the same point-to-point exchange.
   * Products that run ACROSS the partition (transpose(A)*x of a row-partitioned VBCRS /
@@ -19,6 +21,10 @@ MI355X-first counterpart of its `@tasks` fan-out over block rows / colour classe
     rank: one reduce-scatter onto equal chunks (all-reduce when the caller wants the whole y).
     `split_vbcrs(..., axis=1)` is the column partition that makes the TRANSPOSED products
     collective-free (mirror of the forward case, reference src/vbcrs.jl:303-329).
+
+x holds the FULL vector on every rank (8-40 MB at the BASELINE sizes); with gather=True the result
+is replicated again, which is what an iterative solver needs.  Every buffer of the exchange is
+allocated once, at the first product of a given kind.
 """
 import numpy as np
 
@@ -34,7 +40,7 @@ from . import matrices as M
 
 def balanced_cuts(weights, nparts):
     """Cut len(weights) consecutive units into nparts contiguous ranges of ~equal total weight.
-    Returns nparts+1 boundaries (unit indices)."""
+    Returns nparts+1 boundaries (unit indices).  (Same rule as bsm_partition_rows.)"""
     w = np.asarray(weights, dtype=np.float64)
     csum = np.concatenate([[0.0], np.cumsum(w)])
     total = csum[-1]
@@ -48,92 +54,79 @@ def balanced_cuts(weights, nparts):
     return cuts
 
 
+def _minrow(lst):
+    return int(np.min(lst)) if len(lst) else 1
+
+
 def split_vbcrs(problem, rank, nparts, axis=0):
     """Partition a VBCRS problem dict into contiguous ranges of block rows (axis=0) or block columns
-    (axis=1: for transposed products) balanced by stored bytes.
-    Returns (local problem, own=(lo, hi) 1-based inclusive along `axis`)."""
-    rs = np.asarray(problem["rowstart" if axis == 0 else "colstart"], dtype=np.int64)
-    n = problem["size"][axis]
-    starts = np.unique(rs)  # block rows, sorted
-    bytes_per_row = np.zeros(len(starts))
-    idx = np.searchsorted(starts, rs)
-    for b, blk in enumerate(problem["blocks"]):
-        bytes_per_row[idx[b]] += blk.size
-    cuts = balanced_cuts(bytes_per_row, nparts)
-    lo_row = int(starts[cuts[rank]]) if cuts[rank] < len(starts) else n + 1
-    hi_row = int(starts[cuts[rank + 1]]) - 1 if cuts[rank + 1] < len(starts) else n
-    if rank == 0:
-        lo_row = 1
-    keep = [b for b in range(len(rs)) if cuts[rank] <= idx[b] < cuts[rank + 1]]
+    (axis=1: for transposed products) balanced by stored entries (bsm_partition_rows).
+    Returns (local problem, own=(lo, hi) 1-based inclusive along `axis`; hi = lo - 1: nothing)."""
+    keys = np.asarray(problem["rowstart" if axis == 0 else "colstart"], dtype=np.int64)
+    weights = [b.size for b in problem["blocks"]]
+    part, own = M.partition_rows(problem["size"][axis], keys, weights, nparts)
+    keep = np.nonzero(part == rank)[0]
     local = dict(kind="vbcrs", blocks=[problem["blocks"][b] for b in keep],
                  rowstart=np.asarray(problem["rowstart"], dtype=np.int64)[keep],
                  colstart=np.asarray(problem["colstart"], dtype=np.int64)[keep], size=problem["size"])
-    return local, (lo_row, hi_row)
+    return local, own[rank]
+
+
+def _touched(own, lists):
+    lo, hi = own
+    for lst in lists:
+        if len(lst):
+            lo, hi = min(lo, int(np.min(lst))), max(hi, int(np.max(lst)))
+    return (lo, hi) if hi >= lo else (own[0], own[0] - 1)
 
 
 def split_blocksparse(problem, rank, nparts):
-    """Partition a BlockSparseMatrix problem (arbitrary index lists): blocks sorted by their smallest
-    row index, cut into ranges balanced by stored bytes; a rank owns the rows from its first block's
-    smallest row up to the next rank's.  Returns (local problem, own, touched), 1-based inclusive."""
-    n = problem["size"][0]
-    first = np.array([int(np.min(r)) if len(r) else 1 for r in problem["rowindices"]], dtype=np.int64)
-    order = np.argsort(first, kind="stable")
-    w = np.array([problem["blocks"][b].size for b in order], dtype=np.float64)
-    cuts = balanced_cuts(w, nparts)
-    # blocks with the same smallest row stay together, so that the row ranges are disjoint
-    for p in range(1, nparts):
-        k = cuts[p]
-        while 0 < k < len(order) and first[order[k]] == first[order[k - 1]]:
-            k += 1
-        cuts[p] = max(k, cuts[p - 1])
-    lo = int(first[order[cuts[rank]]]) if cuts[rank] < len(order) else n + 1
-    hi = int(first[order[cuts[rank + 1]]]) - 1 if cuts[rank + 1] < len(order) else n
-    if rank == 0:
-        lo = 1
-    keep = [int(order[k]) for k in range(cuts[rank], cuts[rank + 1])]
+    """Partition a BlockSparseMatrix problem (arbitrary index lists): a block goes with the rank that
+    owns its smallest row index.  Returns (local problem, own, touched), 1-based inclusive."""
+    keys = [_minrow(r) for r in problem["rowindices"]]
+    weights = [b.size for b in problem["blocks"]]
+    part, own = M.partition_rows(problem["size"][0], keys, weights, nparts)
+    keep = [int(b) for b in np.nonzero(part == rank)[0]]
     local = dict(kind="blocksparse", blocks=[problem["blocks"][b] for b in keep],
                  rowindices=[problem["rowindices"][b] for b in keep],
                  colindices=[problem["colindices"][b] for b in keep], size=problem["size"])
-    tlo, thi = lo, hi
-    for lst in local["rowindices"]:
-        if len(lst):
-            tlo, thi = min(tlo, int(np.min(lst))), max(thi, int(np.max(lst)))
-    if thi < tlo:
-        tlo, thi = lo, lo - 1
-    return local, (lo, hi), (tlo, thi)
+    return local, own[rank], _touched(own[rank], local["rowindices"])
 
 
 def split_symmetric(problem, rank, nparts):
-    """Partition a SymmetricBlockMatrix problem by diagonal segments (balanced by stored bytes of the
-    segment's diagonal block + the off-diagonal blocks whose rows start in it).
+    """Partition a SymmetricBlockMatrix problem: diagonal block d and off-diagonal block b go with the
+    rank that owns their smallest (row) index, balanced by stored entries.
     Returns (local problem, own=(lo, hi), touched=(lo, hi)), 1-based inclusive."""
-    n = problem["size"][0]
-    dfirst = np.array([int(np.min(d)) for d in problem["diagonalindices"]], dtype=np.int64)
-    order = np.argsort(dfirst, kind="stable")
-    seg_start = dfirst[order]
-    w = np.array([problem["diagonals"][i].size for i in order], dtype=np.float64)
-    ofirst = np.array([int(np.min(r)) for r in problem["rowindices"]], dtype=np.int64)
-    oseg = np.clip(np.searchsorted(seg_start, ofirst, side="right") - 1, 0, len(seg_start) - 1)
-    for b, blk in enumerate(problem["offdiagonals"]):
-        w[oseg[b]] += blk.size
-    cuts = balanced_cuts(w, nparts)
-    lo = int(seg_start[cuts[rank]]) if cuts[rank] < len(seg_start) else n + 1
-    hi = int(seg_start[cuts[rank + 1]]) - 1 if cuts[rank + 1] < len(seg_start) else n
-    if rank == 0:
-        lo = 1
-    dkeep = [int(order[k]) for k in range(cuts[rank], cuts[rank + 1])]
-    okeep = [b for b in range(len(ofirst)) if cuts[rank] <= oseg[b] < cuts[rank + 1]]
+    nd = len(problem["diagonals"])
+    keys = [_minrow(d) for d in problem["diagonalindices"]] + [_minrow(r) for r in problem["rowindices"]]
+    weights = [b.size for b in problem["diagonals"]] + [b.size for b in problem["offdiagonals"]]
+    part, own = M.partition_rows(problem["size"][0], keys, weights, nparts)
+    dkeep = [int(i) for i in np.nonzero(part[:nd] == rank)[0]]
+    okeep = [int(b) for b in np.nonzero(part[nd:] == rank)[0]]
     local = dict(kind="symmetric", diagonals=[problem["diagonals"][i] for i in dkeep],
                  diagonalindices=[problem["diagonalindices"][i] for i in dkeep],
                  offdiagonals=[problem["offdiagonals"][b] for b in okeep],
                  rowindices=[problem["rowindices"][b] for b in okeep],
                  colindices=[problem["colindices"][b] for b in okeep], size=problem["size"])
-    tlo, thi = lo, hi
-    for lst in local["diagonalindices"] + local["rowindices"] + local["colindices"]:
-        tlo, thi = min(tlo, int(np.min(lst))), max(thi, int(np.max(lst)))
-    if thi < tlo:
-        tlo, thi = lo, lo - 1
-    return local, (lo, hi), (tlo, thi)
+    touched = _touched(own[rank], local["diagonalindices"] + local["rowindices"] + local["colindices"])
+    return local, own[rank], touched
+
+
+def is_empty(local):
+    """A rank may receive no block at all (more ranks than block rows): it creates no handle
+    (`RowPartitioned(None, ...)`) and still takes part in every collective."""
+    return (len(local.get("blocks", ())) + len(local.get("diagonals", ())) + len(local.get("offdiagonals", ()))) == 0
+
+
+def build_local(local, touched=None, **kw):
+    """The rank's handle: built with own = the rows it TOUCHES, so that its `y .*= beta` pass covers
+    exactly the rows it writes.  None for a rank without blocks."""
+    if is_empty(local):
+        return None
+    from . import synthetic
+    if touched is not None and touched[1] >= touched[0]:
+        kw["own"] = touched
+    return synthetic.build(local, **kw)
 
 
 class RowPartitioned:
@@ -146,7 +139,7 @@ class RowPartitioned:
     x must hold the FULL vector on every rank.  After mul() the rank's output range is final in y
     (the whole y when gather=True): `own` for products along the partition, `out_range(n)` (equal
     chunks) for products across it.  `local` is this rank's matrix (built with own=touched range so
-    its beta pass covers exactly the rows it touches)."""
+    its beta pass covers exactly the rows it touches), or None for a rank without blocks."""
 
     def __init__(self, local, own, touched=None, group=None, gather=False, axis=0, symmetric=None):
         self.local = local
@@ -159,10 +152,10 @@ class RowPartitioned:
         self.rank = dist.get_rank(group) if dist is not None and dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist is not None and dist.is_initialized() else 1
         self._ranges = None
+        self._plan = None   # halo exchange of products along the partition (buffers included)
         self._work = None
-        self._gbuf = None
-        self._sbuf = None
-        self._pad = None
+        self._gbuf = self._sbuf = self._pad = self._rsout = None
+        self._ops = {}
 
     def out_range(self, n, rank=None):
         """Output rows (1-based, inclusive) rank `rank` holds after a product ACROSS the partition."""
@@ -170,14 +163,13 @@ class RowPartitioned:
         chunk = -(-n // self.world)
         return (min(r * chunk, n) + 1, min((r + 1) * chunk, n))
 
-    def _exchange_ranges(self):
+    def _exchange_ranges(self, device):
         """(own, touched) of every rank -- one small all_gather at first use."""
         if self._ranges is None:
             mine = torch.tensor([self.own[0], self.own[1], self.touched[0], self.touched[1]], dtype=torch.int64)
             if self.world > 1:
-                dev = self._device
-                out = [torch.zeros(4, dtype=torch.int64, device=dev) for _ in range(self.world)]
-                dist.all_gather(out, mine.to(dev), group=self.group)
+                out = [torch.zeros(4, dtype=torch.int64, device=device) for _ in range(self.world)]
+                dist.all_gather(out, mine.to(device), group=self.group)
                 self._ranges = [tuple(int(v) for v in t.cpu()) for t in out]
             else:
                 self._ranges = [tuple(int(v) for v in mine)]
@@ -187,57 +179,91 @@ class RowPartitioned:
         if self._work is None or self._work.shape != y.shape or self._work.device != y.device or \
                 self._work.dtype != y.dtype:
             self._work = torch.zeros_like(y)
+            self._plan = None
         return self._work
+
+    def _halo_plan(self, w, ranges):
+        """Send views into the work vector and preallocated receive buffers, one pair per peer whose
+        owned rows this rank touches / that touches this rank's rows."""
+        if self._plan is None:
+            olo, ohi = self.own
+            tlo, thi = self.touched
+            sends, recvs = [], []
+            for r, (rlo, rhi, rtlo, rthi) in enumerate(ranges):
+                if r == self.rank:
+                    continue
+                a, b = max(tlo, rlo), min(thi, rhi)  # my contributions to rank r's rows
+                if a <= b:
+                    sends.append((r, w[a - 1:b]))
+                a, b = max(rtlo, olo), min(rthi, ohi)  # rank r's contributions to my rows
+                if a <= b:
+                    recvs.append((r, a, b, torch.empty(b - a + 1, dtype=w.dtype, device=w.device)))
+            self._plan = (sends, recvs)
+        return self._plan
+
+    def _host_mediated_fence(self, t):
+        """RCCL orders its transfers against the compute stream by itself.  `gloo` (the CPU rehearsal
+        backend) moves CUDA tensors through host staging on its own side streams and does not order a
+        receive against kernels still reading the REUSED receive buffer: drain the stream first."""
+        if t.is_cuda and dist.get_backend(self.group) != "nccl":
+            torch.cuda.current_stream(t.device).synchronize()
 
     @staticmethod
     def _combine(y, sl, w, beta):
         if beta is False:
             y[sl] = w
+        elif beta is True or beta == 1:
+            y[sl] += w
         else:
-            y[sl] = y[sl] * (1 if beta is True else beta) + w
+            y[sl].mul_(beta).add_(w)
+
+    def _local_op(self, op):
+        if op not in self._ops:
+            A = self.local
+            self._ops[op] = A if op == M.L.BSM_OP_N else (M.transpose(A) if op == M.L.BSM_OP_T else M.adjoint(A))
+        return self._ops[op]
 
     def mul(self, y, x, alpha=True, beta=False, local_mul=None, op=M.L.BSM_OP_N):
         """local_mul(work_or_y, x, alpha, beta[, op]): test hook replacing the HIP product (CPU gloo tests)."""
-        self._device = y.device
         N_ = M.L.BSM_OP_N
         if local_mul is not None:
             lm = (lambda yy, xx, a, b: local_mul(yy, xx, a, b)) if op == N_ and self.axis == 0 else \
                 (lambda yy, xx, a, b: local_mul(yy, xx, a, b, op))
+        elif self.local is None:
+            lm = None  # a rank without blocks: nothing to multiply, the collectives still run
         else:
-            Aop = self.local if op == N_ else (M.transpose(self.local) if op == M.L.BSM_OP_T else M.adjoint(self.local))
+            Aop = self._local_op(op)
             lm = lambda yy, xx, a, b: M.mul(yy, Aop, xx, a, b)
         along = self.symmetric or ((op == N_) == (self.axis == 0))
-        ranges = self._exchange_ranges()
+        ranges = self._exchange_ranges(y.device)
         if not along:
             return self._mul_across(y, x, alpha, beta, lm)
         # collective decision: if ANY rank touches rows it does not own, every rank takes part in
         # the exchange (a rank without a halo of its own may still receive contributions)
         halo = any((rl, rh) != (tl, th) for rl, rh, tl, th in ranges)
+        olo, ohi = self.own
         if not halo and self.axis == 0 and op == N_:
-            lm(y, x, alpha, beta)  # rows outside `own` are left untouched by the handle
+            if lm is not None:
+                lm(y, x, alpha, beta)  # rows outside `own` are left untouched by the handle
+            elif ohi >= olo:
+                self._combine(y, slice(olo - 1, ohi), 0, beta)
         else:
             w = self._workvec(y)
-            lm(w, x, alpha, False)  # strong zero over the touched range, then accumulate
-            ops, recvs = [], []
-            olo, ohi = self.own
-            tlo, thi = self.touched
-            for r, (rlo, rhi, rtlo, rthi) in enumerate(ranges):
-                if r == self.rank or not halo:
-                    continue
-                a, b = max(tlo, rlo), min(thi, rhi)  # my contributions to rank r's rows
-                if a <= b:
-                    ops.append(dist.P2POp(dist.isend, w[a - 1:b].contiguous(), r, group=self.group))
-                a, b = max(rtlo, olo), min(rthi, ohi)  # rank r's contributions to my rows
-                if a <= b:
-                    buf = torch.empty(b - a + 1, dtype=y.dtype, device=y.device)
-                    recvs.append((a, b, buf))
-                    ops.append(dist.P2POp(dist.irecv, buf, r, group=self.group))
-            if ops:
+            if lm is not None:
+                lm(w, x, alpha, False)  # strong zero over the touched range, then accumulate
+            elif ohi >= olo:
+                w[olo - 1:ohi] = 0
+            sends, recvs = self._halo_plan(w, ranges)
+            if halo and (sends or recvs):
+                self._host_mediated_fence(w)
+                ops = [dist.P2POp(dist.isend, v, r, group=self.group) for r, v in sends]
+                ops += [dist.P2POp(dist.irecv, buf, r, group=self.group) for r, _, _, buf in recvs]
                 for req in dist.batch_isend_irecv(ops):
                     req.wait()
-            own_slice = slice(olo - 1, ohi)
-            self._combine(y, own_slice, w[own_slice], beta)
-            for a, b, buf in recvs:
+            if ohi >= olo:
+                own_slice = slice(olo - 1, ohi)
+                self._combine(y, own_slice, w[own_slice], beta)
+            for _, a, b, buf in recvs:
                 y[a - 1:b] += buf
         if self.gather and self.world > 1:
             self._allgather(y, [(rl, rh) for rl, rh, _, _ in ranges])
@@ -248,7 +274,10 @@ class RowPartitioned:
         all-reduce when the whole y is wanted on every rank)."""
         n = y.shape[0]
         w = self._workvec(y)
-        lm(w, x, alpha, False)
+        if lm is not None:
+            lm(w, x, alpha, False)
+        else:
+            w.zero_()
         if self.world == 1:
             self._combine(y, slice(0, n), w, beta)
             return y
@@ -260,18 +289,21 @@ class RowPartitioned:
         if self._pad is None or self._pad.shape[0] != chunk * self.world or self._pad.device != y.device or \
                 self._pad.dtype != y.dtype:
             self._pad = torch.zeros(chunk * self.world, dtype=y.dtype, device=y.device)
+            self._rsout = torch.empty(chunk, dtype=y.dtype, device=y.device)
         self._pad[:n] = w
-        out = torch.empty(chunk, dtype=y.dtype, device=y.device)
-        dist.reduce_scatter(out, list(self._pad.view(self.world, chunk).unbind(0)), group=self.group)
+        self._host_mediated_fence(w)
+        dist.reduce_scatter_tensor(self._rsout, self._pad, group=self.group)
         lo, hi = self.out_range(n)
         if hi >= lo:
-            self._combine(y, slice(lo - 1, hi), out[:hi - lo + 1], beta)
+            self._combine(y, slice(lo - 1, hi), self._rsout[:hi - lo + 1], beta)
         return y
 
     def _allgather(self, y, own_ranges):
         # one all-gather of the (padded) own slices instead of one broadcast per rank: a single
         # collective whose per-peer messages (~n/N entries) use all xGMI links at once
         maxlen = max(max(rh - rl + 1, 0) for rl, rh in own_ranges)
+        if maxlen == 0:
+            return y
         if self._gbuf is None or self._gbuf.shape[0] != self.world * maxlen or self._gbuf.device != y.device or \
                 self._gbuf.dtype != y.dtype:
             self._gbuf = torch.empty(self.world * maxlen, dtype=y.dtype, device=y.device)
@@ -279,7 +311,8 @@ class RowPartitioned:
         olo, ohi = self.own
         if ohi >= olo:
             self._sbuf[:ohi - olo + 1] = y[olo - 1:ohi]
-        dist.all_gather(list(self._gbuf.view(self.world, maxlen).unbind(0)), self._sbuf, group=self.group)
+        self._host_mediated_fence(y)
+        dist.all_gather_into_tensor(self._gbuf, self._sbuf, group=self.group)
         for r, (rlo, rhi) in enumerate(own_ranges):
             if r != self.rank and rhi >= rlo:
                 y[rlo - 1:rhi] = self._gbuf[r * maxlen:r * maxlen + (rhi - rlo + 1)]

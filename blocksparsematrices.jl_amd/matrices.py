@@ -36,7 +36,7 @@ __all__ = [
     "rowindices", "colindices", "colors", "transposecolors", "diagonal", "offdiagonal",
     "eachdiagonalindex", "eachoffdiagonalindex", "diagonalindices", "diagonalcolors",
     "offdiagonalcolors", "transposeoffdiagonalcolors", "rowcolvals", "sparse", "ColorInfo", "conflicts",
-    "color", "coloringalgorithm", "Context", "partition_rows",
+    "color", "coloringalgorithm", "Context", "partition_rows", "host_register", "host_unregister",
 ]
 
 _DT = {np.dtype(np.float32): L.BSM_F32, np.dtype(np.float64): L.BSM_F64,
@@ -65,9 +65,54 @@ def _i64(a):
 
 def _ptrs(arrs):
     out = (C.c_void_p * max(len(arrs), 1))()
+    if len(arrs) and _is_dev(arrs):
+        for i, a in enumerate(arrs):
+            out[i] = a.data_ptr()
+        return out
     for i, a in enumerate(arrs):
         out[i] = a.ctypes.data
     return out
+
+
+_TORCH_DT = {}
+if torch is not None:
+    _TORCH_DT = {torch.float32: np.dtype(np.float32), torch.float64: np.dtype(np.float64),
+                 torch.complex64: np.dtype(np.complex64), torch.complex128: np.dtype(np.complex128)}
+
+
+def _is_dev(blocks):
+    """Blocks given as torch CUDA tensors: device-resident operator data (bsm_options.blocks_memspace
+    = BSM_MEM_DEVICE), repacked by a kernel -- the Python stand-in for a Julia caller's ROCArrays."""
+    return torch is not None and len(blocks) > 0 and isinstance(blocks[0], torch.Tensor) and blocks[0].is_cuda
+
+
+def _dev_blocks(*blocklists):
+    """Checks device-resident blocks (all CUDA tensors of one dtype and device, column-major) -> numpy dtype."""
+    dt = dev = None
+    for bl in blocklists:
+        for b in bl:
+            if not (isinstance(b, torch.Tensor) and b.is_cuda and b.dim() == 2):
+                raise TypeError("device-resident blocks must all be 2-D torch CUDA tensors")
+            if b.dtype not in _TORCH_DT or (dt is not None and _TORCH_DT[b.dtype] != dt):
+                raise TypeError("device-resident blocks must share one supported element type")
+            if b.shape[0] > 1 and b.stride(0) != 1 or (b.shape[1] > 1 and b.stride(1) < max(b.shape[0], 1)):
+                raise TypeError("device-resident blocks must be column-major (e.g. torch.empty(n, m).t())")
+            if dev is not None and b.device != dev:
+                raise ValueError("device-resident blocks must live on one device")
+            dt, dev = _TORCH_DT[b.dtype], b.device
+    return dt
+
+
+def _lds(blocks):
+    """leading dimensions (elements) of column-major blocks"""
+    if _is_dev(blocks):
+        return _i64([max(b.stride(1) if b.shape[1] > 1 else b.shape[0], b.shape[0], 1) for b in blocks])
+    return _i64([max(b.shape[0], 1) for b in blocks])
+
+
+def _host(b):
+    """numpy view of a block wherever it lives (accessors used by sparse() / rowcolvals())"""
+    return b.cpu().numpy() if (torch is not None and isinstance(b, torch.Tensor)) else np.asarray(b)
 
 
 def _blocks_dtype(*blocklists):
@@ -118,6 +163,17 @@ class Context:
         return cls._cache[key]
 
 
+def host_register(a):
+    """bsm_host_register: page-locks a numpy vector used as x / y of host-memory products (DMA straight
+    from / to it).  Keep `a` alive until host_unregister(a)."""
+    L.check(L.lib().bsm_host_register(a.ctypes.data, a.nbytes))
+    return a
+
+
+def host_unregister(a):
+    L.check(L.lib().bsm_host_unregister(a.ctypes.data))
+
+
 def partition_rows(nrows, rowkeys, weights, nparts):
     """bsm_partition_rows: the row partition both multi-GPU layers use.  rowkeys[b] = smallest row
     index of block b (1-based), weights[b] = its stored entries.
@@ -133,7 +189,7 @@ def partition_rows(nrows, rowkeys, weights, nparts):
     return part[:nb], [(int(a), int(b)) for a, b in zip(lo, hi)]
 
 
-def _options(scheduler, device, accumulate, own=None, transpose_image=False, devices=None):
+def _options(scheduler, device, accumulate, own=None, transpose_image=False, devices=None, dev_blocks=False):
     o = L.BsmOptions()
     L.lib().bsm_options_default(C.byref(o))
     o.scheduler = L.BSM_SCHED_SERIAL if isserial(scheduler) else L.BSM_SCHED_DYNAMIC
@@ -148,6 +204,7 @@ def _options(scheduler, device, accumulate, own=None, transpose_image=False, dev
         if own is not None or transpose_image:
             raise ValueError("devices= does not combine with own= / transpose_image=")
         o.ctx = Context.get(devices).ptr
+    o.blocks_memspace = L.BSM_MEM_DEVICE if dev_blocks else L.BSM_MEM_HOST
     return o
 
 
@@ -349,8 +406,9 @@ class BlockSparseMatrix(AbstractBlockMatrix):
         if cols is not None:  # (blocks, rowindices, colindices, rows, cols) form, :81-89
             size = (size, cols)
         scheduler = SerialScheduler() if scheduler is None else scheduler
-        dt = _blocks_dtype(blocks)
-        self.blocks = _fblocks(blocks, dt)
+        devb = _is_dev(blocks)
+        dt = _dev_blocks(blocks) if devb else _blocks_dtype(blocks)
+        self.blocks = list(blocks) if devb else _fblocks(blocks, dt)
         self.rowindices = [_i64(r) for r in rowindices]
         self.colindices = [_i64(c) for c in colindices]
         nb = len(self.blocks)
@@ -361,9 +419,9 @@ class BlockSparseMatrix(AbstractBlockMatrix):
                 raise ValueError("block shape does not match its index lists")
         m = _i64([b.shape[0] for b in self.blocks])
         n = _i64([b.shape[1] for b in self.blocks])
-        ld = _i64([max(b.shape[0], 1) for b in self.blocks])
+        ld = _lds(self.blocks)
         dev = _default_device() if device is None else device
-        o = _options(scheduler, dev, accumulate, own, transpose_image, devices)
+        o = _options(scheduler, dev, accumulate, own, transpose_image, devices, devb)
         h = C.c_void_p()
         I = C.POINTER(C.c_int64)
         L.check(L.lib().bsm_blocksparse_create(
@@ -385,10 +443,11 @@ class SymmetricBlockMatrix(AbstractBlockMatrix):
             size = (size, cols)
             scheduler = SerialScheduler() if scheduler is None else scheduler
         scheduler = DynamicScheduler() if scheduler is None else scheduler
-        dt = _blocks_dtype(diagonals, offdiagonals)
-        self.diagonals = _fblocks(diagonals, dt)
+        devb = _is_dev(diagonals) or _is_dev(offdiagonals)
+        dt = _dev_blocks(diagonals, offdiagonals) if devb else _blocks_dtype(diagonals, offdiagonals)
+        self.diagonals = list(diagonals) if devb else _fblocks(diagonals, dt)
         self.diagonalindices = [_i64(d) for d in diagonalindices]
-        self.offdiagonals = _fblocks(offdiagonals, dt)
+        self.offdiagonals = list(offdiagonals) if devb else _fblocks(offdiagonals, dt)
         self.rowindices = [_i64(r) for r in rowindices]
         self.colindices = [_i64(c) for c in colindices]
         nd, no = len(self.diagonals), len(self.offdiagonals)
@@ -401,12 +460,12 @@ class SymmetricBlockMatrix(AbstractBlockMatrix):
             if b.shape != (len(r), len(c)):
                 raise ValueError("off-diagonal block shape does not match its index lists")
         ds = _i64([b.shape[0] for b in self.diagonals])
-        dld = _i64([max(b.shape[0], 1) for b in self.diagonals])
+        dld = _lds(self.diagonals)
         m = _i64([b.shape[0] for b in self.offdiagonals])
         n = _i64([b.shape[1] for b in self.offdiagonals])
-        ld = _i64([max(b.shape[0], 1) for b in self.offdiagonals])
+        ld = _lds(self.offdiagonals)
         dev = _default_device() if device is None else device
-        o = _options(scheduler, dev, accumulate, own, False, devices)
+        o = _options(scheduler, dev, accumulate, own, False, devices, devb)
         h = C.c_void_p()
         I = C.POINTER(C.c_int64)
         L.check(L.lib().bsm_symmetric_create(
@@ -439,14 +498,15 @@ class VariableBlockCompressedRowStorage(AbstractBlockMatrix):
             dt = s.dtype
             mats = list(s.diagonals) + list(s.offdiagonals) + [o.T for o in s.offdiagonals]  # views
             ds = _i64([b.shape[0] for b in s.diagonals])
-            dld = _i64([max(b.shape[0], 1) for b in s.diagonals])
+            dld = _lds(s.diagonals)
             d0 = _i64([int(d[0]) for d in s.diagonalindices])  # first(...), :231-239
             m = _i64([b.shape[0] for b in s.offdiagonals])
             n = _i64([b.shape[1] for b in s.offdiagonals])
-            ld = _i64([max(b.shape[0], 1) for b in s.offdiagonals])
+            ld = _lds(s.offdiagonals)
             r0 = _i64([int(r[0]) for r in s.rowindices])
             c0 = _i64([int(c[0]) for c in s.colindices])
-            o = _options(scheduler, dev, accumulate, own, False, devices)
+            o = _options(scheduler, dev, accumulate, own, False, devices,
+                         _is_dev(s.diagonals) or _is_dev(s.offdiagonals))
             L.check(L.lib().bsm_vbcrs_create_from_symmetric(
                 _DT[dt], int(s.size[0]), int(s.size[1]), len(s.diagonals), _ptrs(s.diagonals),
                 ds.ctypes.data_as(I), dld.ctypes.data_as(I), d0.ctypes.data_as(I), len(s.offdiagonals),
@@ -466,8 +526,8 @@ class VariableBlockCompressedRowStorage(AbstractBlockMatrix):
                 fb = b.blocks
                 m = _i64([k.shape[0] for k in fb])
                 n = _i64([k.shape[1] for k in fb])
-                ld = _i64([max(k.shape[0], 1) for k in fb])
-                o = _options(scheduler, dev, accumulate, own, transpose_image, devices)
+                ld = _lds(fb)
+                o = _options(scheduler, dev, accumulate, own, transpose_image, devices, _is_dev(fb))
                 L.check(L.lib().bsm_vbcrs_create_from_blocksparse(
                     _DT[dt], int(b.size[0]), int(b.size[1]), len(fb), _ptrs(fb), m.ctypes.data_as(I),
                     n.ctypes.data_as(I), ld.ctypes.data_as(I), _ptrs(b.rowindices), _ptrs(b.colindices),
@@ -489,15 +549,16 @@ class VariableBlockCompressedRowStorage(AbstractBlockMatrix):
             if mats is not None:
                 if len(mats) < 1:
                     raise IndexError("VariableBlockCompressedRowStorage needs at least one block")  # :81
-                dt = _blocks_dtype(mats)
-                fb = _fblocks(mats, dt)
+                devb = _is_dev(mats)
+                dt = _dev_blocks(mats) if devb else _blocks_dtype(mats)
+                fb = list(mats) if devb else _fblocks(mats, dt)
                 rs, cs = _i64(rowindices), _i64(colindices)
                 if len(rs) != len(fb) or len(cs) != len(fb):
                     raise ValueError("matrices, rowindices and colindices must have equal lengths")
                 m = _i64([b.shape[0] for b in fb])
                 n = _i64([b.shape[1] for b in fb])
-                ld = _i64([max(b.shape[0], 1) for b in fb])
-                o = _options(scheduler, dev, accumulate, own, transpose_image, devices)
+                ld = _lds(fb)
+                o = _options(scheduler, dev, accumulate, own, transpose_image, devices, devb)
                 L.check(L.lib().bsm_vbcrs_create(
                     _DT[dt], int(matrixsize[0]), int(matrixsize[1]), len(fb), _ptrs(fb),
                     m.ctypes.data_as(I), n.ctypes.data_as(I), ld.ctypes.data_as(I), rs.ctypes.data_as(I),
@@ -690,7 +751,7 @@ def _wrapblock(b, op):
     if op == L.BSM_OP_T:
         return b.T
     if op == L.BSM_OP_C:
-        return b.conj().T
+        return b.conj().T if not (torch is not None and isinstance(b, torch.Tensor)) else b.conj().t()
     return b
 
 
@@ -775,7 +836,7 @@ def rowcolvals(A):
         R, Cc = np.meshgrid(np.asarray(ri), np.asarray(ci), indexing="ij")
         rows.append(R.ravel())
         cols.append(Cc.ravel())
-        vals.append(np.asarray(b).ravel())
+        vals.append(_host(b).ravel())
 
     if isinstance(base, BlockSparseMatrix):
         for col in colors(A):
@@ -796,7 +857,7 @@ def rowcolvals(A):
             raise NotImplementedError("rowcolvals of a wrapped VBCRS (the reference has none either)")
         for br in range(len(base.rowptr) - 1):
             for bi in range(base.rowptr[br], base.rowptr[br + 1]):
-                b = base.blocks[bi - 1]
+                b = _host(base.blocks[bi - 1])
                 r0, c0 = base.rowindices[br], base.colindices[bi - 1]
                 R, Cc = np.meshgrid(np.arange(r0, r0 + b.shape[0]), np.arange(c0, c0 + b.shape[1]),
                                     indexing="ij")

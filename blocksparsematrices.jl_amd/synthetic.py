@@ -59,6 +59,61 @@ def _segments(seed, stream_off, total, lo, hi):
     return starts, sz
 
 
+# ---- generation in HBM (include/bsm_synth.h): same streams, bit-identical values --------------------
+def device_blocks(seed, ids, ms, ns, dtype=np.float64, symmetrise=None):
+    """Blocks `ids` of config stream `seed`, generated ON the current GPU: one flat allocation, one
+    kernel launch, returned as column-major torch CUDA views (m x n, stride (1, m)) -- what
+    block_values() yields, without the host ever holding the operator.  symmetrise[k] != 0 stores
+    (D + D^T) / 2 of the draw (the diagonal blocks of the symmetric configs)."""
+    import ctypes as C
+    import torch
+    from . import _lib as L
+    dtype = np.dtype(dtype)
+    tdt = {np.dtype(np.float32): torch.float32, np.dtype(np.float64): torch.float64}[dtype]
+    ids = np.ascontiguousarray(ids, dtype=np.int64)
+    ms = np.ascontiguousarray(ms, dtype=np.int64)
+    ns = np.ascontiguousarray(ns, dtype=np.int64)
+    cnt = ms * ns
+    # every block starts on a 16-byte boundary
+    al = 16 // dtype.itemsize
+    padded = (cnt + al - 1) // al * al
+    offs = np.concatenate([[0], np.cumsum(padded)])
+    flat = torch.empty(int(offs[-1]), dtype=tdt, device="cuda")
+    base = flat.data_ptr()
+    ptrs = (C.c_void_p * max(len(ids), 1))()
+    addr = base + offs[:-1] * dtype.itemsize
+    for k in range(len(ids)):
+        ptrs[k] = int(addr[k])
+    sym = None
+    if symmetrise is not None:
+        sym = np.ascontiguousarray(symmetrise, dtype=np.int32)
+    I = C.POINTER(C.c_int64)
+    L.check(L.lib().bsm_synth_blocks(
+        {np.dtype(np.float32): L.BSM_F32, np.dtype(np.float64): L.BSM_F64}[dtype], int(seed), len(ids),
+        ids.ctypes.data_as(I), ms.ctypes.data_as(I), ns.ctypes.data_as(I),
+        sym.ctypes.data_as(C.POINTER(C.c_int32)) if sym is not None else None, ptrs,
+        C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    out = []
+    for k in range(len(ids)):
+        m, n = int(ms[k]), int(ns[k])
+        out.append(flat[int(offs[k]):int(offs[k]) + m * n].view(n, m).t())
+    return out
+
+
+def device_vector(seed, n, dtype=np.float64, first=0):
+    """x[first : first + n] of config `seed`, generated on the current GPU (== vector(seed, ...)[first:first+n])."""
+    import ctypes as C
+    import torch
+    from . import _lib as L
+    dtype = np.dtype(dtype)
+    tdt = {np.dtype(np.float32): torch.float32, np.dtype(np.float64): torch.float64}[dtype]
+    out = torch.empty(int(n), dtype=tdt, device="cuda")
+    L.check(L.lib().bsm_synth_vector(
+        {np.dtype(np.float32): L.BSM_F32, np.dtype(np.float64): L.BSM_F64}[dtype], int(seed), int(first), int(n),
+        C.c_void_p(out.data_ptr()), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    return out
+
+
 def config1(n=1000, nblocks=50, bs=32, dtype=np.float64, seed=0xB5A1):
     """C1: BlockSparseMatrix n x n, nblocks blocks bs x bs; row and column lists are bs distinct
     indices drawn without replacement from 1:n, unsorted (partial Fisher-Yates on the stream)."""
@@ -81,7 +136,7 @@ def config1(n=1000, nblocks=50, bs=32, dtype=np.float64, seed=0xB5A1):
                 x=vector(seed, n, dtype))
 
 
-def config2(n=100_000, nblocks=5000, lo=8, hi=64, dtype=np.float64, seed=0xB5A2, part=None):
+def config2(n=100_000, nblocks=5000, lo=8, hi=64, dtype=np.float64, seed=0xB5A2, part=None, on_device=False):
     """C2: VBCRS n x n; rows and cols each cut into consecutive segments of size U{lo..hi};
     nblocks distinct (row-seg, col-seg) pairs drawn uniformly; block = seg-height x seg-width.
 
@@ -116,20 +171,27 @@ def config2(n=100_000, nblocks=5000, lo=8, hi=64, dtype=np.float64, seed=0xB5A2,
         seg_hi = int(np.searchsorted(rstart, (rank + 1) * n_per, side="left")) if rank + 1 < nparts else nr
         keep = [b for b, (i, _) in enumerate(pairs) if seg_lo <= i < seg_hi]
         own = (int(rstart[seg_lo]) + 1, int(rstart[seg_hi]) if seg_hi < nr else n)
-    blocks = [block_values(seed, b, int(rsz[pairs[b][0]]), int(csz[pairs[b][1]]), dtype) for b in keep]
+    if on_device:  # blocks and x generated in HBM (torch CUDA tensors), bit-identical values
+        blocks = device_blocks(seed, keep, [int(rsz[pairs[b][0]]) for b in keep],
+                               [int(csz[pairs[b][1]]) for b in keep], dtype)
+    else:
+        blocks = [block_values(seed, b, int(rsz[pairs[b][0]]), int(csz[pairs[b][1]]), dtype) for b in keep]
     rowstart = np.array([rstart[pairs[b][0]] + 1 for b in keep], dtype=np.int64)
     colstart = np.array([cstart[pairs[b][1]] + 1 for b in keep], dtype=np.int64)
     out = dict(kind="vbcrs", blocks=blocks, rowstart=rowstart, colstart=colstart, size=(n, n),
-               x=vector(seed, n, dtype))
+               x=device_vector(seed, n, dtype) if on_device else vector(seed, n, dtype))
     if own is not None:
         out["own"] = own
     return out
 
 
-def config3(nseg=3125, bs=64, halfband=8, dtype=np.float64, seed=0xB5A3):
+def config3(nseg=3125, bs=64, halfband=8, dtype=np.float64, seed=0xB5A3, on_device=False):
     """C3: SymmetricBlockMatrix (nseg*bs)^2; nseg diagonal bs x bs blocks symmetrised (D + D^T)/2;
     off-diagonal (I, J) for J = I-1 .. I-halfband; contiguous index lists."""
     n = nseg * bs
+    if on_device:
+        return _banded_symmetric_on_device(seed, np.arange(nseg, dtype=np.int64) * bs,
+                                           np.full(nseg, bs, dtype=np.int64), halfband, n, dtype)
     diag, didx, off, ridx, cidx = [], [], [], [], []
     b = 0
     for I in range(nseg):
@@ -150,7 +212,8 @@ def config3(nseg=3125, bs=64, halfband=8, dtype=np.float64, seed=0xB5A3):
                 rowindices=ridx, colindices=cidx, size=(n, n), x=vector(seed, n, dtype))
 
 
-def config4(ngrid=15625, bs=128, per_row=16, dtype=np.float32, seed=0xB5A4, row_lo=0, row_hi=None):
+def config4(ngrid=15625, bs=128, per_row=16, dtype=np.float32, seed=0xB5A4, row_lo=0, row_hi=None,
+            on_device=False):
     """C4: VBCRS (ngrid*bs)^2, bs x bs blocks, per_row distinct block columns per block row (one on
     the diagonal, the rest uniform).  row_lo/row_hi select a range of block rows (multi-GPU
     partition: every rank generates only its own rows, bit-identically)."""
@@ -167,16 +230,63 @@ def config4(ngrid=15625, bs=128, per_row=16, dtype=np.float32, seed=0xB5A4, row_
             if J not in colsI:
                 colsI.append(J)
         for t, J in enumerate(colsI):
-            blocks.append(block_values(seed, I * per_row + t, bs, bs, dtype))
+            blocks.append(I * per_row + t if on_device else block_values(seed, I * per_row + t, bs, bs, dtype))
             rowstart.append(I * bs + 1)
             colstart.append(J * bs + 1)
+    if on_device:
+        blocks = device_blocks(seed, blocks, [bs] * len(blocks), [bs] * len(blocks), dtype)
     return dict(kind="vbcrs", blocks=blocks, rowstart=np.array(rowstart, np.int64),
-                colstart=np.array(colstart, np.int64), size=(n, n), x=vector(seed, n, dtype))
+                colstart=np.array(colstart, np.int64), size=(n, n),
+                x=device_vector(seed, n, dtype) if on_device else vector(seed, n, dtype))
 
 
-def config5(n=5_000_000, lo=16, hi=256, halfband=4, dtype=np.float64, seed=0xB5A5):
-    """C5: SymmetricBlockMatrix n x n, segments U{lo..hi}, off-diagonal (I, J), J = I-1..I-halfband."""
+def _banded_symmetric_on_device(seed, start, sz, halfband, n, dtype, seg_lo=0, seg_hi=None):
+    """Diagonal segments [seg_lo, seg_hi) of a banded symmetric config with their off-diagonal blocks
+    (I, J), J = I-1 .. I-halfband, generated in HBM.  Block numbering as in config3 / config5: the
+    diagonal blocks are b = 0 .. nseg-1, the off-diagonal ones follow in (I, k) order."""
+    nseg = len(sz)
+    seg_hi = nseg if seg_hi is None else seg_hi
+    # number of off-diagonal blocks in front of segment I: sum_{i < I} min(i, halfband)
+    I = np.arange(nseg + 1, dtype=np.int64)
+    nbefore = np.where(I <= halfband, I * (I - 1) // 2, halfband * (halfband - 1) // 2 + (I - halfband) * halfband)
+    ids, ms, ns, sym = [], [], [], []
+    for i in range(seg_lo, seg_hi):
+        ids.append(i)
+        ms.append(int(sz[i]))
+        ns.append(int(sz[i]))
+        sym.append(1)
+    didx = [np.arange(start[i] + 1, start[i] + sz[i] + 1, dtype=np.int64) for i in range(seg_lo, seg_hi)]
+    ridx, cidx = [], []
+    for i in range(seg_lo, seg_hi):
+        for k in range(1, halfband + 1):
+            j = i - k
+            if j < 0:
+                continue
+            ids.append(int(nseg + nbefore[i] + (k - 1)))
+            ms.append(int(sz[i]))
+            ns.append(int(sz[j]))
+            sym.append(0)
+            ridx.append(didx[i - seg_lo])
+            cidx.append(np.arange(start[j] + 1, start[j] + sz[j] + 1, dtype=np.int64))
+    blocks = device_blocks(seed, ids, ms, ns, dtype, sym)
+    nd = seg_hi - seg_lo
+    return dict(kind="symmetric", diagonals=blocks[:nd], diagonalindices=didx, offdiagonals=blocks[nd:],
+                rowindices=ridx, colindices=cidx, size=(n, n), x=device_vector(seed, n, dtype))
+
+
+def config5_segments(n=5_000_000, lo=16, hi=256, seed=0xB5A5):
+    """(start, size) of C5's diagonal segments (0-based starts)."""
+    return _segments(seed, 0, n, lo, hi)
+
+
+def config5(n=5_000_000, lo=16, hi=256, halfband=4, dtype=np.float64, seed=0xB5A5, on_device=False,
+            seg_lo=0, seg_hi=None):
+    """C5: SymmetricBlockMatrix n x n, segments U{lo..hi}, off-diagonal (I, J), J = I-1..I-halfband.
+    on_device: blocks and x generated in HBM; seg_lo / seg_hi (on_device only) select a range of
+    diagonal segments with their off-diagonal blocks (one rank's share of a row partition)."""
     start, sz = _segments(seed, 0, n, lo, hi)
+    if on_device:
+        return _banded_symmetric_on_device(seed, start, sz, halfband, n, dtype, seg_lo, seg_hi)
     nseg = len(sz)
     diag, didx, off, ridx, cidx = [], [], [], [], []
     b = 0

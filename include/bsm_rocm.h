@@ -220,6 +220,15 @@ int bsm_symmetric_create(int dtype, int64_t nrows, int64_t ncols, int64_t ndiag,
 int bsm_mul(bsm_matrix_t A, int op, const void *x, void *y, const void *alpha,
             const void *beta, int beta_strong_zero, int memspace, void *stream);
 
+/* Page-locks a HOST vector the caller keeps using as x or y of BSM_MEM_HOST products (a Julia
+ * Vector{T} that lives through a solver loop): bsm_mul then moves it by DMA straight from / to the
+ * caller's memory instead of copying it through the library's pinned mirrors (C2-sized product:
+ * measured in DESIGN.md section 6).  The memory must stay allocated until bsm_host_unregister; the
+ * Julia binding registers in the constructor of its vector wrapper and unregisters in the finalizer.
+ * (hipHostRegister / hipHostUnregister, exported so that the host language needs no HIP binding.) */
+int bsm_host_register(void *ptr, int64_t bytes);
+int bsm_host_unregister(void *ptr);
+
 /* Y = alpha * op(A) * X + beta * Y for nrhs right-hand sides -- `A * X` / `mul!(Y, A, X, a, b)`
  * with matrices.  LinearMaps loops the columns of X through _unsafe_mul! (nrhs full sweeps of A);
  * here A is streamed ONCE per batch of up to 8 columns.  X is size(op(A),2) x nrhs and Y is

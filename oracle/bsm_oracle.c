@@ -205,3 +205,27 @@ int64_t orc_color_check(int64_t nblocks, const int64_t *const *idx, const int64_
     free(cnt);
     return bad;
 }
+
+/* ------------------------------------------------------------------------------------
+ * Timed loop for bench.py's `cpu_baseline` leg: `reps` forward VBCRS products (the 3-argument
+ * form, alpha = 1, strong-zero beta) on PRE-MARSHALLED arguments, timed here in C so that no
+ * Python / ctypes marshalling is inside the sample.  parallel != 0: the OpenMP variant (one task
+ * per block row == the reference's `@tasks for browidx`, src/vbcrs.jl:275-276).
+ * Returns the elapsed seconds.
+ * ---------------------------------------------------------------------------------- */
+#include <time.h>
+double orc_vbcrs_bench_f64(int64_t reps, int parallel, int64_t nrows_y, int64_t nblockrows,
+                           const int64_t *rowptr, const int64_t *colindices, const int64_t *rowindices,
+                           const double *const *blocks, const int64_t *m, const int64_t *n,
+                           const int64_t *ld, const double *x, double *y) {
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (int64_t r = 0; r < reps; r++) {
+        if (parallel)
+            orc_vbcrs_mul_par_f64(nrows_y, nblockrows, rowptr, colindices, rowindices, blocks, m, n, ld, x, y, 1.0, 0.0, 1);
+        else
+            orc_vbcrs_mul_f64(nrows_y, nblockrows, rowptr, colindices, rowindices, blocks, m, n, ld, x, y, 1.0, 0.0, 1);
+    }
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+}

@@ -28,6 +28,12 @@ def load_oracle(build=True):
     return Oracle(C.CDLL(path))
 
 
+def load_oracle_native():
+    """The -O3 -march=native build (cpu_baseline timing only; compiled on the machine it runs on)."""
+    subprocess.check_call(["make", "-s", "-C", _HERE, "_native/libbsm_oracle_native.so"])
+    return Oracle(C.CDLL(os.path.join(_HERE, "_native", "libbsm_oracle_native.so")))
+
+
 def _i64(a):
     return np.ascontiguousarray(a, dtype=np.int64)
 
@@ -205,6 +211,28 @@ class Oracle:
         fn.restype = None
         fn(*args)
         return y
+
+    def vbcrs_bench(self, blocks, rowptr, colindices, rowindices, x, y, seconds=10.0, parallel=False):
+        """Timed forward products (fp64, 3-argument form) with everything marshalled ONCE: the loop
+        and the clock live in C (orc_vbcrs_bench_f64).  Returns (reps, elapsed seconds)."""
+        dt = np.dtype(np.float64)
+        fb = _fblocks(blocks, dt)
+        m = _i64([b.shape[0] for b in fb])
+        n = _i64([b.shape[1] for b in fb])
+        ld = _i64([max(b.shape[0], 1) for b in fb])
+        rp, ci, ri = _i64(rowptr), _i64(colindices), _i64(rowindices)
+        x = np.ascontiguousarray(x, dt)
+        assert y.dtype == dt and y.flags.c_contiguous
+        fn = self.lib.orc_vbcrs_bench_f64
+        fn.restype = C.c_double
+        ptrs = _ptr_array(fb)
+        args = [C.c_int64(len(y)), C.c_int64(len(rp) - 1), rp.ctypes.data_as(_I64P), ci.ctypes.data_as(_I64P),
+                ri.ctypes.data_as(_I64P), ptrs, m.ctypes.data_as(_I64P), n.ctypes.data_as(_I64P),
+                ld.ctypes.data_as(_I64P), C.c_void_p(x.ctypes.data), C.c_void_p(y.ctypes.data)]
+        par = C.c_int(1 if parallel else 0)
+        t1 = fn(C.c_int64(3), par, *args) / 3  # calibrate
+        reps = max(3, int(seconds / max(t1, 1e-6)))
+        return reps, fn(C.c_int64(reps), par, *args)
 
     def coo_mul(self, rows, cols, vals, x, y, alpha=1, beta=0, strong_zero=True):
         dt = np.dtype(x.dtype)

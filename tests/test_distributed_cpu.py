@@ -45,6 +45,14 @@ def _worker(rank, world, port, kind, q):
             prob = bsm.synthetic.config2(n=5000, nblocks=300)
             local, own = D.split_vbcrs(prob, rank, world)
             touched = own
+        elif kind == "vbcrs_tiny":  # 2 block rows on 3 ranks: one rank owns nothing and creates no handle
+            rng = np.random.default_rng(1)
+            prob = dict(kind="vbcrs", blocks=[np.asfortranarray(rng.standard_normal((9, 12))),
+                                              np.asfortranarray(rng.standard_normal((7, 5)))],
+                        rowstart=np.array([4, 30]), colstart=np.array([2, 20]), size=(40, 40),
+                        x=rng.standard_normal(40))
+            local, own = D.split_vbcrs(prob, rank, world)
+            touched = own
         elif kind == "vbcrs_T_across":  # transposed product of a ROW-partitioned operator: reduce-scatter
             prob = bsm.synthetic.config2(n=5000, nblocks=300)
             local, own = D.split_vbcrs(prob, rank, world)
@@ -60,7 +68,8 @@ def _worker(rank, world, port, kind, q):
             prob = bsm.synthetic.config5(n=5000, lo=16, hi=96, halfband=3)
             local, own, touched = D.split_symmetric(prob, rank, world)
         # `own` = the rows this handle is responsible for scaling by beta (C ABI bsm_options.own_lo/hi)
-        A = bsm.synthetic.build(local, device=NODEV, **({"own": touched} if axis == 0 else {}))
+        A = None if D.is_empty(local) else \
+            bsm.synthetic.build(local, device=NODEV, **({"own": touched} if axis == 0 else {}))
         n = prob["size"][0]
         x = torch.from_numpy(prob["x"].copy())
         y0 = np.random.default_rng(7).standard_normal(n)
@@ -72,7 +81,7 @@ def _worker(rank, world, port, kind, q):
             out = interpret_image(A, lop, xx.numpy(), yy.numpy(), a, b, strong)
             if lop != N:
                 yy[:] = torch.from_numpy(out)  # transposed products scale the whole y
-            elif kind == "vbcrs":
+            elif kind in ("vbcrs", "vbcrs_tiny"):
                 lo, hi = own  # the handle only writes the rows it owns
                 yy[lo - 1:hi] = torch.from_numpy(out[lo - 1:hi])
             else:
@@ -82,14 +91,15 @@ def _worker(rank, world, port, kind, q):
 
         results = []
         for gather in (True, False):
-            P = D.RowPartitioned(A, own, touched, gather=gather, axis=axis)
+            P = D.RowPartitioned(A, own, touched, gather=gather, axis=axis, symmetric=(kind == "symmetric"))
             for alpha, beta in ((True, False), (0.5, -2.0)):
                 y = torch.from_numpy(y0.copy())
-                P.mul(y, x, alpha, beta, local_mul=local_mul, op=op)
+                P.mul(y, x, alpha, beta, local_mul=(local_mul if A is not None else None), op=op)
                 if not gather:  # only this rank's output range is final: keep it, take the rest from
                     lo, hi = own if (op == N) == (axis == 0) or kind == "symmetric" else P.out_range(n)
                     part = torch.zeros_like(y)
-                    part[lo - 1:hi] = y[lo - 1:hi]
+                    if hi >= lo:
+                        part[lo - 1:hi] = y[lo - 1:hi]
                     dist.all_reduce(part)  # test-side assembly of the slices
                     y = part
                 results.append(y.numpy().copy())
@@ -109,7 +119,8 @@ def _worker(rank, world, port, kind, q):
 
 
 @pytest.mark.parametrize("kind,world", [("vbcrs", 2), ("symmetric", 2), ("symmetric", 3), ("blocksparse", 2),
-                                        ("blocksparse", 3), ("vbcrs_T_across", 2), ("vbcrs_cols_T", 2)])
+                                        ("blocksparse", 3), ("vbcrs_T_across", 2), ("vbcrs_cols_T", 2),
+                                        ("vbcrs_tiny", 3)])
 def test_row_partitioned_over_gloo(kind, world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()

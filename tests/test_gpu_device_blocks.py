@@ -1,0 +1,144 @@
+"""GPU suite (-m gpu): operators whose blocks are DEVICE-resident at construction
+(bsm_options.blocks_memspace = BSM_MEM_DEVICE; SURVEY.md 8f2 "on-device construction"): the strip
+layout is written by pack_kernel, no matrix byte crosses PCIe.  Also the in-HBM generator of the
+synthetic configs (include/bsm_synth.h), which must reproduce the numpy streams bit for bit."""
+import numpy as np
+import pytest
+
+from _common import N, T, oracle_mul, rand_vec, relerr
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "GPU suite needs a GPU"
+    from bsm_amd import _lib as L
+    L.lib()
+    return torch
+
+
+def to_host(prob):
+    """host copy (numpy, column-major) of a problem generated in HBM"""
+    out = dict(prob)
+    for key in ("blocks", "diagonals", "offdiagonals"):
+        if key in prob:
+            out[key] = [np.asfortranarray(b.cpu().numpy()) for b in prob[key]]
+    out["x"] = prob["x"].cpu().numpy()
+    return out
+
+
+def dev_copy(torch, b):
+    """column-major CUDA copy of a numpy block"""
+    t = torch.from_numpy(np.ascontiguousarray(b.T)).cuda()  # (n, m) row-major == (m, n) column-major
+    return t.t()
+
+
+def test_generator_in_hbm_is_bit_identical_to_the_numpy_streams(torch_cuda, bsm):
+    S = bsm.synthetic
+    for dt in (np.float64, np.float32):
+        ids, ms, ns = [0, 7, 12345, 99], [5, 64, 17, 33], [9, 64, 17, 2]
+        sym = [0, 1, 1, 0]
+        got = S.device_blocks(0xB5A5, ids, ms, ns, dt, sym)
+        for b, m, n, s, g in zip(ids, ms, ns, sym, got):
+            ref = S.block_values(0xB5A5, b, m, n, dt)
+            if s:
+                ref = np.asfortranarray((ref + ref.T) / 2)
+            assert g.shape == (m, n) and np.array_equal(g.cpu().numpy(), ref)
+        assert np.array_equal(S.device_vector(0xB5A2, 1000, dt).cpu().numpy(), S.vector(0xB5A2, 1000, dt))
+        assert np.array_equal(S.device_vector(0xB5A2, 100, dt, first=900).cpu().numpy(), S.vector(0xB5A2, 1000, dt)[900:])
+    # whole configs: same structure, same values
+    for host, dev in ((S.config2(n=3000, nblocks=80), S.config2(n=3000, nblocks=80, on_device=True)),
+                      (S.config5(n=4000, lo=16, hi=80, halfband=3), S.config5(n=4000, lo=16, hi=80, halfband=3, on_device=True)),
+                      (S.config3(nseg=12, bs=16, halfband=3), S.config3(nseg=12, bs=16, halfband=3, on_device=True)),
+                      (S.config4(ngrid=12, bs=16, per_row=4), S.config4(ngrid=12, bs=16, per_row=4, on_device=True))):
+        h = to_host(dev)
+        for key in ("blocks", "diagonals", "offdiagonals"):
+            if key in host:
+                assert len(host[key]) == len(h[key])
+                assert all(np.array_equal(a, b) for a, b in zip(host[key], h[key])), key
+        for key in ("rowstart", "colstart"):
+            if key in host:
+                assert np.array_equal(host[key], dev[key])
+        for key in ("rowindices", "colindices", "diagonalindices"):
+            if key in host:
+                assert all(np.array_equal(a, b) for a, b in zip(host[key], dev[key]))
+        assert np.array_equal(host["x"], h["x"])
+
+
+def test_vbcrs_from_device_blocks_equals_host_construction(torch_cuda, bsm, oracle):
+    torch = torch_cuda
+    S = bsm.synthetic
+    for dt, tol in ((np.float64, 1e-12), (np.float32, 2e-5)):
+        dev = S.config2(n=12_000, nblocks=500, dtype=dt, on_device=True)
+        host = to_host(dev)
+        Ad = S.build(dev, transpose_image=True)
+        Ah = S.build(host, transpose_image=True)
+        assert Ad.stats() == Ah.stats()
+        assert np.array_equal(Ad.perm, Ah.perm) and np.array_equal(Ad.rowptr, Ah.rowptr)
+        x = dev["x"]
+        for op in (N, T):
+            Aop_d = Ad if op == N else bsm.transpose(Ad)
+            Aop_h = Ah if op == N else bsm.transpose(Ah)
+            yd, yh = torch.full_like(x, float("nan")), torch.full_like(x, float("nan"))
+            bsm.mul(yd, Aop_d, x)
+            bsm.mul(yh, Aop_h, x)
+            torch.cuda.synchronize()
+            assert torch.equal(yd, yh), "same packed image => bitwise the same product"
+            ref = oracle_mul(oracle, host, op, host["x"], np.zeros(len(host["x"]), dtype=dt))
+            assert relerr(yd.cpu().numpy(), ref) < tol
+
+
+def test_symmetric_and_indexed_blocksparse_from_device_blocks(torch_cuda, bsm, oracle):
+    torch = torch_cuda
+    S = bsm.synthetic
+    dev = S.config5(n=30_000, lo=16, hi=200, halfband=3, on_device=True)
+    host = to_host(dev)
+    A = S.build(dev)
+    x = dev["x"]
+    y = torch.zeros_like(x)
+    for op in (N, T):
+        bsm.mul(y, A if op == N else bsm.transpose(A), x, 0.5, False)
+        ref = oracle_mul(oracle, host, op, host["x"], np.zeros(len(host["x"])), 0.5, 0, True)
+        assert relerr(y.cpu().numpy(), ref) < 1e-12
+    assert bsm.nnz(A) == sum(b.size for b in host["diagonals"]) + 2 * sum(b.size for b in host["offdiagonals"])
+    # VBCRS view of the device-resident symmetric operator
+    V = bsm.VariableBlockCompressedRowStorage(A)
+    bsm.mul(y, V, x)
+    ref = oracle_mul(oracle, host, N, host["x"], np.zeros(len(host["x"])))
+    assert relerr(y.cpu().numpy(), ref) < 1e-12
+    # scattered, unsorted index lists (the packer's permuted placement) with blocks taller than 64 rows
+    rng = np.random.default_rng(11)
+    n = 900
+    blocks, rows, cols = [], [], []
+    for m, k in ((70, 33), (5, 130), (64, 64), (130, 7)):
+        blocks.append(np.asfortranarray(rng.standard_normal((m, k))))
+        rows.append(rng.permutation(n)[:m] + 1)
+        cols.append(rng.permutation(n)[:k] + 1)
+    ph = dict(kind="blocksparse", blocks=blocks, rowindices=rows, colindices=cols, size=(n, n))
+    pd = dict(ph, blocks=[dev_copy(torch, b) for b in blocks])
+    B = S.build(pd, transpose_image=True)
+    xh = rng.standard_normal(n)
+    for op in (N, T):
+        yh = np.zeros(n)
+        bsm.mul(yh, B if op == N else bsm.transpose(B), xh)
+        assert relerr(yh, oracle_mul(oracle, ph, op, xh, np.zeros(n))) < 1e-12
+    assert np.allclose(bsm.sparse(B).toarray(), bsm.sparse(S.build(ph)).toarray())
+
+
+def test_device_blocks_spread_over_a_context(torch_cuda, bsm, oracle):
+    S = bsm.synthetic
+    dev = S.config5(n=30_000, lo=16, hi=120, halfband=3, on_device=True)
+    host = to_host(dev)
+    A = S.build(dev, devices=[0, 0, 0])
+    x = dev["x"]
+    y = torch_cuda.zeros_like(x)
+    bsm.mul(y, A, x)
+    assert relerr(y.cpu().numpy(), oracle_mul(oracle, host, N, host["x"], np.zeros(len(host["x"])))) < 1e-12
+
+
+def test_device_blocks_need_a_device_handle(torch_cuda, bsm):
+    dev = bsm.synthetic.config2(n=2000, nblocks=30, on_device=True)
+    with pytest.raises(bsm._lib.BsmError, match="device"):
+        bsm.synthetic.build(dev, device=-2)

@@ -1,0 +1,113 @@
+"""GPU suite (-m gpu): the process-per-GPU layer (blocksparsematrices.jl_amd/distributed.py) with the
+REAL HIP local product.  world_size 2 (and 3) over `gloo`, every rank on cuda:0 (the GPU box has one
+MI355X; RCCL refuses two ranks on one device, the collectives' code path is the same): each rank
+creates its own single-device handle through the C ABI (own = the rows it touches, from
+bsm_partition_rows), multiplies on the GPU, exchanges the halo / reduce-scatters / all-gathers, and
+rank 0 compares the assembled result with the CPU oracle on the WHOLE operator."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, kind, q):
+    try:
+        sys.path.insert(0, ROOT)
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        import torch
+        import torch.distributed as dist
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        torch.cuda.set_device(0)
+        import bsm_amd as bsm
+        from bsm_amd import distributed as D
+        from _common import N, T, oracle_mul, relerr
+
+        op, axis = N, 0
+        if kind.startswith("vbcrs"):
+            prob = bsm.synthetic.config2(n=20_000, nblocks=900)
+            if kind == "vbcrs_tiny":  # 2 block rows on 3 ranks: one rank owns nothing
+                rng = np.random.default_rng(1)
+                prob = dict(kind="vbcrs", blocks=[np.asfortranarray(rng.standard_normal((9, 12))),
+                                                  np.asfortranarray(rng.standard_normal((7, 5)))],
+                            rowstart=np.array([4, 30]), colstart=np.array([2, 20]), size=(40, 40),
+                            x=rng.standard_normal(40))
+            local, own = D.split_vbcrs(prob, rank, world)
+            touched = own
+            if kind == "vbcrs_T":  # transposed product of a ROW-partitioned operator: reduce-scatter
+                op = T
+        elif kind == "blocksparse":
+            prob = bsm.synthetic.config1(n=3000, nblocks=120, bs=24)
+            local, own, touched = D.split_blocksparse(prob, rank, world)
+        else:
+            prob = bsm.synthetic.config5(n=60_000, lo=16, hi=128, halfband=3)
+            local, own, touched = D.split_symmetric(prob, rank, world)
+        A = D.build_local(local, touched)  # a real device handle (None for a rank without blocks)
+        assert (A is None) == D.is_empty(local)
+        n = prob["size"][0]
+        x = torch.from_numpy(prob["x"].copy()).cuda()
+        y0 = np.random.default_rng(7).standard_normal(n)
+        results = []
+        for gather in (True, False):
+            P = D.RowPartitioned(A, own, touched, gather=gather, axis=axis,
+                                 symmetric=(prob["kind"] == "symmetric"))
+            for alpha, beta in ((True, False), (0.5, -2.0)):
+                y = torch.from_numpy(y0.copy()).cuda()
+                P.mul(y, x, alpha, beta, op=op)
+                P.mul(y.copy_(torch.from_numpy(y0)), x, alpha, beta, op=op)  # again: cached plan / buffers
+                torch.cuda.synchronize()
+                y = y.cpu()
+                if not gather:  # only this rank's output range is final
+                    lo, hi = own if (op == N or prob["kind"] == "symmetric") else P.out_range(n)
+                    part = torch.zeros_like(y)
+                    if hi >= lo:
+                        part[lo - 1:hi] = y[lo - 1:hi]
+                    dist.all_reduce(part)  # test-side assembly of the slices
+                    y = part
+                results.append(y.numpy().copy())
+        if rank == 0:
+            from oracle import load_oracle
+            orc = load_oracle()
+            errs = []
+            for (alpha, beta), got in zip(((1, 0), (0.5, -2.0)) * 2, results):
+                ref = oracle_mul(orc, prob, op, prob["x"], y0, alpha, beta, strong=(beta == 0))
+                errs.append(relerr(got, ref))
+            q.put(("ok", errs))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:  # pragma: no cover
+        import traceback
+        q.put(("err", traceback.format_exc()))
+        raise
+
+
+@pytest.mark.parametrize("kind,world", [("vbcrs", 2), ("symmetric", 2), ("symmetric", 3), ("blocksparse", 2),
+                                        ("vbcrs_T", 2), ("vbcrs_tiny", 3)])
+def test_row_partitioned_with_the_hip_local_product(kind, world):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, kind, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    status, errs = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=120)
+    assert status == "ok", errs
+    assert all(e < 1e-12 for e in errs), errs
+    assert all(p.exitcode == 0 for p in procs)
