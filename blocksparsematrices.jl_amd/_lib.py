@@ -49,7 +49,7 @@ _lib = None
 # every symbol include/bsm_rocm.h declares
 EXPORTS = ["bsm_options_default", "bsm_vbcrs_create", "bsm_vbcrs_create_from_symmetric",
            "bsm_vbcrs_create_from_blocksparse", "bsm_ctx_create", "bsm_ctx_destroy", "bsm_ctx_devices",
-           "bsm_partition_rows", "bsm_part_info", "bsm_host_register", "bsm_host_unregister",
+           "bsm_partition_rows", "bsm_part_info", "bsm_host_register", "bsm_host_unregister", "bsm_rowcolvals",
            "bsm_blocksparse_create",
            "bsm_symmetric_create", "bsm_mul", "bsm_mul_multi", "bsm_get_bookkeeping", "bsm_get_image", "bsm_stats",
            "bsm_color", "bsm_destroy", "bsm_last_error", "bsm_version"]
@@ -108,6 +108,8 @@ def lib():
     for name in ("bsm_vbcrs_create_from_blocksparse", "bsm_ctx_create", "bsm_ctx_destroy", "bsm_ctx_devices",
                  "bsm_partition_rows", "bsm_part_info"):
         getattr(L, name).restype = C.c_int
+    L.bsm_rowcolvals.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, _I64P, C.c_int, C.c_void_p]
+    L.bsm_rowcolvals.restype = C.c_int
     L.bsm_host_register.argtypes = [C.c_void_p, C.c_int64]
     L.bsm_host_unregister.argtypes = [C.c_void_p]
     L.bsm_host_register.restype = L.bsm_host_unregister.restype = C.c_int

@@ -29,8 +29,6 @@ Tunables Tunables::from_env() {
     t.lds_window = (int)geti("BSM_WINDOW", t.lds_window);
     t.deep_group_bytes = geti("BSM_DEEP_GROUP_BYTES", t.deep_group_bytes);
     t.deep_total_bytes = geti("BSM_DEEP_TOTAL_BYTES", t.deep_total_bytes);
-    t.split_mode = (int)geti("BSM_SPLIT_MODE", t.split_mode);
-    t.split_min_strips = geti("BSM_SPLIT_MIN_STRIPS", t.split_min_strips);
     t.chunk_rows = (int)geti("BSM_CHUNK_ROWS", t.chunk_rows);
     if (t.chunk_rows != 8 && t.chunk_rows != 16 && t.chunk_rows != 32) t.chunk_rows = kMaxRowsPerChunk;
     t.window_bytes = (size_t)geti("BSM_UPLOAD_WINDOW_BYTES", (int64_t)t.window_bytes);
@@ -672,27 +670,6 @@ std::string Analysis::build(int mtype_, int dtype_, int64_t nrows_, int64_t ncol
             it.s_end = std::min(G.strips, s + per_item);
             it.bytes = (it.s_end - it.s_begin) * strip_bytes;
             it.nw = it.bytes >= tun.split4_bytes ? 4 : (it.bytes >= tun.split2_bytes ? 2 : 1);
-            if (tun.split_mode == 1) {
-                // fewest dependent iterations per wave: an iteration covers G*L strips (L = 8 loads per
-                // lane, G = 64/P strips per load); take the smallest wave count that reaches the
-                // minimum, but never split below `split_min_strips` strips per wave
-                int P = 8;
-                while (P < G.mc) P <<= 1;
-                const int64_t per_iter = (64 / P) * 8;
-                const int64_t S = it.s_end - it.s_begin;
-                int best = 1;
-                int64_t best_it = (S + per_iter - 1) / per_iter;
-                for (int nw : {2, 4}) {
-                    const int64_t per_wave = (S + nw - 1) / nw;
-                    if (per_wave < tun.split_min_strips) break;
-                    const int64_t iters = (per_wave + per_iter - 1) / per_iter;
-                    if (iters < best_it) {
-                        best_it = iters;
-                        best = nw;
-                    }
-                }
-                it.nw = best;
-            }
             it.color = group_color[g];
             items.push_back(it);
         }
@@ -796,77 +773,22 @@ std::string Analysis::build(int mtype_, int dtype_, int64_t nrows_, int64_t ncol
     }
     while (waves.size() % kWavesPerWg) emit_nop();
     nwg_main = (int64_t)waves.size() / kWavesPerWg;
-    // dispatch order: largest first; for exclusive forward images ("auto") every other block of 256
-    // workgroups (one per CU) is reversed, so that the same CUs do not receive the larger workgroup
-    // of every layer (C2-sized operators: +2.5 %; neutral on long launches)
-    const int wg_order = tun.wg_order >= 0 ? tun.wg_order : (exclusive_fwd ? 102 : 0);
-    if (!colored && wg_order != 0 && nwg_main > 2) {
+    // dispatch order: largest first; for exclusive forward images every other block of 256 workgroups
+    // (one per CU) is reversed, so that the same CUs do not receive the larger workgroup of every
+    // layer (C2-sized operators: +2.5 %; neutral on long launches).  BSM_ORDER=0 keeps plain
+    // largest-first.
+    const bool snake = tun.wg_order != 0 && exclusive_fwd;
+    if (!colored && snake && nwg_main > 2) {
         std::vector<WaveWork> re(waves.size());
-        std::vector<int64_t> ord;
-        if (wg_order == 1) {  // big, small, big, small ...
-            for (int64_t a = 0, b = nwg_main - 1; a <= b; a++, b--) {
-                ord.push_back(a);
-                if (b != a) ord.push_back(b);
+        const int64_t blk = 256;
+        int64_t k = 0;
+        for (int64_t a0 = 0; a0 < nwg_main; a0 += blk) {
+            const int64_t a1 = std::min(nwg_main, a0 + blk);
+            for (int64_t j = 0; j < a1 - a0; j++, k++) {
+                const int64_t src = ((a0 / blk) & 1) ? a1 - 1 - j : a0 + j;
+                for (int w = 0; w < kWavesPerWg; w++) re[k * kWavesPerWg + w] = waves[src * kWavesPerWg + w];
             }
-        } else if (wg_order == 2) {  // smallest first
-            for (int64_t a = nwg_main - 1; a >= 0; a--) ord.push_back(a);
-        } else if (wg_order == 3) {  // sawtooth: 8 size-sorted passes
-            for (int64_t r = 0; r < 8; r++)
-                for (int64_t a = r; a < nwg_main; a += 8) ord.push_back(a);
-        } else if (wg_order == 4) {  // deterministic pseudo-random shuffle
-            ord.resize(nwg_main);
-            std::iota(ord.begin(), ord.end(), (int64_t)0);
-            uint64_t st = 0x9E3779B97F4A7C15ull;
-            for (int64_t a = nwg_main - 1; a > 0; a--) {
-                st ^= st << 13;
-                st ^= st >> 7;
-                st ^= st << 17;
-                std::swap(ord[a], ord[(int64_t)(st % (uint64_t)(a + 1))]);
-            }
-        } else if (wg_order >= 101 && wg_order <= 105) {
-            // snake: largest first, but every other block of 8 (XCDs) / 256 (CUs) / 32 reversed, so
-            // that the same XCD / CU does not receive the larger workgroup of every layer
-            static const int64_t kBlk[5] = {8, 256, 32, 128, 512};
-            const int64_t blk = kBlk[wg_order - 101];
-            for (int64_t a0 = 0; a0 < nwg_main; a0 += blk) {
-                const int64_t a1 = std::min(nwg_main, a0 + blk);
-                if ((a0 / blk) & 1)
-                    for (int64_t a = a1 - 1; a >= a0; a--) ord.push_back(a);
-                else
-                    for (int64_t a = a0; a < a1; a++) ord.push_back(a);
-            }
-        } else if (wg_order == 110 || wg_order == 111) {
-            // layered LPT: the k-th largest workgroup of a layer of NB goes to the k-th least loaded
-            // bin (bin = position inside the layer: the hardware deals workgroups round-robin)
-            const int64_t NB = wg_order == 110 ? 256 : 8;
-            std::vector<int64_t> wgbytes(nwg_main, 0);
-            for (int64_t k = 0; k < nwg_main; k++)
-                for (int w = 0; w < kWavesPerWg; w++) {
-                    const WaveWork &W = waves[k * kWavesPerWg + w];
-                    if (W.work == WORK_PANEL && W.npieces > 0) wgbytes[k] += (int64_t)W.first.nstrips * W.m * 16;
-                }
-            std::vector<int64_t> load(NB, 0), bins(NB);
-            ord.assign(nwg_main, -1);
-            for (int64_t a0 = 0; a0 < nwg_main; a0 += NB) {
-                const int64_t cnt = std::min(NB, nwg_main - a0);
-                std::iota(bins.begin(), bins.end(), (int64_t)0);
-                std::stable_sort(bins.begin(), bins.end(), [&](int64_t x, int64_t y) { return load[x] < load[y]; });
-                if (cnt < NB) {  // last, partial layer: keep positions dense
-                    for (int64_t k = 0; k < cnt; k++) ord[a0 + k] = a0 + k;
-                    break;
-                }
-                for (int64_t k = 0; k < cnt; k++) {
-                    ord[a0 + bins[k]] = a0 + k;
-                    load[bins[k]] += wgbytes[a0 + k];
-                }
-            }
-        } else {  // >= 5: sawtooth with wg_order passes
-            const int64_t np = wg_order;
-            for (int64_t r = 0; r < np; r++)
-                for (int64_t a = r; a < nwg_main; a += np) ord.push_back(a);
         }
-        for (int64_t k = 0; k < nwg_main; k++)
-            for (int w = 0; w < kWavesPerWg; w++) re[k * kWavesPerWg + w] = waves[ord[k] * kWavesPerWg + w];
         waves.swap(re);
     }
     if (colored) {

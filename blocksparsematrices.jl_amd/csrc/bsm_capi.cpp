@@ -116,6 +116,7 @@ int read_options(const bsm_options *opts, bsm_options &o) {
         return fail(BSM_ERR_INVALID, "unknown accumulate mode");
     if (o.own_lo < 0 || o.own_hi < 0 || (o.own_hi > 0 && o.own_hi < o.own_lo))
         return fail(BSM_ERR_INVALID, "bad own_lo/own_hi");
+    if (o.transpose_image < 0 || o.transpose_image > 2) return fail(BSM_ERR_INVALID, "bad transpose_image");
     if (o.blocks_memspace != BSM_MEM_HOST && o.blocks_memspace != BSM_MEM_DEVICE)
         return fail(BSM_ERR_INVALID, "bad blocks_memspace");
     return BSM_OK;
@@ -422,7 +423,15 @@ int create_handle(int mtype, int dtype, int64_t nrows, int64_t ncols, const std:
     if (devblocks && cx.dev == BSM_DEVICE_NONE)
         return fail(BSM_ERR_INVALID, "device-resident blocks need a device handle");
     std::string err = A->an.build(mtype, dtype, nrows, ncols, in, to_aopt(o, devblocks ? nullptr : cx.values()));
-    if (err.empty() && o.transpose_image && mtype != MT_SYMMETRIC) {
+    bool want_t = o.transpose_image == 1;
+    if (o.transpose_image == 2 && cx.dev != BSM_DEVICE_NONE) {  // "when it is cheap"
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
+            want_t = (size_t)A->an.value_bytes <= free_b / 16;
+        else
+            (void)hipGetLastError();
+    }
+    if (err.empty() && want_t && mtype != MT_SYMMETRIC) {
         bool plain = true;
         for (const BlockIn &B : in) plain &= (B.kind == KIND_PLAIN);
         if (plain) err = build_transpose_image(A, in, o, devblocks ? nullptr : cx.values_t());
@@ -721,6 +730,103 @@ extern "C" int bsm_partition_rows(int64_t nrows, int64_t nblocks, const int64_t 
             own_lo[p] = lo[p];
             own_hi[p] = hi[p];
         }
+        return BSM_OK;)
+}
+
+namespace {
+// triples of one packed image -> device buffers of its device (orow / ocol int64, oval element type)
+int export_image(const Analysis &an, const DeviceImage &img, void *orow, void *ocol, void *oval, hipStream_t st) {
+    const long long nw = (long long)an.waves.size();
+    std::vector<long long> off((size_t)nw + 1, 0);
+    for (long long w = 0; w < nw; w++) {
+        const WaveWork &W = an.waves[w];
+        long long cnt = 0;
+        if (W.work == WORK_PANEL && W.npieces > 0) {
+            const Piece &P = W.first;
+            long long noff = 0;
+            if (P.xbase < 0) {
+                if ((P.kind & 3) == KIND_OFF)
+                    for (int32_t k = 0; k < P.ncols; k++) noff += an.cols[(size_t)P.col_off + k] >= 0;
+            } else {
+                const long long w1 = std::min<long long>(W.seg1_w, P.ncols), w2 = std::min<long long>(W.seg2_w, P.ncols);
+                if ((P.kind & 3) == KIND_OFF) noff += w1;
+                if (((P.kind >> 2) & 3) == KIND_OFF) noff += std::max<long long>(0, w2 - w1);
+                if (((P.kind >> 4) & 3) == KIND_OFF) noff += std::max<long long>(0, P.ncols - w2);
+            }
+            cnt = (long long)W.m * (P.ncols + noff);
+        }
+        off[w + 1] = off[w] + cnt;
+    }
+    if (off[nw] != an.nnz) return fail(BSM_ERR_DEVICE, "rowcolvals: image / nnz mismatch");
+    if (nw == 0 || an.nnz == 0) return BSM_OK;
+    void *d_off = nullptr;
+    hipError_t e = hipMalloc(&d_off, off.size() * sizeof(long long));
+    if (e == hipSuccess) e = hipMemcpyAsync(d_off, off.data(), off.size() * sizeof(long long), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess)
+        e = launch_export_coo(an.dtype, img.d_waves, nw, d_off, img.d_values, img.d_rows, img.d_cols, orow, ocol, oval, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (d_off) (void)hipFree(d_off);
+    if (e != hipSuccess) return hip_fail(e, "rowcolvals");
+    return BSM_OK;
+}
+}  // namespace
+
+extern "C" int bsm_rowcolvals(bsm_matrix_t A, int64_t *rows, int64_t *cols, void *vals, int64_t *count,
+                              int memspace, void *stream) {
+    BSM_GUARDED(
+        if (!A || !count) return fail(BSM_ERR_INVALID, "null argument");
+        if (!rows || !cols || !vals) {
+            *count = A->an.nnz;
+            return BSM_OK;
+        }
+        if (*count < A->an.nnz) return fail(BSM_ERR_INVALID, "output buffers too small");
+        if (!A->on_device) return fail(BSM_ERR_DEVICE, "handle has no device image (created with BSM_DEVICE_NONE)");
+        if (memspace != BSM_MEM_HOST && memspace != BSM_MEM_DEVICE) return fail(BSM_ERR_INVALID, "bad memspace");
+        const size_t es = (size_t)A->an.es;
+        // one image per device part (a single one for ordinary handles); parts are written one after another
+        std::vector<std::pair<const Analysis *, const DeviceImage *>> imgs;
+        if (A->dist)
+            dist_images(A, imgs);
+        else
+            imgs.emplace_back(&A->an, &A->img);
+        int64_t done = 0;
+        for (auto &pi : imgs) {
+            const Analysis &an = *pi.first;
+            const DeviceImage &img = *pi.second;
+            const int64_t n = an.nnz;
+            if (n == 0) continue;
+            DeviceGuard g;
+            hipError_t e = g.enter(img.device);
+            if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
+            // staged through buffers on the image's device unless the caller's arrays already live there
+            bool direct = false;
+            if (memspace == BSM_MEM_DEVICE && !A->dist) direct = true;
+            void *r = nullptr; void *c = nullptr; void *v = nullptr;
+            if (direct) {
+                r = rows + done;
+                c = cols + done;
+                v = (char *)vals + (size_t)done * es;
+            } else {
+                e = hipMalloc(&r, (size_t)n * 8);
+                if (e == hipSuccess) e = hipMalloc(&c, (size_t)n * 8);
+                if (e == hipSuccess) e = hipMalloc(&v, (size_t)n * es);
+                if (e != hipSuccess) {
+                    for (void *q : {r, c, v}) if (q) (void)hipFree(q);
+                    return hip_fail(e, "rowcolvals staging");
+                }
+            }
+            int rc = export_image(an, img, r, c, v, direct ? (hipStream_t)stream : nullptr);
+            if (rc == BSM_OK && !direct) {
+                e = hipMemcpy(rows + done, r, (size_t)n * 8, hipMemcpyDefault);
+                if (e == hipSuccess) e = hipMemcpy(cols + done, c, (size_t)n * 8, hipMemcpyDefault);
+                if (e == hipSuccess) e = hipMemcpy((char *)vals + (size_t)done * es, v, (size_t)n * es, hipMemcpyDefault);
+                if (e != hipSuccess) rc = hip_fail(e, "rowcolvals copy");
+            }
+            if (!direct) for (void *q : {r, c, v}) (void)hipFree(q);
+            if (rc != BSM_OK) return rc;
+            done += n;
+        }
+        *count = done;
         return BSM_OK;)
 }
 

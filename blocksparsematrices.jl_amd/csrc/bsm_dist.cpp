@@ -521,6 +521,11 @@ int dist_part_info(bsm_matrix_s *A, int32_t part, bsm_part_info_t *out) {
     return BSM_OK;
 }
 
+void dist_images(bsm_matrix_s *A, std::vector<std::pair<const Analysis *, const DeviceImage *>> &out) {
+    for (const auto &p : A->dist->parts)
+        if (p->has_image) out.emplace_back(&p->an, &p->img);
+}
+
 int64_t dist_device_bytes(const bsm_matrix_s *A) {
     int64_t s = 0;
     for (const auto &p : A->dist->parts) s += p->img.device_bytes;

@@ -75,6 +75,8 @@ int dist_mul(bsm_matrix_s *A, int op, const void *x, void *y, const void *alpha,
 void dist_destroy(bsm_matrix_s *A);
 int dist_part_info(bsm_matrix_s *A, int32_t part, bsm_part_info_t *out);
 int64_t dist_device_bytes(const bsm_matrix_s *A);
+// (analysis, image) of every part that holds blocks
+void dist_images(bsm_matrix_s *A, std::vector<std::pair<const Analysis *, const DeviceImage *>> &out);
 
 // smallest row index of every block (its partition key) and its weight (stored entries)
 void block_row_keys(const std::vector<BlockIn> &in, std::vector<int64_t> &key, std::vector<int64_t> &weight);

@@ -46,6 +46,13 @@ hipError_t launch_mul_multi(const DeviceImage &img, bool opT, bool conj, long lo
                             long long ldx, void *y, long long ldy, const void *alpha, const void *beta,
                             int strong_zero, hipStream_t stream);
 
+// rowcolvals(A): COO triples (1-based int64 rows / cols, values of the image's element type) written from
+// the packed device image; d_out_off[w] = first output slot of wave descriptor w (host prefix sum of
+// m * ncols + m * #KIND_OFF columns)
+hipError_t launch_export_coo(int dtype, const void *d_waves, long long nwaves, const void *d_out_off,
+                             const void *d_values, const void *d_rows, const void *d_cols, void *orow, void *ocol,
+                             void *oval, hipStream_t stream);
+
 // executes Analysis::pack_plan on the device (blocks already in HBM): d_plan = PackChunk[nchunks],
 // d_colpos = int32 placements (may be null when no chunk is scattered), es = element bytes
 hipError_t launch_pack(int es, const void *d_plan, long long nchunks, const void *d_colpos, void *d_values,

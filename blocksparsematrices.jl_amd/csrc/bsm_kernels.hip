@@ -1107,6 +1107,94 @@ hipError_t launch_vec_axpby(int dtype, void *y, const void *r, long long n, cons
 }
 
 // ========================================================================================
+// rowcolvals(A) from the packed image (reference src/sparse.jl:17-123): every stored entry leaves as
+// a COO triple (1-based), the off-diagonal columns of a symmetric operator a second time transposed.
+// One wave per WaveWork descriptor; its output offset was summed up on the host (no atomics, the
+// order of the triples is fixed).  HBM-bound, one-off.
+// ========================================================================================
+template <typename T>
+__global__ void __launch_bounds__(256) export_coo_kernel(const WaveWork *__restrict__ waves, long long nwaves,
+                                                         const long long *__restrict__ out_off,
+                                                         const uint4 *__restrict__ values, const int *__restrict__ rows,
+                                                         const int *__restrict__ cols, long long *__restrict__ orow,
+                                                         long long *__restrict__ ocol, T *__restrict__ oval) {
+    constexpr int E = TT<T>::E;
+    const long long wv = (long long)blockIdx.x * kWavesPerWg + (threadIdx.x >> 6);
+    if (wv >= nwaves) return;
+    const int lane = threadIdx.x & 63;
+    const WaveD wd = load_wave(waves + wv);
+    if (wd.work != WORK_PANEL || wd.npieces == 0) return;
+    const PieceD pc = wd.first;
+    const int m = wd.m, ncols = pc.ncols, kinds = pc.kind;
+    const T *__restrict__ vb = reinterpret_cast<const T *>(values + (((uint64_t)pc.val_hi << 32) | pc.val_lo));
+    const int s1w = wd.seg1_w, s1x = wd.seg1_x - wd.seg1_w;
+    const int s2w = wd.seg2_w, s2x = pc.seg2_x - wd.seg2_w;
+    const long long base = out_off[wv];
+    const long long tbase = base + (long long)m * ncols;  // transposed copies follow the forward triples
+    // t-th KIND_OFF column of the piece gets the t-th transposed slot: count them in order per lane
+    // group is not needed -- the host laid the transposed region out per column index w as well, with
+    // holes squeezed out by its own prefix; here the prefix over columns is recomputed by lane 0..63
+    // cooperatively in chunks of 64 columns
+    int toff = 0;  // number of KIND_OFF columns in front of the current chunk
+    for (int w0 = 0; w0 < ncols; w0 += 64) {
+        const int w = w0 + lane;
+        bool off = false;
+        int ci = 0;
+        if (w < ncols) {
+            if (pc.xbase < 0) {
+                const int raw = cols[pc.col_off + w];
+                off = raw >= 0 && (kinds & 3) == KIND_OFF;
+                ci = raw & 0x7fffffff;
+            } else {
+                const int sh = w < s1w ? 0 : (w < s2w ? 2 : 4);
+                off = ((kinds >> sh) & 3) == KIND_OFF;
+                ci = w + (w < s1w ? pc.xbase : (w < s2w ? s1x : s2x));
+            }
+        }
+        const unsigned long long mask = __ballot(off);
+        const int rank = __popcll(mask & ((1ull << lane) - 1ull));
+        if (w < ncols) {
+            const int s = w / E, e = w % E;
+            for (int i = 0; i < m; ++i) {
+                const int ri = (wd.rbase >= 0) ? wd.rbase + i : rows[wd.row_off + i];
+                const T v = vb[((long long)s * m + i) * E + e];
+                const long long o = base + (long long)w * m + i;
+                orow[o] = ri + 1;
+                ocol[o] = ci + 1;
+                oval[o] = v;
+                if (off) {
+                    const long long t = tbase + (long long)(toff + rank) * m + i;
+                    orow[t] = ci + 1;
+                    ocol[t] = ri + 1;
+                    oval[t] = v;
+                }
+            }
+        }
+        toff += __popcll(mask);
+    }
+}
+
+hipError_t launch_export_coo(int dtype, const void *d_waves, long long nwaves, const void *d_out_off,
+                             const void *d_values, const void *d_rows, const void *d_cols, void *orow, void *ocol,
+                             void *oval, hipStream_t stream) {
+    if (nwaves <= 0) return hipSuccess;
+    const dim3 grid((unsigned)((nwaves + kWavesPerWg - 1) / kWavesPerWg)), block(256);
+#define BSM_EXPORT(T)                                                                                             \
+    hipLaunchKernelGGL((export_coo_kernel<T>), grid, block, 0, stream, (const WaveWork *)d_waves, nwaves,         \
+                       (const long long *)d_out_off, (const uint4 *)d_values, (const int *)d_rows,                \
+                       (const int *)d_cols, (long long *)orow, (long long *)ocol, (T *)oval)
+    switch (dtype) {
+        case 0: BSM_EXPORT(float); break;
+        case 1: BSM_EXPORT(double); break;
+        case 2: BSM_EXPORT(c64); break;
+        case 3: BSM_EXPORT(c128); break;
+        default: return hipErrorInvalidValue;
+    }
+#undef BSM_EXPORT
+    return hipGetLastError();
+}
+
+// ========================================================================================
 // device-side repacking (bsm_options.blocks_memspace = BSM_MEM_DEVICE): the caller's blocks already
 // live in HBM (e.g. ROCArrays), so the strip layout is written by a kernel instead of the host
 // packer -- no matrix byte crosses PCIe.  One workgroup per chunk (<= 64 rows of one block);

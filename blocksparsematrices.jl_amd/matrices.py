@@ -36,7 +36,7 @@ __all__ = [
     "rowindices", "colindices", "colors", "transposecolors", "diagonal", "offdiagonal",
     "eachdiagonalindex", "eachoffdiagonalindex", "diagonalindices", "diagonalcolors",
     "offdiagonalcolors", "transposeoffdiagonalcolors", "rowcolvals", "sparse", "ColorInfo", "conflicts",
-    "color", "coloringalgorithm", "Context", "partition_rows", "host_register", "host_unregister",
+    "color", "coloringalgorithm", "Context", "partition_rows", "host_register", "host_unregister", "rowcolvals_device", "sparse_device",
 ]
 
 _DT = {np.dtype(np.float32): L.BSM_F32, np.dtype(np.float64): L.BSM_F64,
@@ -199,7 +199,7 @@ def _options(scheduler, device, accumulate, own=None, transpose_image=False, dev
                     "direct": L.BSM_ACC_DIRECT}[accumulate]
     if own is not None:
         o.own_lo, o.own_hi = int(own[0]), int(own[1])
-    o.transpose_image = 1 if transpose_image else 0
+    o.transpose_image = 2 if transpose_image == "auto" else (1 if transpose_image else 0)
     if devices is not None:
         if own is not None or transpose_image:
             raise ValueError("devices= does not combine with own= / transpose_image=")
@@ -870,6 +870,52 @@ def rowcolvals(A):
         z = np.zeros(0, np.int64)
         return z, z, np.zeros(0, base.dtype)
     return np.concatenate(rows), np.concatenate(cols), np.concatenate(vals)
+
+
+def rowcolvals_device(A, device=True):
+    """bsm_rowcolvals: (rows, cols, vals), 1-based, written by a kernel from the packed DEVICE image
+    (no block returns to the host).  device=True: torch CUDA tensors on the handle's device (multi-
+    device handles: numpy arrays); False: numpy arrays.  Wrapped matrices: rows / cols swapped, values
+    conjugated for the adjoint."""
+    base, op = _unwrap(A)
+    n = C.c_int64(0)
+    L.check(L.lib().bsm_rowcolvals(base._h.ptr, None, None, None, C.byref(n), L.BSM_MEM_HOST, None))
+    cnt = n.value
+    dt = base.dtype
+    if device and base.devices is None and torch is not None:
+        tdt = {v: k for k, v in _TORCH_DT.items()}[dt]
+        dev = torch.device("cuda", base.device)
+        r = torch.empty(max(cnt, 1), dtype=torch.int64, device=dev)
+        c = torch.empty(max(cnt, 1), dtype=torch.int64, device=dev)
+        v = torch.empty(max(cnt, 1), dtype=tdt, device=dev)
+        L.check(L.lib().bsm_rowcolvals(base._h.ptr, r.data_ptr(), c.data_ptr(), v.data_ptr(), C.byref(n),
+                                       L.BSM_MEM_DEVICE, torch.cuda.current_stream(dev).cuda_stream))
+        r, c, v = r[:cnt], c[:cnt], v[:cnt]
+        if op != L.BSM_OP_N:
+            r, c = c, r
+            if op == L.BSM_OP_C:
+                v = v.conj()
+        return r, c, v
+    r = np.zeros(max(cnt, 1), dtype=np.int64)
+    c = np.zeros(max(cnt, 1), dtype=np.int64)
+    v = np.zeros(max(cnt, 1), dtype=dt)
+    L.check(L.lib().bsm_rowcolvals(base._h.ptr, r.ctypes.data, c.ctypes.data, v.ctypes.data, C.byref(n),
+                                   L.BSM_MEM_HOST, None))
+    r, c, v = r[:cnt], c[:cnt], v[:cnt]
+    if op != L.BSM_OP_N:
+        r, c = c, r
+        if op == L.BSM_OP_C:
+            v = v.conj()
+    return r, c, v
+
+
+def sparse_device(A):
+    """sparse(A) assembled ON the GPU: COO triples from the packed image (bsm_rowcolvals), duplicates
+    summed and rows compressed by torch -> torch.sparse_csr_tensor on the handle's device
+    (direct VBCRS -> CSR)."""
+    r, c, v = rowcolvals_device(A, device=True)
+    coo = torch.sparse_coo_tensor(torch.stack([r - 1, c - 1]), v, size=size(A)).coalesce()
+    return coo.to_sparse_csr()
 
 
 def sparse(A):

@@ -87,7 +87,10 @@ typedef struct {
     /* 1: VBCRS / BlockSparseMatrix handles also keep a SECOND, transposed ordering of the blocks
      * (the reference's own TODO, src/vbcrs.jl:124): transpose(A)*x and A'*x then run as a forward
      * product on it -- one launch, no atomics, bitwise reproducible -- at twice the device
-     * memory.  0 (default): the transposed products run on the single image with atomics. */
+     * memory.  0 (default): the transposed products run on the single image with atomics.
+     * 2: build the second ordering when it is cheap -- packed values of at most 1/16 of the device's
+     * free memory -- else behave like 0 (the default of the Julia binding's ROCmScheduler: Krylov
+     * solvers that apply A' every iteration get the one-launch transposed product). */
     int32_t transpose_image;
     /* rows of y this handle is responsible for scaling by beta (1-based, inclusive);
      * 0,0 = all rows.  Used when block rows are partitioned over several GPUs. */
@@ -253,6 +256,17 @@ typedef enum {
 } bsm_bookkeeping;
 int bsm_get_bookkeeping(bsm_matrix_t A, int which, int64_t *out, int64_t *len);
 
+/* rowcolvals(A) -- reference src/sparse.jl:17-123, the COO triples behind `sparse(A)`
+ * (src/sparse.jl:125-129): written by a kernel straight from the packed DEVICE image -- every stored
+ * entry once, the off-diagonal blocks of a SymmetricBlockMatrix a second time transposed -- so that a
+ * CSR / CSC matrix can be assembled on the GPU without the blocks ever returning to the host.
+ * rows / cols: 1-based int64, vals: the handle's element type, all with room for *count entries
+ * (call with NULL arrays to obtain the count = nnz(A) as the reference defines it).  The order of the
+ * triples is fixed but unspecified (`sparse` sums duplicates, like mul!'s +=).  memspace: where the
+ * three arrays live (BSM_MEM_DEVICE: on the handle's device).  Synchronous. */
+int bsm_rowcolvals(bsm_matrix_t A, int64_t *rows, int64_t *cols, void *vals, int64_t *count, int memspace,
+                   void *stream);
+
 /* Statistics of a handle. */
 typedef struct {
     int64_t nnz;            /* SparseArrays.nnz as the reference defines it (off-diagonal
@@ -277,9 +291,18 @@ int bsm_stats(bsm_matrix_t A, bsm_stats_t *out);
 int bsm_get_image(bsm_matrix_t A, int which, void *out, int64_t *nbytes);
 
 /* color(conflictgraph(ColorInfo(lists)); algorithm).colors -- reference src/coloring.jl:15-61 +
- * GraphsColoring.jl (not in the reference tree).  Two lists conflict iff they share an index.
- * Deterministic DSATUR (specification: oracle/bsm_oracle.c).  lists[b] has lens[b] 1-based
- * entries; color_out[b] receives the 0-based colour of list b; *ncolors the number of colours. */
+ * GraphsColoring.jl (compat 0.2.0, NOT in the reference tree; the reference's default algorithm is its
+ * WorkstreamDSATUR, src/BlockSparseMatrices.jl:10).  Two lists conflict iff they share an index.
+ * CONTRACT: the classes returned here (and by BSM_BK_COLORS / _TRANSPOSECOLORS / _DIAGONALCOLORS) are
+ * VALID -- they partition 1..nlists and no two lists of a class share an index, which is all the
+ * reference's mul! relies on (src/blockmatrix.jl:233-245) -- and DETERMINISTIC, but they are NOT
+ * claimed to be identical to GraphsColoring's: plain DSATUR with fixed tie-breaking (specification:
+ * oracle/bsm_oracle.c:orc_color_dsatur, compared bit-exactly in tests/test_host_logic.py).  No
+ * reference test inspects colour classes, and the serial scheduler's single class [1:nblocks]
+ * (src/blockmatrix.jl:91-92) IS reproduced exactly.  The GPU product does not depend on them
+ * (BSM_ACC_COLORED colours row GROUPS itself).
+ * lists[b] has lens[b] 1-based entries; color_out[b] receives the 0-based colour of list b;
+ * *ncolors the number of colours. */
 int bsm_color(int64_t nlists, const int64_t *const *lists, const int64_t *lens, int64_t *color_out,
               int64_t *ncolors);
 

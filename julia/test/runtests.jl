@@ -75,3 +75,33 @@ end
     end
     @test nnz(G) == nnz(Sg)
 end
+
+@testset "fallbacks, page-locked vectors, converters, several (virtual) devices" begin
+    using .BlockSparseMatricesROCm: ROCmVBCRS, pin!
+    Random.seed!(3)
+    n = 2_000
+    segs = [(20k + 1):(20k + 20) for k in 0:(n ÷ 20 - 1)]
+    pairs = unique([(rand(1:length(segs)), rand(1:length(segs))) for _ in 1:300])
+    blocks = [randn(Float64, 20, 20) for _ in pairs]
+    r0 = [first(segs[i]) for (i, _) in pairs]; c0 = [first(segs[j]) for (_, j) in pairs]
+    S = sparse(VariableBlockCompressedRowStorage(blocks, r0, c0, (n, n)))
+    A = VariableBlockCompressedRowStorage(blocks, r0, c0, (n, n); scheduler=ROCmScheduler())
+    A2 = VariableBlockCompressedRowStorage(blocks, r0, c0, (n, n); scheduler=ROCmScheduler(devices=[0, 0]))
+    X = randn(n, 3); x = pin!(randn(n)); y = pin!(zeros(n))
+    @test mul!(y, A, x) ≈ S * x                                  # DMA straight from / to the pinned vectors
+    @test A2 * x ≈ S * x                                         # two parts, halo-free row partition
+    @test A * view(X, :, 2) ≈ S * X[:, 2]                        # SubArray -> contiguous temporary
+    xc = randn(ComplexF64, n); yc = randn(ComplexF64, n)
+    @test mul!(copy(yc), A, xc, im, 2im) ≈ im * (S * xc) + 2im * yc   # complex x, α, β on a real matrix
+    # converters: same bookkeeping as the reference's, transposes not materialised
+    sets = [collect(s) for s in segs]
+    D = [(d = randn(20, 20); (d + d') / 2) for _ in sets]
+    offp = unique([(i, rand(1:(i - 1))) for i in rand(2:length(sets), 200)])
+    O = [randn(20, 20) for _ in offp]
+    sym = SymmetricBlockMatrix(D, sets, O, [sets[i] for (i, _) in offp], [sets[j] for (_, j) in offp], (n, n))
+    ref = VariableBlockCompressedRowStorage(sym)
+    V = ROCmVBCRS(sym)
+    @test V.rowptr == ref.rowptr && V.colindices == ref.colindices && V.rowindices == ref.rowindices
+    @test V * x ≈ sparse(sym) * x
+    @test V' * x ≈ sparse(sym)' * x
+end
