@@ -459,3 +459,64 @@ def test_auto_mode_splits_only_large_deep_operators(bsm):
     assert bsm.synthetic.build(big, device=NODEV, accumulate="direct").stats()["exclusive"] == 1
     c2 = bsm.synthetic.config2(n=200000, nblocks=10000)                   # 110 MB of ~20 KB row groups
     assert bsm.synthetic.build(c2, device=NODEV).stats()["exclusive"] == 1
+
+
+def test_partition_rows_c_abi(bsm):
+    """bsm_partition_rows: contiguous key ranges, balanced weights, own ranges tile the rows, blocks
+    with equal keys stay together, empty parts get empty ranges -- the partition both multi-GPU layers use."""
+    rng = np.random.default_rng(0)
+    keys = np.sort(rng.integers(1, 5000, 400))
+    w = rng.integers(1, 1000, 400)
+    for nparts in (1, 2, 3, 8):
+        part, own = bsm.partition_rows(5000, keys, w, nparts)
+        assert np.all(np.diff(part) >= 0), "sorted keys -> monotone parts"
+        for k in np.unique(keys):
+            assert len(set(part[keys == k])) == 1
+        assert own[0][0] == 1 and own[-1][1] == 5000 or any(hi < lo for lo, hi in own)
+        cover = np.zeros(5000, int)
+        for p, (lo, hi) in enumerate(own):
+            if hi >= lo:
+                cover[lo - 1:hi] += 1
+            assert np.all((keys[part == p] >= lo) & (keys[part == p] <= hi))
+        assert np.all(cover == 1)
+        loads = np.array([w[part == p].sum() for p in range(nparts)])
+        assert loads.max() <= w.sum() / nparts + w.max() * 2
+    # more parts than keys: the surplus parts are empty, everything is still owned exactly once
+    part, own = bsm.partition_rows(100, [10, 40], [5, 5], 4)
+    assert sorted(part.tolist()) == sorted(set(part.tolist())) and sum(hi >= lo for lo, hi in own) == 2
+    cover = np.zeros(100, int)
+    for lo, hi in own:
+        if hi >= lo:
+            cover[lo - 1:hi] += 1
+    assert np.all(cover == 1)
+    # no block at all: part 0 owns every row
+    part, own = bsm.partition_rows(7, [], [], 3)
+    assert own[0] == (1, 7) and all(hi < lo for lo, hi in own[1:])
+    with pytest.raises(bsm._lib.BsmError):
+        bsm.partition_rows(10, [11], [1], 2)
+
+
+def test_vbcrs_from_blocksparse_c_abi_matches_the_reference_converter(bsm, oracle):
+    """bsm_vbcrs_create_from_blocksparse (reference src/vbcrs.jl:150-160, 201-215): block i sits at
+    (first(rowindices[i]), first(colindices[i])); bookkeeping bit-exact against the oracle's constructor."""
+    rng = np.random.default_rng(4)
+    n = 400
+    cuts = np.sort(rng.choice(np.arange(2, n), 30, replace=False))
+    segs = [np.arange(a, b) for a, b in zip(np.r_[1, cuts], np.r_[cuts, n + 1])]
+    pairs = {(int(rng.integers(len(segs))), int(rng.integers(len(segs)))) for _ in range(60)}
+    pairs = list(pairs)
+    rng.shuffle(pairs)
+    blocks = [np.asfortranarray(rng.standard_normal((len(segs[i]), len(segs[j])))) for i, j in pairs]
+    B = bsm.BlockSparseMatrix(blocks, [segs[i] for i, _ in pairs], [segs[j] for _, j in pairs], (n, n), device=NODEV)
+    V = bsm.VariableBlockCompressedRowStorage(B, device=NODEV)
+    perm, rowptr, colind, rowind = oracle.vbcrs_build([int(segs[i][0]) for i, _ in pairs],
+                                                      [int(segs[j][0]) for _, j in pairs])
+    assert np.array_equal(V.perm, perm) and np.array_equal(V.rowptr, rowptr)
+    assert np.array_equal(V.colindices, colind) and np.array_equal(V.rowindices, rowind)
+    assert bsm.nnz(V) == bsm.nnz(B)
+    x = rng.standard_normal(n)
+    got = interpret_image(V, N, x, np.zeros(n))
+    assert relerr(got, bsm.sparse(B) @ x) < 1e-13
+    with pytest.raises(bsm._lib.BsmError, match="empty index list"):
+        bsm.VariableBlockCompressedRowStorage(
+            bsm.BlockSparseMatrix([np.zeros((0, 2))], [[]], [[1, 2]], (4, 4), device=NODEV), device=NODEV)
