@@ -22,9 +22,11 @@ in-library multi-device handles (bsm_ctx_t, csrc/bsm_dist.cpp) are the two MI355
     `split_vbcrs(..., axis=1)` is the column partition that makes the TRANSPOSED products
     collective-free (mirror of the forward case, reference src/vbcrs.jl:303-329).
 
-x holds the FULL vector on every rank (8-40 MB at the BASELINE sizes); with gather=True the result
-is replicated again, which is what an iterative solver needs.  Every buffer of the exchange is
-allocated once, at the first product of a given kind.
+Vectors: either x holds the FULL vector on every rank (and gather=True replicates the result again),
+or -- what scales -- x and y stay PARTITIONED like the rows (mul(..., x_distributed=True)): a rank
+then fetches only the x entries its blocks read (`xneed`: own range + halo for banded / symmetric
+operators, one batched send/recv; everything for operators with scattered columns: all-gather).
+Every buffer of the exchange is allocated once, at the first product of a given kind.
 """
 import numpy as np
 
@@ -141,10 +143,14 @@ class RowPartitioned:
     chunks) for products across it.  `local` is this rank's matrix (built with own=touched range so
     its beta pass covers exactly the rows it touches), or None for a rank without blocks."""
 
-    def __init__(self, local, own, touched=None, group=None, gather=False, axis=0, symmetric=None):
+    def __init__(self, local, own, touched=None, group=None, gather=False, axis=0, symmetric=None, xneed=None):
         self.local = local
         self.own = (int(own[0]), int(own[1]))
         self.touched = self.own if touched is None else (int(touched[0]), int(touched[1]))
+        # x entries this rank's blocks read (1-based inclusive) when x arrives PARTITIONED like y
+        # (mul(..., x_distributed=True)); None: everything (the x slices are all-gathered first)
+        self.xneed = None if xneed is None else (int(xneed[0]), int(xneed[1]))
+        self._xplan = None
         self.group = group
         self.gather = gather
         self.axis = axis
@@ -166,14 +172,52 @@ class RowPartitioned:
     def _exchange_ranges(self, device):
         """(own, touched) of every rank -- one small all_gather at first use."""
         if self._ranges is None:
-            mine = torch.tensor([self.own[0], self.own[1], self.touched[0], self.touched[1]], dtype=torch.int64)
+            xn = self.xneed if self.xneed is not None else (0, -1)
+            mine = torch.tensor([self.own[0], self.own[1], self.touched[0], self.touched[1], xn[0], xn[1]],
+                                dtype=torch.int64)
             if self.world > 1:
-                out = [torch.zeros(4, dtype=torch.int64, device=device) for _ in range(self.world)]
+                out = [torch.zeros(6, dtype=torch.int64, device=device) for _ in range(self.world)]
                 dist.all_gather(out, mine.to(device), group=self.group)
-                self._ranges = [tuple(int(v) for v in t.cpu()) for t in out]
+                full = [tuple(int(v) for v in t.cpu()) for t in out]
             else:
-                self._ranges = [tuple(int(v) for v in mine)]
+                full = [tuple(int(v) for v in mine)]
+            self._ranges = [t[:4] for t in full]
+            self._xneeds = [t[4:] for t in full]
         return self._ranges
+
+    def fetch_x(self, x):
+        """x arrives PARTITIONED like y (every rank holds x[own] only, the rest of the full-length
+        tensor is undefined): bring in what this rank's blocks read.  With `xneed` ranges (banded /
+        symmetric operators: own range + a halo) that is one batched point-to-point exchange with the
+        owners, received straight into x; without, the all-gather of the x slices."""
+        ranges = self._exchange_ranges(x.device)
+        if self.world == 1:
+            return x
+        own_ranges = [(rl, rh) for rl, rh, _, _ in ranges]
+        if any(xn == (0, -1) for xn in self._xneeds):  # somebody reads everything: all-gather (collective)
+            return self._allgather(x, own_ranges)
+        if self._xplan is None or self._xplan[0] is not x:
+            olo, ohi = self.own
+            nlo, nhi = self._xneeds[self.rank]
+            sends, recvs = [], []
+            for r, (rlo, rhi) in enumerate(own_ranges):
+                if r == self.rank:
+                    continue
+                a, b = max(self._xneeds[r][0], olo), min(self._xneeds[r][1], ohi)  # what rank r reads of mine
+                if a <= b:
+                    sends.append((r, x[a - 1:b]))
+                a, b = max(nlo, rlo), min(nhi, rhi)  # what I read of rank r's
+                if a <= b:
+                    recvs.append((r, x[a - 1:b]))
+            self._xplan = (x, sends, recvs)
+        _, sends, recvs = self._xplan
+        if sends or recvs:
+            self._host_mediated_fence(x)
+            ops = [dist.P2POp(dist.isend, v, r, group=self.group) for r, v in sends]
+            ops += [dist.P2POp(dist.irecv, v, r, group=self.group) for r, v in recvs]
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        return x
 
     def _workvec(self, y):
         if self._work is None or self._work.shape != y.shape or self._work.device != y.device or \
@@ -223,9 +267,13 @@ class RowPartitioned:
             self._ops[op] = A if op == M.L.BSM_OP_N else (M.transpose(A) if op == M.L.BSM_OP_T else M.adjoint(A))
         return self._ops[op]
 
-    def mul(self, y, x, alpha=True, beta=False, local_mul=None, op=M.L.BSM_OP_N):
-        """local_mul(work_or_y, x, alpha, beta[, op]): test hook replacing the HIP product (CPU gloo tests)."""
+    def mul(self, y, x, alpha=True, beta=False, local_mul=None, op=M.L.BSM_OP_N, x_distributed=False):
+        """local_mul(work_or_y, x, alpha, beta[, op]): test hook replacing the HIP product (CPU gloo tests).
+        x_distributed: x is valid only on this rank's own range (see fetch_x); products along the
+        partition only."""
         N_ = M.L.BSM_OP_N
+        if x_distributed:
+            self.fetch_x(x)
         if local_mul is not None:
             lm = (lambda yy, xx, a, b: local_mul(yy, xx, a, b)) if op == N_ and self.axis == 0 else \
                 (lambda yy, xx, a, b: local_mul(yy, xx, a, b, op))

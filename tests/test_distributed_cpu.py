@@ -103,10 +103,26 @@ def _worker(rank, world, port, kind, q):
                     dist.all_reduce(part)  # test-side assembly of the slices
                     y = part
                 results.append(y.numpy().copy())
+        if kind in ("vbcrs", "symmetric", "vbcrs_tiny"):
+            # x and y PARTITIONED like the rows: x is valid on the own range only (NaN elsewhere); the
+            # symmetric operator fetches its halo point-to-point, the VBCRS one all-gathers the slices
+            sym = kind == "symmetric"
+            P = D.RowPartitioned(A, own, touched, gather=False, symmetric=sym, xneed=touched if sym else None)
+            for _ in range(2):
+                xd = torch.full_like(x, float("nan"))
+                if own[1] >= own[0]:
+                    xd[own[0] - 1:own[1]] = x[own[0] - 1:own[1]]
+                y = torch.from_numpy(y0.copy())
+                P.mul(y, xd, 0.5, -2.0, x_distributed=True, local_mul=(local_mul if A is not None else None))
+            part = torch.zeros_like(y)
+            if own[1] >= own[0]:
+                part[own[0] - 1:own[1]] = y[own[0] - 1:own[1]]
+            dist.all_reduce(part)
+            results.append(part.numpy().copy())
         if rank == 0:
             orc = load_oracle()
             errs = []
-            for (alpha, beta), got in zip(((1, 0), (0.5, -2.0)) * 2, results):
+            for (alpha, beta), got in zip(((1, 0), (0.5, -2.0)) * 2 + ((0.5, -2.0),), results):
                 ref = oracle_mul(orc, prob, op, prob["x"], y0, alpha, beta, strong=(beta == 0))
                 errs.append(relerr(got, ref))
             q.put(("ok", errs, own, touched))
