@@ -47,6 +47,31 @@ int main(int argc, char **argv) {
     printf("\nrowptr     =");
     for (int64_t i = 0; i < len; i++) printf(" %lld", (long long)buf[i]);
     const int rowptr_ok = len == 3 && buf[0] == 1 && buf[1] == 3 && buf[2] == 5;
+    /* VariableBlockCompressedRowStorage(bsm) (src/vbcrs.jl:150-160): same four blocks given with index
+     * lists; only first(rowindices), first(colindices) are used => identical bookkeeping */
+    {
+        int64_t l5[2] = {5, 6}, l1[4] = {1, 2, 3, 4}, c1[3] = {1, 2, 3}, c7[2] = {7, 8}, c3[4] = {3, 4, 5, 6}, c9[1] = {9};
+        const int64_t *ri[4] = {l5, l1, l1, l5}, *ci[4] = {c1, c7, c3, c9};
+        bsm_matrix_t W;
+        CHECK(bsm_vbcrs_create_from_blocksparse(BSM_F64, 6, 9, 4, blocks, m, n, ld, ri, ci, &o, &W));
+        int64_t b2[16], l2 = 16;
+        CHECK(bsm_get_bookkeeping(W, BSM_BK_VBCRS_PERM, b2, &l2));
+        if (l2 != 4 || b2[0] != 3 || b2[1] != 2 || b2[2] != 1 || b2[3] != 4) {
+            fprintf(stderr, "converter bookkeeping mismatch\n");
+            return 1;
+        }
+        CHECK(bsm_destroy(W));
+    }
+    /* the row partition both multi-GPU layers use: 4 blocks, keys 5 1 1 5, weights = stored entries */
+    {
+        int64_t w[4] = {6, 8, 16, 2}, lo[2], hi[2];
+        int32_t part[4];
+        CHECK(bsm_partition_rows(6, 4, r0, w, 2, part, lo, hi));
+        printf("partition  = %d %d %d %d, own = [%lld,%lld] [%lld,%lld]\n", part[0], part[1], part[2], part[3],
+               (long long)lo[0], (long long)hi[0], (long long)lo[1], (long long)hi[1]);
+        if (part[1] != 0 || part[2] != 0 || part[0] != 1 || part[3] != 1 || lo[0] != 1 || hi[0] != 4 || lo[1] != 5 || hi[1] != 6)
+            return 1;
+    }
     bsm_stats_t st;
     CHECK(bsm_stats(V, &st));
     printf("\nnnz = %lld, exclusive = %lld\n", (long long)st.nnz, (long long)st.exclusive);
@@ -81,6 +106,33 @@ int main(int argc, char **argv) {
         if (y[0] != 11 || y[1] != 14 || y[2] != 1 || y[3] != 2) return 1;
         CHECK(bsm_destroy(A));
         CHECK(bsm_destroy(S));
+        /* the same symmetric KAT with the handle spread over a context of TWO (virtual) devices: the
+         * diagonal block and the off-diagonal block land on different parts, the transposed
+         * contribution y[3:4] crosses the partition (bsm_ctx_create, bsm_options.ctx) */
+        int32_t devs[2] = {0, 0};
+        bsm_ctx_t ctx;
+        CHECK(bsm_ctx_create(devs, 2, &ctx));
+        bsm_options oc = o;
+        oc.ctx = ctx;
+        bsm_matrix_t S2;
+        CHECK(bsm_symmetric_create(BSM_F64, 4, 4, 1, dd, ds, dl, di, 1, oo, om, on, old_, orr, occ, &oc, &S2));
+        bsm_part_info_t pi;
+        CHECK(bsm_part_info(S2, 1, &pi));
+        double y2[4] = {-1, -1, -1, -1};
+        CHECK(bsm_mul(S2, BSM_OP_N, x, y2, NULL, NULL, 1, BSM_MEM_HOST, NULL));
+        printf("two-device SymmetricBlockMatrix KAT y = [%g %g %g %g] (part 1 owns rows %lld..%lld)\n", y2[0], y2[1],
+               y2[2], y2[3], (long long)pi.own_lo, (long long)pi.own_hi);
+        if (y2[0] != 11 || y2[1] != 14 || y2[2] != 1 || y2[3] != 2) return 1;
+        /* rowcolvals: nnz = 2*2 + 1 = 5 triples (src/symmetricblockmatrix.jl:377-382) */
+        int64_t rr[8], cc[8], cnt = 8;
+        double vv[8];
+        CHECK(bsm_rowcolvals(S2, rr, cc, vv, &cnt, BSM_MEM_HOST, NULL));
+        double dense[16] = {0};
+        for (int64_t k = 0; k < cnt; k++) dense[(rr[k] - 1) * 4 + (cc[k] - 1)] += vv[k];
+        printf("rowcolvals: %lld triples, A[1,3] = %g, A[3,1] = %g, A[2,2] = %g\n", (long long)cnt, dense[2], dense[8], dense[5]);
+        if (cnt != 5 || dense[2] != 1 || dense[3] != 2 || dense[8] != 1 || dense[12] != 2 || dense[5] != 7) return 1;
+        CHECK(bsm_destroy(S2));
+        CHECK(bsm_ctx_destroy(ctx));
     }
     CHECK(bsm_destroy(V));
     printf("OK\n");

@@ -24,6 +24,7 @@ def test_c_demo_bookkeeping(tmp_path, bsm):
     out = subprocess.run([_build(tmp_path)], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stderr
     assert "perm       = 3 2 1 4" in out.stdout and "rowptr     = 1 3 5" in out.stdout
+    assert "partition  = 1 0 0 1, own = [1,4] [5,6]" in out.stdout
     assert out.stdout.strip().endswith("OK")
 
 
@@ -33,3 +34,5 @@ def test_c_demo_products_on_gpu(tmp_path, bsm):
     assert out.returncode == 0, out.stderr + out.stdout
     assert "BlockSparseMatrix KAT y = [10 0 27 0]" in out.stdout
     assert "SymmetricBlockMatrix KAT y = [11 14 1 2]" in out.stdout
+    assert "two-device SymmetricBlockMatrix KAT y = [11 14 1 2]" in out.stdout
+    assert "rowcolvals: 5 triples" in out.stdout
