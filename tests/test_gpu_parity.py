@@ -623,3 +623,27 @@ def test_streamed_upload_matches_one_shot_upload(torch_cuda, bsm, oracle, monkey
                       (bsm.synthetic.config1(), np.float64, {})):
         A = bsm.synthetic.build(p, **kw)
         check_all(torch_cuda, bsm, oracle, p, A, dt, host_too=False)
+
+
+@pytest.mark.parametrize("dtype,part", [(np.complex128, "full"), (np.float64, "real")])
+def test_bem_fixture_tiled_along_the_diagonal(torch_cuda, bsm, oracle, dtype, part):
+    """The reference's real BEM structure at a size where the launch has several rounds of workgroups
+    (tools/bem_real.py's operator, 12 tiles instead of 300): the "cuboid" fixture repeated along the
+    diagonal -- 3-28-row leaves, scattered near-field columns, the LDS y window of locality-packed
+    workgroups -- fused symmetric product and both wrappers against the oracle."""
+    K = 12
+    p = fixture_problem("cuboid", dtype, part)
+    n0 = p["size"][0]
+
+    def tile(lists):
+        return [l + k * n0 for k in range(K) for l in lists]
+
+    prob = dict(kind="symmetric", diagonals=p["diagonals"] * K, diagonalindices=tile(p["diagonalindices"]),
+                offdiagonals=p["offdiagonals"] * K, rowindices=tile(p["rowindices"]),
+                colindices=tile(p["colindices"]), size=(n0 * K, n0 * K))
+    A = bsm.synthetic.build(prob)
+    assert bsm.nnz(A) == K * (sum(b.size for b in p["diagonals"]) + 2 * sum(b.size for b in p["offdiagonals"]))
+    check_all(torch_cuda, bsm, oracle, prob, A, dtype, host_too=False)
+    for acc in ("gather", "colored"):  # the bitwise reproducible modes on the same structure
+        B = bsm.synthetic.build(prob, accumulate=acc)
+        check_all(torch_cuda, bsm, oracle, prob, B, dtype, ops=[N], host_too=False)
