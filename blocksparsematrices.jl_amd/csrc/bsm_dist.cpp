@@ -9,9 +9,12 @@
 // One host thread issues everything; every step is asynchronous and ordered by events.
 #include <algorithm>
 #include <complex>
+#include <condition_variable>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <numeric>
+#include <thread>
 
 #include "bsm_internal.h"
 
@@ -61,7 +64,75 @@ struct Part {
     void *d_x = nullptr, *d_w = nullptr, *d_recv = nullptr;
 };
 
+// One persistent thread per part, bound to the part's device once.  run(f) executes f(p) on every
+// worker and returns when all are done (first failure wins; its message is handed to the caller's
+// thread-local error slot).
+class Workers {
+  public:
+    explicit Workers(const std::vector<int> &devices) : n_((int)devices.size()), rc_(devices.size(), BSM_OK), msg_(devices.size()) {
+        for (int p = 0; p < n_; p++) th_.emplace_back([this, p, dev = devices[p]] { loop(p, dev); });
+    }
+    ~Workers() {
+        {
+            std::lock_guard<std::mutex> l(mu_);
+            stop_ = true;
+            gen_++;
+        }
+        go_.notify_all();
+        for (auto &t : th_) t.join();
+    }
+    int run(const std::function<int(int)> &f) {
+        std::unique_lock<std::mutex> l(mu_);
+        fn_ = &f;
+        pending_ = n_;
+        gen_++;
+        go_.notify_all();
+        done_.wait(l, [&] { return pending_ == 0; });
+        fn_ = nullptr;
+        for (int p = 0; p < n_; p++)
+            if (rc_[p] != BSM_OK) return fail(rc_[p], msg_[p]);
+        return BSM_OK;
+    }
+
+  private:
+    void loop(int p, int dev) {
+        (void)hipSetDevice(dev);
+        uint64_t seen = 0;
+        std::unique_lock<std::mutex> l(mu_);
+        for (;;) {
+            go_.wait(l, [&] { return gen_ != seen; });
+            seen = gen_;
+            if (stop_) return;
+            const std::function<int(int)> *f = fn_;
+            l.unlock();
+            int rc = BSM_ERR_DEVICE;
+            std::string msg;
+            try {
+                rc = (*f)(p);
+                if (rc != BSM_OK) msg = bsm_last_error();  // this thread's slot
+            } catch (const std::exception &e) {
+                msg = e.what();
+            }
+            l.lock();
+            rc_[p] = rc;
+            msg_[p] = msg;
+            if (--pending_ == 0) done_.notify_all();
+        }
+    }
+    int n_;
+    std::vector<std::thread> th_;
+    std::mutex mu_;
+    std::condition_variable go_, done_;
+    uint64_t gen_ = 0;
+    int pending_ = 0;
+    bool stop_ = false;
+    const std::function<int(int)> *fn_ = nullptr;
+    std::vector<int> rc_;
+    std::vector<std::string> msg_;
+};
+
 struct DistState {
+    std::unique_ptr<Workers> workers;  // more than two parts: one issuing thread per device
     bsm_ctx_s *ctx = nullptr;
     int dtype = 1, es = 8;
     long long nrows = 0, ncols = 0;
@@ -219,6 +290,7 @@ int pointer_device(const void *p, int fallback) {
 void dist_destroy(bsm_matrix_s *A) {
     if (!A->dist) return;
     DistState &D = *A->dist;
+    D.workers.reset();
     for (auto &pp : D.parts) {
         Part &p = *pp;
         DeviceGuard g;
@@ -331,6 +403,7 @@ int dist_create(bsm_matrix_s *A, bsm_ctx_s *ctx, int mtype, int dtype, int64_t n
         if (e == hipSuccess && rb) e = hipMalloc(&pt.d_recv, rb);
         if (e != hipSuccess) return hip_fail(e, "multi-device buffers");
     }
+    if (P > 2) D.workers.reset(new Workers(ctx->devices));
     return BSM_OK;
 }
 
@@ -401,52 +474,56 @@ int dist_mul(bsm_matrix_s *A, int op, const void *x, void *y, const void *alpha,
         }
     }
 
-    // 1 + 2: x to every device, local products, one stream per device
-    for (int p = 0; p < P; p++) {
+    // The issue of every part's work -- one stream per device -- is two phases with a host barrier in
+    // between (a stream can only wait for an event that HAS been recorded):
+    //   phase 0 (part p): x to its device, local product, record ev_prod
+    //   phase 1 (part q): the y segments other parts produced for q's rows (peer copy over xGMI + add),
+    //                     then q's owned range to the caller's y, record ev_done
+    // Run inline by the calling thread for up to two parts, by one persistent worker thread per device
+    // beyond that (each bound to its device once: the host-side issue cost no longer grows with the
+    // number of GPUs).
+    std::vector<char> late_flag((size_t)P, 0);  // numeric beta, remote part, y on a device: combined below
+    auto phase = [&](int ph, int p, bool bind) -> int {
+        hipError_t e = hipSuccess;  // (per invocation: the phases of different parts run concurrently)
         Part &pt = *D.parts[p];
         DeviceGuard g;
-        DCHECK(g.enter(pt.device), "hipSetDevice");
-        if (ev_ready) DCHECK(hipStreamWaitEvent(pt.stream, ev_ready, 0), "hipStreamWaitEvent");
-        const Range zr = pl.zr[p];
-        if (pt.has_image) {
-            const Range xr = pl.xr[p];
-            const void *xp = pt.d_x;
-            if (host) {
-                DCHECK(hipMemcpyAsync((char *)pt.d_x + xr.lo * es, xb + xr.lo * es, (size_t)xr.len() * es,
-                                      hipMemcpyHostToDevice, pt.stream), "x upload");
-            } else if (xdev == pt.device) {
-                xp = x;  // same device: the local product reads the caller's x directly
-            } else {
-                DCHECK(copy_between((char *)pt.d_x + xr.lo * es, pt.device, xb + xr.lo * es, xdev,
-                                    (size_t)xr.len() * es, pt.stream), "x peer copy");
+        if (bind) DCHECK(g.enter(pt.device), "hipSetDevice");
+        if (ph == 0) {
+            if (ev_ready) DCHECK(hipStreamWaitEvent(pt.stream, ev_ready, 0), "hipStreamWaitEvent");
+            const Range zr = pl.zr[p];
+            if (pt.has_image) {
+                const Range xr = pl.xr[p];
+                const void *xp = pt.d_x;
+                if (host) {
+                    DCHECK(hipMemcpyAsync((char *)pt.d_x + xr.lo * es, xb + xr.lo * es, (size_t)xr.len() * es,
+                                          hipMemcpyHostToDevice, pt.stream), "x upload");
+                } else if (xdev == pt.device) {
+                    xp = x;  // same device: the local product reads the caller's x directly
+                } else {
+                    DCHECK(copy_between((char *)pt.d_x + xr.lo * es, pt.device, xb + xr.lo * es, xdev,
+                                        (size_t)xr.len() * es, pt.stream), "x peer copy");
+                }
+                const long long z[2] = {zr.lo, zr.hi};
+                DCHECK(launch_mul(pt.img, opT, conj, xp, pt.d_w, alpha, nullptr, 1, pt.stream, pt.img.d_ws != nullptr, z),
+                       "kernel launch");
+            } else if (!zr.empty()) {
+                DCHECK(hipMemsetAsync((char *)pt.d_w + zr.lo * es, 0, (size_t)zr.len() * es, pt.stream), "memset");
             }
-            const long long z[2] = {zr.lo, zr.hi};
-            DCHECK(launch_mul(pt.img, opT, conj, xp, pt.d_w, alpha, nullptr, 1, pt.stream, pt.img.d_ws != nullptr, z),
-                   "kernel launch");
-        } else if (!zr.empty()) {
-            DCHECK(hipMemsetAsync((char *)pt.d_w + zr.lo * es, 0, (size_t)zr.len() * es, pt.stream), "memset");
+            DCHECK(hipEventRecord(pt.ev_prod, pt.stream), "hipEventRecord");
+            return BSM_OK;
         }
-        DCHECK(hipEventRecord(pt.ev_prod, pt.stream), "hipEventRecord");
-    }
-    // 3: y segments produced for rows of another device: peer copy over xGMI + local add
-    for (const Transfer &t : pl.transfers) {
-        Part &src = *D.parts[t.from];
-        Part &dst = *D.parts[t.to];
-        DeviceGuard g;
-        DCHECK(g.enter(dst.device), "hipSetDevice");
-        DCHECK(hipStreamWaitEvent(dst.stream, src.ev_prod, 0), "hipStreamWaitEvent");
-        char *rb = (char *)dst.d_recv + t.recv_off;
-        DCHECK(copy_between(rb, dst.device, (char *)src.d_w + t.range.lo * es, src.device,
-                            (size_t)t.range.len() * es, dst.stream), "halo peer copy");
-        DCHECK(launch_vec_add(D.dtype, (char *)dst.d_w + t.range.lo * es, rb, t.range.len(), dst.stream), "halo add");
-    }
-    // 4: deliver the owned ranges
-    std::vector<int> late;  // numeric beta, remote part, y on a device: combined on the caller's stream
-    for (int q = 0; q < P; q++) {
-        Part &pt = *D.parts[q];
-        const Range o = pl.out[q];
-        DeviceGuard g;
-        DCHECK(g.enter(pt.device), "hipSetDevice");
+        // 3: y segments produced for rows of THIS part: peer copy over xGMI + local add
+        for (const Transfer &t : pl.transfers) {
+            if (t.to != p) continue;
+            Part &src = *D.parts[t.from];
+            DCHECK(hipStreamWaitEvent(pt.stream, src.ev_prod, 0), "hipStreamWaitEvent");
+            char *rb = (char *)pt.d_recv + t.recv_off;
+            DCHECK(copy_between(rb, pt.device, (char *)src.d_w + t.range.lo * es, src.device,
+                                (size_t)t.range.len() * es, pt.stream), "halo peer copy");
+            DCHECK(launch_vec_add(D.dtype, (char *)pt.d_w + t.range.lo * es, rb, t.range.len(), pt.stream), "halo add");
+        }
+        // 4: deliver the owned range
+        const Range o = pl.out[p];
         if (!o.empty()) {
             const size_t off = (size_t)o.lo * es, bytes = (size_t)o.len() * es;
             const char *w = (const char *)pt.d_w + off;
@@ -459,11 +536,23 @@ int dist_mul(bsm_matrix_s *A, int op, const void *x, void *y, const void *alpha,
                 DCHECK(launch_vec_axpby(D.dtype, yb + off, w, o.len(), beta, pt.stream), "y combine");
             } else {
                 DCHECK(copy_between((char *)D.d_res + off, ydev, w, pt.device, bytes, pt.stream), "y peer copy");
-                late.push_back(q);
+                late_flag[p] = 1;
             }
         }
         DCHECK(hipEventRecord(pt.ev_done, pt.stream), "hipEventRecord");
+        return BSM_OK;
+    };
+    for (int ph = 0; ph < 2; ph++) {
+        int rc = BSM_OK;
+        if (D.workers)
+            rc = D.workers->run([&](int p) { return phase(ph, p, false); });
+        else
+            for (int p = 0; p < P && rc == BSM_OK; p++) rc = phase(ph, p, true);
+        if (rc != BSM_OK) return rc;
     }
+    std::vector<int> late;
+    for (int q = 0; q < P; q++)
+        if (late_flag[q]) late.push_back(q);
     if (host) {
         for (int q = 0; q < P; q++) {
             Part &pt = *D.parts[q];
