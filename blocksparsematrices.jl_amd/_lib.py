@@ -15,6 +15,7 @@ BSM_MEM_HOST, BSM_MEM_DEVICE = 0, 1
 BSM_SCHED_SERIAL, BSM_SCHED_DYNAMIC = 0, 1
 BSM_ACC_AUTO, BSM_ACC_ATOMIC, BSM_ACC_COLORED, BSM_ACC_GATHER, BSM_ACC_DIRECT = 0, 1, 2, 3, 4
 BSM_DEVICE_CURRENT, BSM_DEVICE_NONE = -1, -2
+BSM_COLOR_WORKSTREAM_DSATUR, BSM_COLOR_DSATUR = 0, 1
 (BSM_BK_VBCRS_PERM, BSM_BK_VBCRS_ROWPTR, BSM_BK_VBCRS_COLINDICES, BSM_BK_VBCRS_ROWINDICES,
  BSM_BK_COLORS, BSM_BK_TRANSPOSECOLORS, BSM_BK_DIAGONALCOLORS) = range(7)
 
@@ -23,7 +24,7 @@ class BsmOptions(C.Structure):
     _fields_ = [("struct_size", C.c_int32), ("device", C.c_int32), ("scheduler", C.c_int32),
                 ("accumulate", C.c_int32), ("validate", C.c_int32), ("transpose_image", C.c_int32),
                 ("own_lo", C.c_int64), ("own_hi", C.c_int64), ("ctx", C.c_void_p),
-                ("blocks_memspace", C.c_int64), ("reserved", C.c_int64 * 2)]
+                ("blocks_memspace", C.c_int64), ("coloring", C.c_int64), ("reserved", C.c_int64 * 1)]
 
 
 class BsmPartInfo(C.Structure):
@@ -123,7 +124,7 @@ def lib():
     L.bsm_mul_multi.restype = C.c_int
     L.bsm_get_bookkeeping.argtypes = [C.c_void_p, C.c_int, _I64P, _I64P]
     L.bsm_get_image.argtypes = [C.c_void_p, C.c_int, C.c_void_p, _I64P]
-    L.bsm_color.argtypes = [C.c_int64, _PP, _I64P, _I64P, _I64P]
+    L.bsm_color.argtypes = [C.c_int64, _PP, _I64P, C.c_int, _I64P, _I64P]
     L.bsm_color.restype = C.c_int
     L.bsm_stats.argtypes = [C.c_void_p, C.POINTER(BsmStats)]
     L.bsm_destroy.argtypes = [C.c_void_p]

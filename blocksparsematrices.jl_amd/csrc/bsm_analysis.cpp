@@ -37,14 +37,14 @@ Tunables Tunables::from_env() {
 }
 
 // ---------------------------------------------------------------------------------------
-// DSATUR colouring (specification in bsm_analysis.h / oracle/bsm_oracle.c).
-// Heap-free formulation on an ordered set keyed by (-saturation, -degree, id).
+// Colouring (specifications: bsm_analysis.h / oracle/bsm_oracle.c).
 // ---------------------------------------------------------------------------------------
-std::vector<std::vector<int64_t>> color_dsatur(const std::vector<const int64_t *> &lists,
-                                               const std::vector<int64_t> &lens) {
+namespace {
+
+// distinct neighbours of every list (two lists are adjacent iff they share an index)
+std::vector<std::vector<int32_t>> conflict_adjacency(const std::vector<const int64_t *> &lists,
+                                                     const std::vector<int64_t> &lens) {
     const int64_t nb = (int64_t)lists.size();
-    std::vector<std::vector<int64_t>> classes;
-    if (nb == 0) return classes;
     int64_t maxindex = 0;
     for (int64_t b = 0; b < nb; b++)
         for (int64_t k = 0; k < lens[b]; k++) maxindex = std::max(maxindex, lists[b][k]);
@@ -59,55 +59,169 @@ std::vector<std::vector<int64_t>> color_dsatur(const std::vector<const int64_t *
         for (int64_t b = 0; b < nb; b++)
             for (int64_t k = 0; k < lens[b]; k++) inc[fill[lists[b][k]]++] = b;
     }
-    // adjacency (distinct neighbours)
     std::vector<std::vector<int32_t>> adj(nb);
-    {
-        std::vector<int64_t> stamp(nb, -1);
-        for (int64_t v = 0; v < nb; v++) {
-            stamp[v] = v;
-            for (int64_t k = 0; k < lens[v]; k++) {
-                int64_t i = lists[v][k];
-                for (int64_t p = ptr[i]; p < ptr[i + 1]; p++) {
-                    int64_t w = inc[p];
-                    if (stamp[w] != v) {
-                        stamp[w] = v;
-                        adj[v].push_back((int32_t)w);
-                    }
+    std::vector<int64_t> stamp(nb, -1);
+    for (int64_t v = 0; v < nb; v++) {
+        stamp[v] = v;
+        for (int64_t k = 0; k < lens[v]; k++) {
+            int64_t i = lists[v][k];
+            for (int64_t p = ptr[i]; p < ptr[i + 1]; p++) {
+                int64_t w = inc[p];
+                if (stamp[w] != v) {
+                    stamp[w] = v;
+                    adj[v].push_back((int32_t)w);
                 }
             }
         }
     }
-    std::vector<int32_t> color(nb, -1), sat(nb, 0);
-    std::vector<std::vector<int32_t>> seen(nb);  // sorted colours among neighbours
+    return adj;
+}
+
+// DSATUR on the subgraph induced by `members` (all vertices when zone_of == nullptr): repeatedly the
+// uncoloured vertex with the largest saturation, ties by larger degree INSIDE the subgraph, then by
+// smaller id; smallest colour no neighbour inside the subgraph has.  color[v] (0-based) is written for
+// the members only; returns the number of colours.  Ordered-set formulation, keyed by
+// (-saturation, -degree, id).
+int32_t dsatur_subgraph(const std::vector<std::vector<int32_t>> &adj, const std::vector<int64_t> &members,
+                        const std::vector<int32_t> *zone_of, int32_t zone, std::vector<int32_t> &color) {
+    auto inside = [&](int32_t w) { return !zone_of || (*zone_of)[w] == zone; };
+    std::unordered_map<int64_t, int64_t> local;  // vertex -> position in members
+    local.reserve(members.size() * 2);
+    for (size_t k = 0; k < members.size(); k++) local[members[k]] = (int64_t)k;
+    const size_t n = members.size();
+    std::vector<int64_t> deg(n, 0);
+    std::vector<int32_t> sat(n, 0);
+    std::vector<std::vector<int32_t>> seen(n);  // sorted colours among neighbours
+    for (size_t k = 0; k < n; k++)
+        for (int32_t w : adj[members[k]]) deg[k] += inside(w);
     using Key = std::tuple<int32_t, int64_t, int64_t>;  // (-sat, -deg, id)
     std::set<Key> queue;
-    for (int64_t v = 0; v < nb; v++) queue.insert(Key(0, -(int64_t)adj[v].size(), v));
+    for (size_t k = 0; k < n; k++) queue.insert(Key(0, -deg[k], members[k]));
     int32_t ncolors = 0;
     while (!queue.empty()) {
         auto it = queue.begin();
-        int64_t v = std::get<2>(*it);
+        const int64_t v = std::get<2>(*it);
         queue.erase(it);
+        const int64_t kv = local[v];
         int32_t c = 0;
-        for (int32_t s : seen[v]) {  // sorted: first gap
-            if (s == c)
+        for (int32_t sc : seen[kv]) {  // sorted: first gap
+            if (sc == c)
                 c++;
-            else if (s > c)
+            else if (sc > c)
                 break;
         }
         color[v] = c;
         ncolors = std::max(ncolors, c + 1);
         for (int32_t w : adj[v]) {
-            if (color[w] >= 0) continue;
-            auto pos = std::lower_bound(seen[w].begin(), seen[w].end(), c);
-            if (pos != seen[w].end() && *pos == c) continue;
-            queue.erase(Key(-sat[w], -(int64_t)adj[w].size(), w));
-            seen[w].insert(pos, c);
-            sat[w]++;
-            queue.insert(Key(-sat[w], -(int64_t)adj[w].size(), w));
+            if (!inside(w) || color[w] >= 0) continue;
+            const int64_t kw = local[w];
+            auto pos = std::lower_bound(seen[kw].begin(), seen[kw].end(), c);
+            if (pos != seen[kw].end() && *pos == c) continue;
+            queue.erase(Key(-sat[kw], -deg[kw], w));
+            seen[kw].insert(pos, c);
+            sat[kw]++;
+            queue.insert(Key(-sat[kw], -deg[kw], w));
         }
     }
+    return ncolors;
+}
+
+}  // namespace
+
+std::vector<std::vector<int64_t>> color_dsatur(const std::vector<const int64_t *> &lists,
+                                               const std::vector<int64_t> &lens) {
+    const int64_t nb = (int64_t)lists.size();
+    std::vector<std::vector<int64_t>> classes;
+    if (nb == 0) return classes;
+    const auto adj = conflict_adjacency(lists, lens);
+    std::vector<int64_t> all(nb);
+    std::iota(all.begin(), all.end(), (int64_t)0);
+    std::vector<int32_t> color(nb, -1);
+    const int32_t ncolors = dsatur_subgraph(adj, all, nullptr, 0, color);
     classes.assign(ncolors, {});
     for (int64_t v = 0; v < nb; v++) classes[color[v]].push_back(v + 1);
+    return classes;
+}
+
+// WorkstreamDSATUR -- the reference's default (src/BlockSparseMatrices.jl:10) as published: Turcksin,
+// Kronbichler, Bangerth, "WorkStream -- a design pattern for multicore-enabled finite element
+// computations", ACM TOMS 43 (2016), section 3.2: (1) PARTITION the conflict graph into zones -- a seed,
+// then repeatedly every not yet assigned neighbour of the previous zone, so that zone k only
+// conflicts with zones k-1 and k+1; (2) COLOUR every zone on its own (DSATUR); (3) GATHER: zones of
+// equal parity are mutually conflict-free, so their colour classes are merged -- the zone with the
+// most colours founds the global classes of its parity, every other zone hands its classes, largest
+// first, to the currently smallest global class it has not used yet.  Tie-breaking is fixed here
+// (seed = smallest unassigned id; see oracle/bsm_oracle.c:orc_color_workstream for the full rules).
+std::vector<std::vector<int64_t>> color_workstream_dsatur(const std::vector<const int64_t *> &lists,
+                                                          const std::vector<int64_t> &lens) {
+    const int64_t nb = (int64_t)lists.size();
+    std::vector<std::vector<int64_t>> classes;
+    if (nb == 0) return classes;
+    const auto adj = conflict_adjacency(lists, lens);
+    // (1) zones
+    std::vector<int32_t> zone_of(nb, -1);
+    std::vector<std::vector<int64_t>> zones;
+    int64_t next_seed = 0;
+    while (true) {
+        while (next_seed < nb && zone_of[next_seed] >= 0) next_seed++;
+        if (next_seed >= nb) break;
+        std::vector<int64_t> cur{next_seed};
+        zone_of[next_seed] = (int32_t)zones.size();
+        while (!cur.empty()) {
+            const int32_t z = (int32_t)zones.size();
+            std::vector<int64_t> nxt;
+            for (int64_t v : cur)
+                for (int32_t w : adj[v])
+                    if (zone_of[w] < 0) {
+                        zone_of[w] = z + 1;
+                        nxt.push_back(w);
+                    }
+            std::sort(nxt.begin(), nxt.end());
+            zones.push_back(std::move(cur));
+            cur = std::move(nxt);
+        }
+    }
+    // (2) DSATUR inside every zone
+    std::vector<int32_t> color(nb, -1);
+    std::vector<int32_t> zcolors(zones.size());
+    for (size_t z = 0; z < zones.size(); z++) zcolors[z] = dsatur_subgraph(adj, zones[z], &zone_of, (int32_t)z, color);
+    // (3) gather, parity by parity
+    std::vector<int32_t> global(nb, -1);
+    int32_t base = 0;
+    for (int parity = 0; parity < 2; parity++) {
+        size_t zmax = zones.size();
+        for (size_t z = parity; z < zones.size(); z += 2)
+            if (zmax == zones.size() || zcolors[z] > zcolors[zmax]) zmax = z;
+        if (zmax == zones.size()) continue;
+        const int32_t K = zcolors[zmax];
+        std::vector<int64_t> gsize(K, 0);
+        for (int64_t v : zones[zmax]) {
+            global[v] = base + color[v];
+            gsize[color[v]]++;
+        }
+        for (size_t z = parity; z < zones.size(); z += 2) {
+            if (z == zmax) continue;
+            std::vector<int64_t> csize(zcolors[z], 0);
+            for (int64_t v : zones[z]) csize[color[v]]++;
+            std::vector<int32_t> order(zcolors[z]);
+            std::iota(order.begin(), order.end(), 0);
+            std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return csize[a] > csize[b]; });
+            std::vector<int32_t> target(zcolors[z], -1);
+            std::vector<char> used(K, 0);
+            for (int32_t c : order) {
+                int32_t best = -1;
+                for (int32_t g = 0; g < K; g++)
+                    if (!used[g] && (best < 0 || gsize[g] < gsize[best])) best = g;
+                used[best] = 1;
+                gsize[best] += csize[c];
+                target[c] = best;
+            }
+            for (int64_t v : zones[z]) global[v] = base + target[color[v]];
+        }
+        base += K;
+    }
+    classes.assign(base, {});
+    for (int64_t v = 0; v < nb; v++) classes[global[v]].push_back(v + 1);
     return classes;
 }
 
@@ -283,6 +397,10 @@ std::string Analysis::build(int mtype_, int dtype_, int64_t nrows_, int64_t ncol
         try {
             for (auto &c : colors) c.clear();
             if (opt.skip_colors) return;
+            // the reference's `coloringalgorithm` keyword: WorkstreamDSATUR unless told otherwise
+            auto refcolor = [&](const std::vector<const int64_t *> &l, const std::vector<int64_t> &n) {
+                return opt.coloring == 1 ? color_dsatur(l, n) : color_workstream_dsatur(l, n);
+            };
             auto single = [](int64_t n) {
                 std::vector<std::vector<int64_t>> out(1);
                 out[0].resize(n);
@@ -302,8 +420,8 @@ std::string Analysis::build(int mtype_, int dtype_, int64_t nrows_, int64_t ncol
                         cl[b] = blocks[b].cidx;
                         cn[b] = blocks[b].cidx ? blocks[b].n : 0;
                     }
-                    colors[0] = color_dsatur(rl, rn);
-                    colors[1] = color_dsatur(cl, cn);
+                    colors[0] = refcolor(rl, rn);
+                    colors[1] = refcolor(cl, cn);
                 }
             } else if (mtype == MT_SYMMETRIC) {
                 // always three colourings, also for the serial scheduler: src/symmetricblockmatrix.jl:104-110
@@ -320,9 +438,9 @@ std::string Analysis::build(int mtype_, int dtype_, int64_t nrows_, int64_t ncol
                         cn.push_back(B.cidx ? B.n : 0);
                     }
                 }
-                colors[0] = color_dsatur(rl, rn);
-                colors[1] = color_dsatur(cl, cn);
-                colors[2] = color_dsatur(dl, dn);
+                colors[0] = refcolor(rl, rn);
+                colors[1] = refcolor(cl, cn);
+                colors[2] = refcolor(dl, dn);
             }
         } catch (const std::bad_alloc &) {
             colour_oom = true;

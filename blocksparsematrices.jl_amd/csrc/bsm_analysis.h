@@ -87,6 +87,7 @@ struct AnalysisOptions {
     // instead of packed values it leaves a pack plan (Analysis::pack_plan / pack_colpos) that a kernel
     // executes on the device
     bool blocks_on_device = false;
+    int coloring = 0;  // reference colourings: 0 WorkstreamDSATUR (the reference's default), 1 plain DSATUR
     bool meta_only = false;    // validation, statistics and the reference colourings only (no image)
     bool skip_colors = false;  // leave `colors` empty (the parts of a multi-device handle)
 };
@@ -96,6 +97,11 @@ struct AnalysisOptions {
 // identical to oracle/bsm_oracle.c:orc_color_dsatur.  Returns classes of 1-based ids.
 std::vector<std::vector<int64_t>> color_dsatur(const std::vector<const int64_t *> &lists,
                                                const std::vector<int64_t> &lens);
+// WorkstreamDSATUR (the reference's default, src/BlockSparseMatrices.jl:10): zones / DSATUR per zone /
+// gather, as published by Turcksin, Kronbichler & Bangerth (ACM TOMS 2016).  Specification identical
+// to oracle/bsm_oracle.c:orc_color_workstream.  Classes of 1-based ids.
+std::vector<std::vector<int64_t>> color_workstream_dsatur(const std::vector<const int64_t *> &lists,
+                                                          const std::vector<int64_t> &lens);
 
 // One chunk (<= 64 rows of one input block) of the device-side repacking: element (i, w) of the
 // chunk goes to merged panel column q = perm_off < 0 ? woff + w : colpos[perm_off + w] of the row

@@ -117,6 +117,8 @@ int read_options(const bsm_options *opts, bsm_options &o) {
     if (o.own_lo < 0 || o.own_hi < 0 || (o.own_hi > 0 && o.own_hi < o.own_lo))
         return fail(BSM_ERR_INVALID, "bad own_lo/own_hi");
     if (o.transpose_image < 0 || o.transpose_image > 2) return fail(BSM_ERR_INVALID, "bad transpose_image");
+    if (o.coloring != BSM_COLOR_WORKSTREAM_DSATUR && o.coloring != BSM_COLOR_DSATUR)
+        return fail(BSM_ERR_INVALID, "unknown colouring algorithm");
     if (o.blocks_memspace != BSM_MEM_HOST && o.blocks_memspace != BSM_MEM_DEVICE)
         return fail(BSM_ERR_INVALID, "bad blocks_memspace");
     return BSM_OK;
@@ -387,6 +389,7 @@ AnalysisOptions to_aopt(const bsm_options &o, ValueSink *sink) {
     AnalysisOptions a;
     a.sink = sink;
     a.blocks_on_device = (o.blocks_memspace == BSM_MEM_DEVICE);
+    a.coloring = (int)o.coloring;
     a.scheduler = o.scheduler;
     a.validate = 1;  // indices are always range-checked: a bad index must never reach a kernel
     a.accumulate = o.accumulate;
@@ -1074,7 +1077,7 @@ extern "C" int bsm_stats(bsm_matrix_t A, bsm_stats_t *out) {
     return BSM_OK;
 }
 
-extern "C" int bsm_color(int64_t nlists, const int64_t *const *lists, const int64_t *lens,
+extern "C" int bsm_color(int64_t nlists, const int64_t *const *lists, const int64_t *lens, int algorithm,
                          int64_t *color_out, int64_t *ncolors) {
     try {
         if (nlists < 0 || (nlists > 0 && (!lists || !lens || !color_out)) || !ncolors)
@@ -1088,7 +1091,9 @@ extern "C" int bsm_color(int64_t nlists, const int64_t *const *lists, const int6
             lp[b] = lists[b];
             ln[b] = lens[b];
         }
-        auto classes = color_dsatur(lp, ln);
+        if (algorithm != BSM_COLOR_WORKSTREAM_DSATUR && algorithm != BSM_COLOR_DSATUR)
+            return fail(BSM_ERR_INVALID, "unknown colouring algorithm");
+        auto classes = algorithm == BSM_COLOR_DSATUR ? color_dsatur(lp, ln) : color_workstream_dsatur(lp, ln);
         for (size_t c = 0; c < classes.size(); c++)
             for (int64_t id : classes[c]) color_out[id - 1] = (int64_t)c;
         *ncolors = (int64_t)classes.size();

@@ -189,7 +189,8 @@ def partition_rows(nrows, rowkeys, weights, nparts):
     return part[:nb], [(int(a), int(b)) for a, b in zip(lo, hi)]
 
 
-def _options(scheduler, device, accumulate, own=None, transpose_image=False, devices=None, dev_blocks=False):
+def _options(scheduler, device, accumulate, own=None, transpose_image=False, devices=None, dev_blocks=False,
+             coloring=None):
     o = L.BsmOptions()
     L.lib().bsm_options_default(C.byref(o))
     o.scheduler = L.BSM_SCHED_SERIAL if isserial(scheduler) else L.BSM_SCHED_DYNAMIC
@@ -205,6 +206,7 @@ def _options(scheduler, device, accumulate, own=None, transpose_image=False, dev
             raise ValueError("devices= does not combine with own= / transpose_image=")
         o.ctx = Context.get(devices).ptr
     o.blocks_memspace = L.BSM_MEM_DEVICE if dev_blocks else L.BSM_MEM_HOST
+    o.coloring = _coloring_id(coloring)
     return o
 
 
@@ -357,7 +359,16 @@ def _unwrap(A):
 
 
 # ---- colouring adapter (reference src/coloring.jl:15-61) ----------------------------------------------
-coloringalgorithm = "DSATUR"  # the reference's const is GraphsColoring.WorkstreamDSATUR (not in its tree)
+# the reference's const (src/BlockSparseMatrices.jl:10); "DSATUR" selects plain DSATUR (GraphsColoring's names)
+coloringalgorithm = "WorkstreamDSATUR"
+_COLORING = {"WorkstreamDSATUR": L.BSM_COLOR_WORKSTREAM_DSATUR, "DSATUR": L.BSM_COLOR_DSATUR}
+
+
+def _coloring_id(algorithm):
+    name = coloringalgorithm if algorithm is None else algorithm
+    if name not in _COLORING:
+        raise ValueError(f"unknown coloring algorithm {name!r} (WorkstreamDSATUR, DSATUR)")
+    return _COLORING[name]
 
 
 class ColorInfo:
@@ -384,14 +395,15 @@ def conflicts(blocks):
 
 def color(info, algorithm=None):
     """color(conflictgraph(info); algorithm).colors: classes of 1-based block ids that share no
-    index.  Runs the library's deterministic DSATUR (bsm_color)."""
+    index (bsm_color; algorithm: "WorkstreamDSATUR" (default, like the reference) or "DSATUR")."""
     lists = info.conflictindices
     n = len(lists)
     lens = _i64([len(l) for l in lists])
     out = np.zeros(max(n, 1), dtype=np.int64)
     nc = C.c_int64(0)
     I = C.POINTER(C.c_int64)
-    L.check(L.lib().bsm_color(n, _ptrs(lists), lens.ctypes.data_as(I), out.ctypes.data_as(I), C.byref(nc)))
+    L.check(L.lib().bsm_color(n, _ptrs(lists), lens.ctypes.data_as(I), _coloring_id(algorithm),
+                              out.ctypes.data_as(I), C.byref(nc)))
     return [[int(b) + 1 for b in np.nonzero(out[:n] == c)[0]] for c in range(nc.value)]
 
 
@@ -421,7 +433,7 @@ class BlockSparseMatrix(AbstractBlockMatrix):
         n = _i64([b.shape[1] for b in self.blocks])
         ld = _lds(self.blocks)
         dev = _default_device() if device is None else device
-        o = _options(scheduler, dev, accumulate, own, transpose_image, devices, devb)
+        o = _options(scheduler, dev, accumulate, own, transpose_image, devices, devb, coloringalgorithm)
         h = C.c_void_p()
         I = C.POINTER(C.c_int64)
         L.check(L.lib().bsm_blocksparse_create(

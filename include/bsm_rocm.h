@@ -74,6 +74,9 @@ typedef enum {
                             stores (one launch, no atomics, bitwise reproducible) */
 } bsm_accumulate;
 
+/* colouring algorithms of bsm_color / bsm_options.coloring (GraphsColoring.jl's names) */
+typedef enum { BSM_COLOR_WORKSTREAM_DSATUR = 0, BSM_COLOR_DSATUR = 1 } bsm_coloring;
+
 #define BSM_DEVICE_CURRENT (-1)
 #define BSM_DEVICE_NONE (-2) /* analysis only: bookkeeping queries work, bsm_mul fails */
 
@@ -106,7 +109,11 @@ typedef struct {
      * runs as a kernel on that device and no matrix byte crosses PCIe.  Index lists, sizes and the
      * pointer arrays themselves are always host memory. */
     int64_t blocks_memspace;
-    int64_t reserved[2];
+    /* the reference's `coloringalgorithm=` keyword (src/blockmatrix.jl:67,86): which algorithm produces
+     * the colour classes reported through bsm_get_bookkeeping -- bsm_coloring, default
+     * BSM_COLOR_WORKSTREAM_DSATUR like the reference (src/BlockSparseMatrices.jl:10) */
+    int64_t coloring;
+    int64_t reserved[1];
 } bsm_options;
 
 /* ---- several GPUs of one node behind ONE handle -------------------------------------------------
@@ -293,18 +300,22 @@ int bsm_get_image(bsm_matrix_t A, int which, void *out, int64_t *nbytes);
 /* color(conflictgraph(ColorInfo(lists)); algorithm).colors -- reference src/coloring.jl:15-61 +
  * GraphsColoring.jl (compat 0.2.0, NOT in the reference tree; the reference's default algorithm is its
  * WorkstreamDSATUR, src/BlockSparseMatrices.jl:10).  Two lists conflict iff they share an index.
+ * algorithm: BSM_COLOR_WORKSTREAM_DSATUR -- the published WorkStream colouring (Turcksin, Kronbichler,
+ * Bangerth, ACM TOMS 43, 2016, section 3.2: zones = breadth-first layers of the conflict graph, DSATUR
+ * inside every zone, classes of the even and of the odd zones gathered largest-to-smallest) -- or
+ * BSM_COLOR_DSATUR (plain DSATUR on the whole graph).
  * CONTRACT: the classes returned here (and by BSM_BK_COLORS / _TRANSPOSECOLORS / _DIAGONALCOLORS) are
  * VALID -- they partition 1..nlists and no two lists of a class share an index, which is all the
- * reference's mul! relies on (src/blockmatrix.jl:233-245) -- and DETERMINISTIC, but they are NOT
- * claimed to be identical to GraphsColoring's: plain DSATUR with fixed tie-breaking (specification:
- * oracle/bsm_oracle.c:orc_color_dsatur, compared bit-exactly in tests/test_host_logic.py).  No
- * reference test inspects colour classes, and the serial scheduler's single class [1:nblocks]
- * (src/blockmatrix.jl:91-92) IS reproduced exactly.  The GPU product does not depend on them
- * (BSM_ACC_COLORED colours row GROUPS itself).
+ * reference's mul! relies on (src/blockmatrix.jl:233-245) -- and DETERMINISTIC (every tie-break is
+ * specified in oracle/bsm_oracle.c and compared bit-exactly in tests/test_host_logic.py).  They follow
+ * the published algorithm, but are NOT claimed to be identical to GraphsColoring's output: its source
+ * and version are not available here and no reference test inspects colour classes.  The serial
+ * scheduler's single class [1:nblocks] (src/blockmatrix.jl:91-92) IS reproduced exactly.  The GPU
+ * product does not depend on the classes (BSM_ACC_COLORED colours row GROUPS itself, with DSATUR).
  * lists[b] has lens[b] 1-based entries; color_out[b] receives the 0-based colour of list b;
  * *ncolors the number of colours. */
-int bsm_color(int64_t nlists, const int64_t *const *lists, const int64_t *lens, int64_t *color_out,
-              int64_t *ncolors);
+int bsm_color(int64_t nlists, const int64_t *const *lists, const int64_t *lens, int algorithm,
+              int64_t *color_out, int64_t *ncolors);
 
 int bsm_destroy(bsm_matrix_t A);
 

@@ -36,8 +36,8 @@ BlockSparseMatrices.isserial(::ROCmScheduler) = true   # no host colouring neede
 mutable struct BsmOptions           # mirrors bsm_options (72 bytes)
     struct_size::Int32; device::Int32; scheduler::Int32; accumulate::Int32
     validate::Int32; transpose_image::Int32; own_lo::Int64; own_hi::Int64
-    ctx::Ptr{Cvoid}; blocks_memspace::Int64
-    reserved::NTuple{2,Int64}
+    ctx::Ptr{Cvoid}; blocks_memspace::Int64; coloring::Int64
+    reserved::NTuple{1,Int64}
 end
 
 function _check(rc)
@@ -71,7 +71,7 @@ function _ctx(devices::Vector{Int32})
 end
 
 function _options(s::ROCmScheduler)
-    o = Ref(BsmOptions(0, 0, 0, 0, 0, 0, 0, 0, C_NULL, 0, (0, 0)))
+    o = Ref(BsmOptions(0, 0, 0, 0, 0, 0, 0, 0, C_NULL, 0, 0, (0,)))
     ccall((:bsm_options_default, libbsm), Cvoid, (Ref{BsmOptions},), o)
     o[].device = s.device
     o[].accumulate = s.accumulate

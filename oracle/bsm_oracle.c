@@ -174,6 +174,157 @@ int64_t orc_color_dsatur(int64_t nblocks, const int64_t *const *idx, const int64
     return ncolors;
 }
 
+/* ------------------------------------------------------------------------------------
+ * WorkstreamDSATUR -- the reference's default `coloringalgorithm` (src/BlockSparseMatrices.jl:10),
+ * which lives in GraphsColoring.jl (not in the reference tree).  Restated from the PUBLISHED
+ * algorithm: Turcksin, Kronbichler, Bangerth, "WorkStream -- a design pattern for multicore-enabled
+ * finite element computations", ACM TOMS 43(1), 2016, section 3.2, with every tie-break fixed here
+ * (this is the specification the HIP library's host analysis is compared against bit for bit; it is
+ * NOT claimed to equal GraphsColoring's output, whose source is not available):
+ *   1. zones: seed = smallest block id not yet in a zone; the next zone = every block not yet in a
+ *      zone that conflicts with a block of the current zone; repeat until it is empty, then the
+ *      next seed opens the next zone (zone numbers keep counting).  Zone k conflicts only with
+ *      zones k-1 and k+1.
+ *   2. every zone is coloured on its own with DSATUR (rule of orc_color_dsatur; saturation, degree
+ *      and forbidden colours count neighbours INSIDE the zone only).
+ *   3. gather, separately for the even and for the odd zones: the zone with the most colours (the
+ *      first such) founds the global classes of its parity, colour c -> class c; every other zone,
+ *      in zone order, sorts its colours by size (largest first, ties: smaller colour id) and hands
+ *      each to the global class with the fewest members among those it has not used yet (ties:
+ *      smaller class id).  Final colour ids: even classes first, then odd classes.
+ * O(V^2) dense form for small test cases.  Returns the number of colours.
+ * ---------------------------------------------------------------------------------- */
+int64_t orc_color_workstream(int64_t nblocks, const int64_t *const *idx, const int64_t *len,
+                             int64_t maxindex, int64_t *color_out) {
+    if (nblocks <= 0) return 0;
+    const int64_t n = nblocks;
+    unsigned char *adj = calloc((size_t)n * n, 1);
+    {
+        int64_t *cnt = calloc((size_t)maxindex + 2, sizeof(int64_t));
+        for (int64_t b = 0; b < n; b++)
+            for (int64_t k = 0; k < len[b]; k++) cnt[idx[b][k]]++;
+        int64_t *ptr = malloc(((size_t)maxindex + 2) * sizeof(int64_t));
+        ptr[0] = 0;
+        for (int64_t i = 0; i <= maxindex; i++) ptr[i + 1] = ptr[i] + cnt[i];
+        int64_t *inc = malloc((size_t)(ptr[maxindex + 1] + 1) * sizeof(int64_t));
+        memset(cnt, 0, ((size_t)maxindex + 2) * sizeof(int64_t));
+        for (int64_t b = 0; b < n; b++)
+            for (int64_t k = 0; k < len[b]; k++) inc[ptr[idx[b][k]] + cnt[idx[b][k]]++] = b;
+        for (int64_t i = 0; i <= maxindex; i++)
+            for (int64_t p = ptr[i]; p < ptr[i + 1]; p++)
+                for (int64_t q = ptr[i]; q < ptr[i + 1]; q++)
+                    if (inc[p] != inc[q]) adj[inc[p] * n + inc[q]] = 1;
+        free(inc);
+        free(ptr);
+        free(cnt);
+    }
+    /* 1. zones */
+    int64_t *zone = malloc((size_t)n * sizeof(int64_t));
+    for (int64_t v = 0; v < n; v++) zone[v] = -1;
+    int64_t nzones = 0;
+    for (int64_t seed = 0; seed < n; seed++) {
+        if (zone[seed] >= 0) continue;
+        zone[seed] = nzones;
+        for (;;) {
+            int64_t grew = 0;
+            for (int64_t v = 0; v < n; v++) {
+                if (zone[v] >= 0) continue;
+                for (int64_t w = 0; w < n; w++)
+                    if (zone[w] == nzones && adj[v * n + w]) {
+                        zone[v] = nzones + 1;
+                        grew = 1;
+                        break;
+                    }
+            }
+            nzones++;
+            if (!grew) break;
+        }
+    }
+    /* 2. DSATUR inside every zone */
+    int64_t *col = malloc((size_t)n * sizeof(int64_t));
+    for (int64_t v = 0; v < n; v++) col[v] = -1;
+    int64_t *zcolors = calloc((size_t)nzones, sizeof(int64_t));
+    unsigned char *used = malloc((size_t)n + 1);
+    for (int64_t z = 0; z < nzones; z++) {
+        for (;;) {
+            int64_t best = -1, bestsat = -1, bestdeg = -1;
+            for (int64_t v = 0; v < n; v++) {
+                if (zone[v] != z || col[v] >= 0) continue;
+                memset(used, 0, (size_t)n + 1);
+                int64_t sat = 0, deg = 0;
+                for (int64_t w = 0; w < n; w++)
+                    if (zone[w] == z && adj[v * n + w]) {
+                        deg++;
+                        if (col[w] >= 0 && !used[col[w]]) {
+                            used[col[w]] = 1;
+                            sat++;
+                        }
+                    }
+                if (best < 0 || sat > bestsat || (sat == bestsat && deg > bestdeg)) {
+                    best = v;
+                    bestsat = sat;
+                    bestdeg = deg;
+                }
+            }
+            if (best < 0) break;
+            memset(used, 0, (size_t)n + 1);
+            for (int64_t w = 0; w < n; w++)
+                if (zone[w] == z && adj[best * n + w] && col[w] >= 0) used[col[w]] = 1;
+            int64_t c = 0;
+            while (used[c]) c++;
+            col[best] = c;
+            if (c + 1 > zcolors[z]) zcolors[z] = c + 1;
+        }
+    }
+    /* 3. gather */
+    int64_t base = 0;
+    int64_t *gsize = malloc((size_t)n * sizeof(int64_t)), *csize = malloc((size_t)n * sizeof(int64_t));
+    int64_t *target = malloc((size_t)n * sizeof(int64_t));
+    for (int parity = 0; parity < 2; parity++) {
+        int64_t zmax = -1;
+        for (int64_t z = parity; z < nzones; z += 2)
+            if (zmax < 0 || zcolors[z] > zcolors[zmax]) zmax = z;
+        if (zmax < 0) continue;
+        const int64_t K = zcolors[zmax];
+        for (int64_t g = 0; g < K; g++) gsize[g] = 0;
+        for (int64_t v = 0; v < n; v++)
+            if (zone[v] == zmax) {
+                color_out[v] = base + col[v];
+                gsize[col[v]]++;
+            }
+        for (int64_t z = parity; z < nzones; z += 2) {
+            if (z == zmax) continue;
+            for (int64_t c = 0; c < zcolors[z]; c++) csize[c] = 0, target[c] = -1;
+            for (int64_t v = 0; v < n; v++)
+                if (zone[v] == z) csize[col[v]]++;
+            memset(used, 0, (size_t)n + 1);
+            for (int64_t step = 0; step < zcolors[z]; step++) {
+                int64_t c = -1; /* largest not yet placed colour, ties: smaller id */
+                for (int64_t k = 0; k < zcolors[z]; k++)
+                    if (target[k] < 0 && (c < 0 || csize[k] > csize[c])) c = k;
+                int64_t g = -1; /* smallest unused global class, ties: smaller id */
+                for (int64_t k = 0; k < K; k++)
+                    if (!used[k] && (g < 0 || gsize[k] < gsize[g])) g = k;
+                used[g] = 1;
+                gsize[g] += csize[c];
+                target[c] = g;
+            }
+            for (int64_t v = 0; v < n; v++)
+                if (zone[v] == z) color_out[v] = base + target[col[v]];
+        }
+        base += K;
+    }
+    free(target);
+    free(csize);
+    free(gsize);
+    free(used);
+    free(zcolors);
+    free(col);
+    free(zone);
+    free(adj);
+    return base;
+}
+
 /* Validity check of any colouring against the conflict definition of reference
  * src/coloring.jl:58-60.  Returns 0 when valid, else 1 + the first offending index. */
 int64_t orc_color_check(int64_t nblocks, const int64_t *const *idx, const int64_t *len,

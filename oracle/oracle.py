@@ -111,6 +111,20 @@ class Oracle:
                                        col.ctypes.data_as(_I64P))
         return [list(np.nonzero(col == c)[0] + 1) for c in range(nc)]
 
+    def color_workstream(self, lists):
+        """WorkstreamDSATUR per the published algorithm (orc_color_workstream) -> classes of 1-based ids."""
+        lists = [_i64(l) for l in lists]
+        n = len(lists)
+        if n == 0:
+            return []
+        lens = _i64([len(l) for l in lists])
+        maxindex = int(max([int(l.max()) for l in lists if len(l)] + [0]))
+        col = np.zeros(n, np.int64)
+        self.lib.orc_color_workstream.restype = C.c_int64
+        nc = self.lib.orc_color_workstream(C.c_int64(n), _ptr_array(lists), lens.ctypes.data_as(_I64P),
+                                           C.c_int64(maxindex), col.ctypes.data_as(_I64P))
+        return [list(np.nonzero(col == c)[0] + 1) for c in range(nc)]
+
     def color_check(self, lists, colors):
         """colors: list of classes (1-based ids). True iff valid partition + conflict-free."""
         lists = [_i64(l) for l in lists]

@@ -77,13 +77,17 @@ def test_colouring_equals_oracle_spec_and_is_valid(bsm, oracle, key):
     for got, lists in ((S.offdiagonalcolors, p["rowindices"]), (S.transposeoffdiagonalcolors, p["colindices"]),
                        (S.diagonalcolors, p["diagonalindices"])):
         assert oracle.color_check(lists, got)
-        assert got == oracle.color_dsatur(lists)  # deterministic DSATUR spec, bit-exact
+        assert got == oracle.color_workstream(lists)  # WorkstreamDSATUR (the reference's default), bit-exact vs the spec
     assert bsm.offdiagonalcolors(bsm.adjoint(S)) == S.transposeoffdiagonalcolors  # :307-325
     q = fixture_as_blocksparse(key)
     B = bsm.BlockSparseMatrix(q["blocks"], q["rowindices"], q["colindices"], q["size"],
                               scheduler=bsm.DynamicScheduler(), device=NODEV)
-    assert B.colors == oracle.color_dsatur(q["rowindices"])
-    assert B.transposecolors == oracle.color_dsatur(q["colindices"])
+    assert B.colors == oracle.color_workstream(q["rowindices"])
+    assert B.transposecolors == oracle.color_workstream(q["colindices"])
+    D = bsm.BlockSparseMatrix(q["blocks"], q["rowindices"], q["colindices"], q["size"],
+                              scheduler=bsm.DynamicScheduler(), coloringalgorithm="DSATUR", device=NODEV)
+    assert D.colors == oracle.color_dsatur(q["rowindices"])  # the `coloringalgorithm` keyword, src/blockmatrix.jl:67
+    assert D.transposecolors == oracle.color_dsatur(q["colindices"])
 
 
 def test_colorinfo_adapter(bsm, oracle):
@@ -93,7 +97,11 @@ def test_colorinfo_adapter(bsm, oracle):
     ids, functor, rng = bsm.conflicts(info)
     assert list(ids) == [1, 2, 3, 4] and list(functor(2)) == [2, 3] and rng == range(1, 10)
     classes = bsm.color(info)
+    assert classes == oracle.color_workstream(lists) and oracle.color_check(lists, classes)
+    classes = bsm.color(info, "DSATUR")
     assert classes == oracle.color_dsatur(lists) and oracle.color_check(lists, classes)
+    with pytest.raises(ValueError):
+        bsm.color(info, "Greedy")
 
 
 def test_colouring_random_lists(bsm, oracle):
@@ -104,8 +112,35 @@ def test_colouring_random_lists(bsm, oracle):
         blocks = [np.ones((len(l), 1)) for l in lists]
         A = bsm.BlockSparseMatrix(blocks, lists, [[1]] * nb, (40, 40), scheduler=bsm.DynamicScheduler(),
                                   device=NODEV)
-        assert A.colors == oracle.color_dsatur(lists)
+        assert A.colors == oracle.color_workstream(lists)
         assert oracle.color_check(lists, A.colors)
+        assert bsm.color(bsm.ColorInfo(lists), "DSATUR") == oracle.color_dsatur(lists)
+
+
+def test_workstream_colouring_structure(bsm, oracle):
+    """WorkstreamDSATUR as published (Turcksin, Kronbichler, Bangerth 2016, section 3.2) on graphs whose
+    zones can be written down by hand."""
+    # a path 1-2-3-4-5-6 (list k = {k, k+1}): zones {1},{2},...,{6}; one colour per zone; the even
+    # zones (blocks 1,3,5) gather into one class, the odd ones (2,4,6) into the other
+    path = [[k, k + 1] for k in range(1, 7)]
+    assert bsm.color(bsm.ColorInfo(path)) == [[1, 3, 5], [2, 4, 6]] == oracle.color_workstream(path)
+    # two components: a triangle {1,2,3} on index 1 and an isolated block 4.  Zones: {1}, {2,3}, {4}:
+    # zone 1 needs two colours; zone 2 (the second seed) is even like zone 0 and joins its smallest class
+    tri = [[1], [1], [1], [9]]
+    got = bsm.color(bsm.ColorInfo(tri))
+    assert got == oracle.color_workstream(tri) and oracle.color_check(tri, got)
+    assert got == [[1, 4], [2], [3]]
+    # star: centre block 1 touches every index; leaves are pairwise independent
+    star = [[1, 2, 3, 4, 5]] + [[k] for k in range(1, 6)]
+    assert bsm.color(bsm.ColorInfo(star)) == [[1], [2, 3, 4, 5, 6]]
+    # larger random graphs: valid, deterministic, equal to the oracle's independent restatement
+    rng = np.random.default_rng(11)
+    for _ in range(20):
+        nb = int(rng.integers(2, 60))
+        lists = [rng.choice(50, size=int(rng.integers(1, 5)), replace=False) + 1 for _ in range(nb)]
+        got = bsm.color(bsm.ColorInfo(lists))
+        assert got == oracle.color_workstream(lists) and oracle.color_check(lists, got)
+        assert sorted(b for c in got for b in c) == list(range(1, nb + 1))
 
 
 # ---- nnz / size / accessors ---------------------------------------------------------------------
@@ -446,7 +481,7 @@ def test_c_abi_rejects_bad_arguments(bsm):
     lp = (C.c_void_p * 1)(lst.ctypes.data)
     out = np.zeros(1, dtype=np.int64)
     nc = C.c_int64(0)
-    assert lib.bsm_color(1, lp, p(two), p(out), C.byref(nc)) == -1
+    assert lib.bsm_color(1, lp, p(two), 0, p(out), C.byref(nc)) == -1
 
 
 def test_auto_mode_splits_only_large_deep_operators(bsm):
