@@ -150,7 +150,7 @@ class Oracle:
 
     # -- products --------------------------------------------------------------------
     def bsm_mul(self, op, blocks, rowidx, colidx, colors, x, y, alpha=1, beta=0,
-                strong_zero=True):
+                strong_zero=True, prepare=False):
         dt = np.dtype(x.dtype)
         fb = _fblocks(blocks, dt)
         ri = [_i64(r) for r in rowidx]
@@ -163,15 +163,19 @@ class Oracle:
         assert y.dtype == dt and y.flags.c_contiguous
         fn = getattr(self.lib, "orc_bsm_mul_" + _SFX[dt])
         fn.restype = None
-        fn(C.c_int(op), C.c_int64(len(y)), C.c_int64(len(fb)), _ptr_array(fb),
-           m.ctypes.data_as(_I64P), n.ctypes.data_as(_I64P), ld.ctypes.data_as(_I64P),
-           _ptr_array(ri), _ptr_array(ci), C.c_int64(nc), cp.ctypes.data_as(_I64P),
-           cb.ctypes.data_as(_I64P), C.c_void_p(x.ctypes.data), C.c_void_p(y.ctypes.data),
-           _scalar(dt, alpha), _scalar(dt, beta), C.c_int(1 if strong_zero else 0))
+        args = [C.c_int(op), C.c_int64(len(y)), C.c_int64(len(fb)), _ptr_array(fb),
+                m.ctypes.data_as(_I64P), n.ctypes.data_as(_I64P), ld.ctypes.data_as(_I64P),
+                _ptr_array(ri), _ptr_array(ci), C.c_int64(nc), cp.ctypes.data_as(_I64P),
+                cb.ctypes.data_as(_I64P), C.c_void_p(x.ctypes.data), C.c_void_p(y.ctypes.data),
+                _scalar(dt, alpha), _scalar(dt, beta), C.c_int(1 if strong_zero else 0)]
+        if prepare:  # everything marshalled once: the returned closure is one C call (timing loops)
+            keep = (fb, ri, ci, m, n, ld, cp, cb, x, y)
+            return lambda: fn(*args) or keep and None
+        fn(*args)
         return y
 
     def sym_mul(self, op, diag, didx, off, rowidx, colidx, colorsets, x, y, alpha=1, beta=0,
-                strong_zero=True):
+                strong_zero=True, prepare=False):
         """colorsets = (offdiagonalcolors, transposeoffdiagonalcolors, diagonalcolors)."""
         dt = np.dtype(x.dtype)
         fd = _fblocks(diag, dt)
@@ -192,17 +196,21 @@ class Oracle:
         assert y.dtype == dt and y.flags.c_contiguous
         fn = getattr(self.lib, "orc_sym_mul_" + _SFX[dt])
         fn.restype = None
-        fn(C.c_int(op), C.c_int64(len(y)), C.c_int64(len(fd)), _ptr_array(fd),
-           ds.ctypes.data_as(_I64P), dld.ctypes.data_as(_I64P), _ptr_array(di),
-           C.c_int64(len(fo)), _ptr_array(fo), m.ctypes.data_as(_I64P),
-           n.ctypes.data_as(_I64P), ld.ctypes.data_as(_I64P), _ptr_array(ri), _ptr_array(ci),
-           ncol.ctypes.data_as(_I64P), cptr, cblk, C.c_void_p(x.ctypes.data),
-           C.c_void_p(y.ctypes.data), _scalar(dt, alpha), _scalar(dt, beta),
-           C.c_int(1 if strong_zero else 0))
+        args = [C.c_int(op), C.c_int64(len(y)), C.c_int64(len(fd)), _ptr_array(fd),
+                ds.ctypes.data_as(_I64P), dld.ctypes.data_as(_I64P), _ptr_array(di),
+                C.c_int64(len(fo)), _ptr_array(fo), m.ctypes.data_as(_I64P),
+                n.ctypes.data_as(_I64P), ld.ctypes.data_as(_I64P), _ptr_array(ri), _ptr_array(ci),
+                ncol.ctypes.data_as(_I64P), cptr, cblk, C.c_void_p(x.ctypes.data),
+                C.c_void_p(y.ctypes.data), _scalar(dt, alpha), _scalar(dt, beta),
+                C.c_int(1 if strong_zero else 0)]
+        if prepare:
+            keep = (fd, fo, di, ri, ci, ds, dld, m, n, ld, csr, ncol, x, y)
+            return lambda: fn(*args) or keep and None
+        fn(*args)
         return y
 
     def vbcrs_mul(self, op, blocks, rowptr, colindices, rowindices, x, y, alpha=1, beta=0,
-                  strong_zero=True, parallel=False):
+                  strong_zero=True, parallel=False, prepare=False):
         """blocks already in VBCRS (sorted) order; rowptr/colindices/rowindices 1-based."""
         dt = np.dtype(x.dtype)
         fb = _fblocks(blocks, dt)
@@ -223,6 +231,9 @@ class Oracle:
             fn = getattr(self.lib, "orc_vbcrs_mul_t_" + _SFX[dt])
             args = [C.c_int(op)] + args
         fn.restype = None
+        if prepare:
+            keep = (fb, m, n, ld, rp, ci, ri, x, y)
+            return lambda: fn(*args) or keep and None
         fn(*args)
         return y
 

@@ -85,24 +85,26 @@ def single_color(n):
     return [list(range(1, n + 1))]
 
 
-def oracle_mul(orc, problem, op, x, y0, alpha=1, beta=0, strong=True, colorsets=None):
-    """y = alpha*op(A)*x + beta*y0 through the CPU oracle (reference loop structure)."""
+def oracle_mul(orc, problem, op, x, y0, alpha=1, beta=0, strong=True, colorsets=None, prepare=False):
+    """y = alpha*op(A)*x + beta*y0 through the CPU oracle (reference loop structure).
+    prepare=True: returns a zero-argument closure with every argument marshalled once (timing loops)."""
     y = np.array(y0, copy=True)
     k = problem["kind"]
     if k == "blocksparse":
         nb = len(problem["blocks"])
         cs = colorsets if colorsets is not None else (single_color(nb), single_color(nb))
         return orc.bsm_mul(op, problem["blocks"], problem["rowindices"], problem["colindices"],
-                           cs[0] if op == N else cs[1], x, y, alpha, beta, strong)
+                           cs[0] if op == N else cs[1], x, y, alpha, beta, strong, prepare=prepare)
     if k == "symmetric":
         nd, no = len(problem["diagonals"]), len(problem["offdiagonals"])
         cs = colorsets if colorsets is not None else (single_color(no), single_color(no), single_color(nd))
         return orc.sym_mul(op, problem["diagonals"], problem["diagonalindices"], problem["offdiagonals"],
-                           problem["rowindices"], problem["colindices"], cs, x, y, alpha, beta, strong)
+                           problem["rowindices"], problem["colindices"], cs, x, y, alpha, beta, strong,
+                           prepare=prepare)
     if k == "vbcrs":
         perm, rowptr, colind, rowind = orc.vbcrs_build(problem["rowstart"], problem["colstart"])
         blocks = [problem["blocks"][p - 1] for p in perm]
-        return orc.vbcrs_mul(op, blocks, rowptr, colind, rowind, x, y, alpha, beta, strong)
+        return orc.vbcrs_mul(op, blocks, rowptr, colind, rowind, x, y, alpha, beta, strong, prepare=prepare)
     raise ValueError(k)
 
 
