@@ -209,12 +209,12 @@ class RowPartitioned:
                 a, b = max(nlo, rlo), min(nhi, rhi)  # what I read of rank r's
                 if a <= b:
                     recvs.append((r, x[a - 1:b]))
-            self._xplan = (x, sends, recvs)
-        _, sends, recvs = self._xplan
-        if sends or recvs:
-            self._host_mediated_fence(x)
             ops = [dist.P2POp(dist.isend, v, r, group=self.group) for r, v in sends]
             ops += [dist.P2POp(dist.irecv, v, r, group=self.group) for r, v in recvs]
+            self._xplan = (x, ops)  # the descriptors point at fixed views of x: built once
+        ops = self._xplan[1]
+        if ops:
+            self._host_mediated_fence(x)
             for req in dist.batch_isend_irecv(ops):
                 req.wait()
         return x
@@ -242,7 +242,9 @@ class RowPartitioned:
                 a, b = max(rtlo, olo), min(rthi, ohi)  # rank r's contributions to my rows
                 if a <= b:
                     recvs.append((r, a, b, torch.empty(b - a + 1, dtype=w.dtype, device=w.device)))
-            self._plan = (sends, recvs)
+            ops = [dist.P2POp(dist.isend, v, r, group=self.group) for r, v in sends]
+            ops += [dist.P2POp(dist.irecv, buf, r, group=self.group) for r, _, _, buf in recvs]
+            self._plan = (ops, recvs)  # the descriptors point at fixed views / buffers: built once
         return self._plan
 
     def _host_mediated_fence(self, t):
@@ -301,11 +303,9 @@ class RowPartitioned:
                 lm(w, x, alpha, False)  # strong zero over the touched range, then accumulate
             elif ohi >= olo:
                 w[olo - 1:ohi] = 0
-            sends, recvs = self._halo_plan(w, ranges)
-            if halo and (sends or recvs):
+            ops, recvs = self._halo_plan(w, ranges)
+            if halo and ops:
                 self._host_mediated_fence(w)
-                ops = [dist.P2POp(dist.isend, v, r, group=self.group) for r, v in sends]
-                ops += [dist.P2POp(dist.irecv, buf, r, group=self.group) for r, _, _, buf in recvs]
                 for req in dist.batch_isend_irecv(ops):
                     req.wait()
             if ohi >= olo:
