@@ -26,11 +26,8 @@ Tunables Tunables::from_env() {
     t.wgitem_max_bytes = geti("BSM_WGITEM_MAX_BYTES", t.wgitem_max_bytes);
     t.pack_threads = (int)geti("BSM_PACK_THREADS", t.pack_threads);
     t.wg_order = (int)geti("BSM_ORDER", t.wg_order);
-    t.lds_window = (int)geti("BSM_WINDOW", t.lds_window);
     t.deep_group_bytes = geti("BSM_DEEP_GROUP_BYTES", t.deep_group_bytes);
     t.deep_total_bytes = geti("BSM_DEEP_TOTAL_BYTES", t.deep_total_bytes);
-    t.chunk_rows = (int)geti("BSM_CHUNK_ROWS", t.chunk_rows);
-    if (t.chunk_rows != 8 && t.chunk_rows != 16 && t.chunk_rows != 32) t.chunk_rows = kMaxRowsPerChunk;
     t.window_bytes = (size_t)geti("BSM_UPLOAD_WINDOW_BYTES", (int64_t)t.window_bytes);
     if (t.pack_threads < 1) t.pack_threads = 1;
     return t;

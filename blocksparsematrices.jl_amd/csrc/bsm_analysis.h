@@ -55,12 +55,12 @@ struct Tunables {
     int64_t split2_bytes = 8 << 10;     // row groups at least this big get 2 waves
     int64_t split4_bytes = 24 << 10;    // ... and 4 waves
     int64_t wgitem_max_bytes = 32 << 10;   // non-exclusive groups are cut into items this big (4 waves x one 8 KB iteration)
-    int chunk_rows = kMaxRowsPerChunk;  // blocks taller than this are cut into chunks (BSM_CHUNK_ROWS: 8/16/32/64)
+    int chunk_rows = kMaxRowsPerChunk;  // blocks taller than this are cut into chunks
     int64_t deep_group_bytes = 128 << 10;  // auto mode: row groups above this are "deep" (BSM_DEEP_GROUP_BYTES)
     int64_t deep_total_bytes = 64 << 20;  // ... and only operators at least this big are split (BSM_DEEP_TOTAL_BYTES)
     int pack_threads = 8;
     size_t window_bytes = 64u << 20;  // staging window of a streamed upload (BSM_UPLOAD_WINDOW_BYTES)
-    int lds_window = 1;  // LDS y window for locality-packed small symmetric row groups (BSM_WINDOW)
+    int lds_window = 1;  // LDS y window for locality-packed small symmetric row groups
     int wg_order = -1;  // workgroup dispatch order (BSM_ORDER): -1 auto (snake for exclusive images), 0 plain largest first
     static Tunables from_env();
 };

@@ -1013,17 +1013,9 @@ static hipError_t launch_multi_typed(const DeviceImage &img, bool opT, bool conj
     // kernels keep L = 4 loads per lane in flight instead of 8: with 8 accumulators and 8 x values
     // per lane the registers, i.e. the resident waves, are worth more than the deeper load queue
     // (fp64 fused: 143 -> 103 VGPRs; C3 3.0x -> 3.3x, 8-28-row blocks 2.0x -> 2.4x over 8 products).
-    static const int lm = [] {
-        const char *v = std::getenv("BSM_LMULTI");
-        return v ? std::atoi(v) : 4;
-    }();
     while (e == hipSuccess && nrhs - k >= 8) {
-        if (lm == 8)
-            e = launch_typed_multi<T, 8, 8>(img, opT, conj, xd + k * ldx, ldx, yd + k * ldy, ldy, alpha, beta,
-                                            strong_zero, stream);
-        else
-            e = launch_typed_multi<T, 4, 8>(img, opT, conj, xd + k * ldx, ldx, yd + k * ldy, ldy, alpha, beta,
-                                            strong_zero, stream);
+        e = launch_typed_multi<T, 4, 8>(img, opT, conj, xd + k * ldx, ldx, yd + k * ldy, ldy, alpha, beta,
+                                        strong_zero, stream);
         k += 8;
     }
     if (e == hipSuccess && nrhs - k >= 4) {
