@@ -27,6 +27,12 @@ def test_library_exports_every_declared_symbol(bsm):
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/bsm_rocm.h but not exported"
     assert sorted(L.EXPORTS) == declared
+    # ... and the bench / test utility header
+    syn = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "bsm_synth.h")).read(), flags=re.S)
+    syn_declared = sorted(set(re.findall(r"\b(bsm_synth_[a-z_]+)\s*\(", syn)))
+    assert syn_declared == sorted(L.SYNTH_EXPORTS)
+    for name in syn_declared:
+        assert hasattr(lib, name), f"{name} declared in include/bsm_synth.h but not exported"
     assert b"gfx950" in lib.bsm_version()
     assert C.sizeof(L.BsmOptions) == 72 and C.sizeof(L.BsmStats) == 128
 
