@@ -174,3 +174,74 @@ def test_rowcolvals_from_the_device_image(torch_cuda, bsm):
     r, c, v = bsm.rowcolvals_device(bsm.adjoint(A), device=False)
     got = sp.coo_matrix((v, (r - 1, c - 1)), shape=bsm.size(A)).tocsc()
     assert abs(got - bsm.sparse(A).conj().T).max() == 0
+
+
+def test_config5_FULL_size_properties_on_one_gpu(torch_cuda, bsm):
+    """BASELINE.json configs[4] at its FULL size (SymmetricBlockMatrix 5M x 5M, 36.8 k diagonal + 147 k
+    off-diagonal blocks of 16-256 rows, 28.6 GB fp64) -- generated in HBM, packed by the device-side
+    packer -- through size-independent properties: symmetry S x = S^T x, <S x, z> = <x, S z>, linearity,
+    alpha / beta, and the SAME operator spread over two (virtual) devices (a different row partition,
+    halo exchange) giving the same product.  The oracle cannot finish this size in seconds; the
+    partitioned and reduced-size cases against it are above / in test_gpu_parity.py."""
+    torch = torch_cuda
+    S_ = bsm.synthetic
+    p = S_.config5(on_device=True)
+    n = p["size"][0]
+    assert n == 5_000_000 and len(p["offdiagonals"]) > 140_000
+    A = S_.build(p)
+    assert A.stats()["stored_entries"] * 8 > 28e9
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.rand(n, dtype=torch.float64, device="cuda", generator=g) - 0.5
+    z = torch.rand(n, dtype=torch.float64, device="cuda", generator=g) - 0.5
+    sx, stx, sz, comb = (torch.full_like(x, float("nan")) for _ in range(4))
+    bsm.mul(sx, A, x)
+    bsm.mul(stx, bsm.transpose(A), x)
+    bsm.mul(sz, A, z)
+    bsm.mul(comb, A, 2 * x - 3 * z)
+    scale = float(sx.abs().max())
+    assert scale > 0 and bool(torch.isfinite(sx).all())
+    assert float((stx - sx).abs().max()) < 1e-12 * scale
+    assert abs(float(torch.dot(sx, z)) - float(torch.dot(x, sz))) < 1e-11 * abs(float(torch.dot(sx, z)))
+    assert float((comb - (2 * sx - 3 * sz)).abs().max()) < 1e-12 * scale
+    y0 = torch.rand(n, dtype=torch.float64, device="cuda", generator=g)
+    ab = y0.clone()
+    bsm.mul(ab, A, x, -0.5, 2.0)
+    assert float((ab - (-0.5 * sx + 2.0 * y0)).abs().max()) < 1e-12 * scale
+    del A
+    torch.cuda.empty_cache()
+    B = S_.build(p, devices=[0, 0])  # two parts, x / partial-y halo over the (virtual) link
+    parts = B.parts()
+    assert parts[1]["touched"][0] < parts[1]["own"][0]
+    y2 = torch.full_like(x, float("nan"))
+    bsm.mul(y2, B, x)
+    assert float((y2 - sx).abs().max()) < 1e-12 * scale
+
+
+def test_config4_FULL_size_properties_on_one_gpu(torch_cuda, bsm):
+    """BASELINE.json configs[3] at its FULL size (VBCRS 2M x 2M, 250 000 blocks of 128x128 fp32, 16.4 GB):
+    adjoint identity <A x, z> = <x, A^T z>, linearity, and the row-partitioned multi-device handle."""
+    torch = torch_cuda
+    S_ = bsm.synthetic
+    p = S_.config4(on_device=True)
+    n = p["size"][0]
+    assert n == 2_000_000 and len(p["blocks"]) == 250_000
+    A = S_.build(p)
+    g = torch.Generator(device="cuda").manual_seed(4)
+    x = torch.rand(n, dtype=torch.float32, device="cuda", generator=g) - 0.5
+    z = torch.rand(n, dtype=torch.float32, device="cuda", generator=g) - 0.5
+    ax, az, atz, comb = (torch.full_like(x, float("nan")) for _ in range(4))
+    bsm.mul(ax, A, x)
+    bsm.mul(az, A, z)
+    bsm.mul(atz, bsm.transpose(A), z)
+    bsm.mul(comb, A, 2 * x - 3 * z)
+    scale = float(ax.abs().max())
+    assert scale > 0 and bool(torch.isfinite(ax).all())
+    lhs, rhs = float(torch.dot(ax.double(), z.double())), float(torch.dot(x.double(), atz.double()))
+    assert abs(lhs - rhs) < 1e-4 * max(abs(lhs), float(ax.double().norm() * z.double().norm()) * 1e-3)
+    assert float((comb - (2 * ax - 3 * az)).abs().max()) < 2e-5 * scale
+    del A
+    torch.cuda.empty_cache()
+    B = S_.build(p, devices=[0, 0, 0])
+    y2 = torch.full_like(x, float("nan"))
+    bsm.mul(y2, B, x)
+    assert float((y2 - ax).abs().max()) < 2e-5 * scale
