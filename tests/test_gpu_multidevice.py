@@ -163,3 +163,44 @@ def test_tensor_on_the_wrong_device_is_an_error_not_a_fault(torch_cuda, bsm):
     x = torch_cuda.from_numpy(prob["x"]).cuda()
     with pytest.raises(ValueError, match="lives on cuda"):
         bsm.mul(torch_cuda.zeros_like(x), A, x)
+
+
+def test_concurrent_products_on_one_multi_device_handle(torch_cuda, bsm, oracle):
+    """Two host threads drive the SAME four-part handle (worker-thread fan-out) with different x / y:
+    the handle serialises the products (its work vectors belong to it), every result must be exact."""
+    import threading
+    torch = torch_cuda
+    prob = bsm.synthetic.config5(n=30_000, lo=16, hi=96, halfband=3)
+    A = bsm.synthetic.build(prob, devices=[0, 0, 0, 0])
+    n = prob["size"][0]
+    rng = np.random.default_rng(9)
+    xs = [rng.standard_normal(n) for _ in range(2)]
+    refs = [oracle_mul(oracle, prob, N, x, np.zeros(n)) for x in xs]
+    errs = []
+
+    def worker(k):
+        try:
+            xd = torch.from_numpy(xs[k]).cuda()
+            s = torch.cuda.Stream()
+            with torch.cuda.stream(s):
+                for it in range(60):
+                    if it % 2:
+                        yd = torch.full((n,), float("nan"), dtype=torch.float64, device="cuda")
+                        bsm.mul(yd, A, xd)
+                        s.synchronize()
+                        got = yd.cpu().numpy()
+                    else:
+                        got = np.full(n, np.nan)
+                        bsm.mul(got, A, xs[k])
+                    e = relerr(got, refs[k])
+                    if not e < 1e-12:
+                        errs.append((k, it, e))
+        except Exception as ex:  # pragma: no cover
+            errs.append((k, repr(ex)))
+
+    th = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=120)
+    assert not errs, errs[:3]
