@@ -948,15 +948,8 @@ extern "C" int bsm_mul_multi(bsm_matrix_t A, int op, int64_t nrhs, const void *X
     const long long ylen = (op == 0 ? A->img.nrows : A->img.ncols);
     if (ldx < std::max<long long>(xlen, 1) || ldy < std::max<long long>(ylen, 1))
         return fail(BSM_ERR_INVALID, "leading dimension smaller than the vector length");
-    if (A->dist) {  // multi-device handles: one fan-out per column
-        const size_t esz = (size_t)A->an.es;
-        for (int64_t k = 0; k < nrhs; k++) {
-            int rc = dist_mul(A, op, (const char *)X + (size_t)k * ldx * esz, (char *)Y + (size_t)k * ldy * esz, alpha,
-                              beta, beta_strong_zero, memspace, (hipStream_t)stream);
-            if (rc != BSM_OK) return rc;
-        }
-        return BSM_OK;
-    }
+    if (A->dist)  // multi-device handles: every device streams its part once per batch of <= 8 columns
+        return dist_mul_multi(A, op, nrhs, X, ldx, Y, ldy, alpha, beta, beta_strong_zero, memspace, (hipStream_t)stream);
     const bool use_t = (op != BSM_OP_N) && A->has_t;
     const DeviceImage &img = use_t ? A->img_t : A->img;
     const bool opT = (op != BSM_OP_N) && !use_t;

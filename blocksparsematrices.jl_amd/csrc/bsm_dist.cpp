@@ -139,6 +139,8 @@ struct DistState {
     bool symmetric = false;  // op(A) has A's structure: every op runs ALONG the partition
     std::vector<std::unique_ptr<Part>> parts;
     Plan plan_n, plan_t;
+    size_t vlen = 0;  // elements per column of the parts' x / work buffers
+    int kcap = 1;     // columns those buffers hold (grows with bsm_mul_multi)
     std::mutex mu;  // one product in flight per handle: the work vectors belong to the handle
     std::map<int, hipEvent_t> ev_x;  // "x and y are ready" on the caller's stream, one event per device
     void *d_res = nullptr;  // numeric beta, y on a device: segments of remote parts wait here
@@ -365,7 +367,8 @@ int dist_create(bsm_matrix_s *A, bsm_ctx_s *ctx, int mtype, int dtype, int64_t n
     finish_plan(D.plan_n, touched_n, D.es);
     finish_plan(D.plan_t, touched_t, D.es);
 
-    const size_t vec_bytes = (size_t)std::max<long long>(std::max(nrows, ncols), 1) * D.es + 16;
+    D.vlen = (size_t)std::max<long long>(std::max(nrows, ncols), 1) + 2;
+    const size_t vec_bytes = D.vlen * D.es;
     for (int p = 0; p < P; p++) {
         Part &pt = *D.parts[p];
         DeviceGuard g;
@@ -407,8 +410,10 @@ int dist_create(bsm_matrix_s *A, bsm_ctx_s *ctx, int mtype, int dtype, int64_t n
     return BSM_OK;
 }
 
-int dist_mul(bsm_matrix_s *A, int op, const void *x, void *y, const void *alpha, const void *beta,
-             int beta_strong_zero, int memspace, hipStream_t stream) {
+// K <= 8 right-hand sides in one fan-out (K = 1: bsm_mul).  X / Y: column k at x + k * ldx / y + k * ldy
+// elements.  The part buffers hold column k at k * vlen elements.
+static int dist_mul_k(bsm_matrix_s *A, int op, int K, const void *x, long long ldx, void *y, long long ldy,
+                      const void *alpha, const void *beta, int beta_strong_zero, int memspace, hipStream_t stream) {
     DistState &D = *A->dist;
     std::lock_guard<std::mutex> lock(D.mu);
     const int P = (int)D.parts.size();
@@ -418,6 +423,7 @@ int dist_mul(bsm_matrix_s *A, int op, const void *x, void *y, const void *alpha,
     const bool conj = (op == BSM_OP_C);
     const size_t es = (size_t)D.es;
     const long long ylen = (op == BSM_OP_N) ? D.nrows : D.ncols;
+    const size_t vlen = D.vlen;  // elements per column of the part buffers
     const char *xb = (const char *)x;
     char *yb = (char *)y;
     const bool host = (memspace == BSM_MEM_HOST);
@@ -428,6 +434,25 @@ int dist_mul(bsm_matrix_s *A, int op, const void *x, void *y, const void *alpha,
         e = (call);                               \
         if (e != hipSuccess) return hip_fail(e, what); \
     } while (0)
+
+    // part buffers for K columns (grow-only; the parts are idle: products on one handle are serialised)
+    if (K > D.kcap) {
+        for (int p = 0; p < P; p++) {
+            Part &pt = *D.parts[p];
+            DeviceGuard g;
+            DCHECK(g.enter(pt.device), "hipSetDevice");
+            DCHECK(hipStreamSynchronize(pt.stream), "hipStreamSynchronize");
+            for (void **q : {&pt.d_x, &pt.d_w, &pt.d_recv}) {
+                if (*q) (void)hipFree(*q);
+                *q = nullptr;
+            }
+            DCHECK(hipMalloc(&pt.d_x, vlen * es * K), "multi-device buffers");
+            DCHECK(hipMalloc(&pt.d_w, vlen * es * K), "multi-device buffers");
+            const size_t rb = std::max(D.plan_n.recv_bytes[p], D.plan_t.recv_bytes[p]);
+            if (rb) DCHECK(hipMalloc(&pt.d_recv, rb * K), "multi-device buffers");
+        }
+        D.kcap = K;
+    }
 
     int cur = 0;
     DCHECK(hipGetDevice(&cur), "hipGetDevice");
@@ -455,11 +480,12 @@ int dist_mul(bsm_matrix_s *A, int op, const void *x, void *y, const void *alpha,
         DCHECK(hipEventRecord(ev_ready, stream), "hipEventRecord");  // x (and the incoming y) are ready
     }
     const bool numeric_beta = !beta_strong_zero;
-    if (numeric_beta && host && D.h_res.size() < (size_t)ylen * es) D.h_res.resize((size_t)ylen * es);
+    const size_t res_need = (size_t)ylen * es * K;  // staging of numeric-beta results: column k at k * ylen
+    if (numeric_beta && host && D.h_res.size() < res_need) D.h_res.resize(res_need);
     if (numeric_beta && !host) {
         bool remote = false;
         for (int q = 0; q < P; q++) remote |= (!pl.out[q].empty() && D.parts[q]->device != ydev);
-        if (remote && (D.res_dev != ydev || D.res_bytes < (size_t)ylen * es)) {
+        if (remote && (D.res_dev != ydev || D.res_bytes < res_need)) {
             if (D.d_res) {
                 DeviceGuard g;
                 (void)g.enter(D.res_dev);
@@ -468,9 +494,9 @@ int dist_mul(bsm_matrix_s *A, int op, const void *x, void *y, const void *alpha,
             }
             DeviceGuard g;
             DCHECK(g.enter(ydev), "hipSetDevice");
-            DCHECK(hipMalloc(&D.d_res, (size_t)ylen * es + 16), "hipMalloc(result staging)");
+            DCHECK(hipMalloc(&D.d_res, res_need + 16), "hipMalloc(result staging)");
             D.res_dev = ydev;
-            D.res_bytes = (size_t)ylen * es;
+            D.res_bytes = res_need;
         }
     }
 
@@ -494,49 +520,68 @@ int dist_mul(bsm_matrix_s *A, int op, const void *x, void *y, const void *alpha,
             if (pt.has_image) {
                 const Range xr = pl.xr[p];
                 const void *xp = pt.d_x;
-                if (host) {
-                    DCHECK(hipMemcpyAsync((char *)pt.d_x + xr.lo * es, xb + xr.lo * es, (size_t)xr.len() * es,
-                                          hipMemcpyHostToDevice, pt.stream), "x upload");
-                } else if (xdev == pt.device) {
+                long long xld = (long long)vlen;
+                if (!host && xdev == pt.device) {
                     xp = x;  // same device: the local product reads the caller's x directly
+                    xld = ldx;
                 } else {
-                    DCHECK(copy_between((char *)pt.d_x + xr.lo * es, pt.device, xb + xr.lo * es, xdev,
-                                        (size_t)xr.len() * es, pt.stream), "x peer copy");
+                    for (int k = 0; k < K; k++) {
+                        char *dst = (char *)pt.d_x + ((size_t)k * vlen + xr.lo) * es;
+                        const char *src = xb + ((size_t)k * ldx + xr.lo) * es;
+                        if (host)
+                            DCHECK(hipMemcpyAsync(dst, src, (size_t)xr.len() * es, hipMemcpyHostToDevice, pt.stream), "x upload");
+                        else
+                            DCHECK(copy_between(dst, pt.device, src, xdev, (size_t)xr.len() * es, pt.stream), "x peer copy");
+                    }
                 }
                 const long long z[2] = {zr.lo, zr.hi};
-                DCHECK(launch_mul(pt.img, opT, conj, xp, pt.d_w, alpha, nullptr, 1, pt.stream, pt.img.d_ws != nullptr, z),
-                       "kernel launch");
+                if (K == 1)
+                    DCHECK(launch_mul(pt.img, opT, conj, xp, pt.d_w, alpha, nullptr, 1, pt.stream, pt.img.d_ws != nullptr, z),
+                           "kernel launch");
+                else
+                    DCHECK(launch_mul_multi(pt.img, opT, conj, K, xp, xld, pt.d_w, (long long)vlen, alpha, nullptr, 1,
+                                            pt.stream, z), "kernel launch");
             } else if (!zr.empty()) {
-                DCHECK(hipMemsetAsync((char *)pt.d_w + zr.lo * es, 0, (size_t)zr.len() * es, pt.stream), "memset");
+                for (int k = 0; k < K; k++)
+                    DCHECK(hipMemsetAsync((char *)pt.d_w + ((size_t)k * vlen + zr.lo) * es, 0, (size_t)zr.len() * es, pt.stream),
+                           "memset");
             }
             DCHECK(hipEventRecord(pt.ev_prod, pt.stream), "hipEventRecord");
             return BSM_OK;
         }
         // 3: y segments produced for rows of THIS part: peer copy over xGMI + local add
+        const size_t rstride = std::max(D.plan_n.recv_bytes[p], D.plan_t.recv_bytes[p]);
         for (const Transfer &t : pl.transfers) {
             if (t.to != p) continue;
             Part &src = *D.parts[t.from];
             DCHECK(hipStreamWaitEvent(pt.stream, src.ev_prod, 0), "hipStreamWaitEvent");
-            char *rb = (char *)pt.d_recv + t.recv_off;
-            DCHECK(copy_between(rb, pt.device, (char *)src.d_w + t.range.lo * es, src.device,
-                                (size_t)t.range.len() * es, pt.stream), "halo peer copy");
-            DCHECK(launch_vec_add(D.dtype, (char *)pt.d_w + t.range.lo * es, rb, t.range.len(), pt.stream), "halo add");
+            for (int k = 0; k < K; k++) {
+                char *rb = (char *)pt.d_recv + (size_t)k * rstride + t.recv_off;
+                const size_t off = ((size_t)k * vlen + t.range.lo) * es;
+                DCHECK(copy_between(rb, pt.device, (char *)src.d_w + off, src.device, (size_t)t.range.len() * es, pt.stream),
+                       "halo peer copy");
+                DCHECK(launch_vec_add(D.dtype, (char *)pt.d_w + off, rb, t.range.len(), pt.stream), "halo add");
+            }
         }
         // 4: deliver the owned range
         const Range o = pl.out[p];
         if (!o.empty()) {
-            const size_t off = (size_t)o.lo * es, bytes = (size_t)o.len() * es;
-            const char *w = (const char *)pt.d_w + off;
-            if (host) {
-                char *dst = numeric_beta ? D.h_res.data() + off : yb + off;
-                DCHECK(hipMemcpyAsync(dst, w, bytes, hipMemcpyDeviceToHost, pt.stream), "y download");
-            } else if (!numeric_beta) {
-                DCHECK(copy_between(yb + off, ydev, w, pt.device, bytes, pt.stream), "y peer copy");
-            } else if (pt.device == ydev) {
-                DCHECK(launch_vec_axpby(D.dtype, yb + off, w, o.len(), beta, pt.stream), "y combine");
-            } else {
-                DCHECK(copy_between((char *)D.d_res + off, ydev, w, pt.device, bytes, pt.stream), "y peer copy");
-                late_flag[p] = 1;
+            const size_t bytes = (size_t)o.len() * es;
+            for (int k = 0; k < K; k++) {
+                const char *w = (const char *)pt.d_w + ((size_t)k * vlen + o.lo) * es;
+                char *yk = yb + ((size_t)k * ldy + o.lo) * es;
+                const size_t roff = ((size_t)k * ylen + o.lo) * es;
+                if (host) {
+                    char *dst = numeric_beta ? D.h_res.data() + roff : yk;
+                    DCHECK(hipMemcpyAsync(dst, w, bytes, hipMemcpyDeviceToHost, pt.stream), "y download");
+                } else if (!numeric_beta) {
+                    DCHECK(copy_between(yk, ydev, w, pt.device, bytes, pt.stream), "y peer copy");
+                } else if (pt.device == ydev) {
+                    DCHECK(launch_vec_axpby(D.dtype, yk, w, o.len(), beta, pt.stream), "y combine");
+                } else {
+                    DCHECK(copy_between((char *)D.d_res + roff, ydev, w, pt.device, bytes, pt.stream), "y peer copy");
+                    late_flag[p] = 1;
+                }
             }
         }
         DCHECK(hipEventRecord(pt.ev_done, pt.stream), "hipEventRecord");
@@ -550,9 +595,6 @@ int dist_mul(bsm_matrix_s *A, int op, const void *x, void *y, const void *alpha,
             for (int p = 0; p < P && rc == BSM_OK; p++) rc = phase(ph, p, true);
         if (rc != BSM_OK) return rc;
     }
-    std::vector<int> late;
-    for (int q = 0; q < P; q++)
-        if (late_flag[q]) late.push_back(q);
     if (host) {
         for (int q = 0; q < P; q++) {
             Part &pt = *D.parts[q];
@@ -564,12 +606,15 @@ int dist_mul(bsm_matrix_s *A, int op, const void *x, void *y, const void *alpha,
             for (int q = 0; q < P; q++) {
                 const Range o = pl.out[q];
                 if (o.empty()) continue;
-                const size_t off = (size_t)o.lo * es;
-                switch (D.dtype) {
-                    case BSM_F32: host_axpby((float *)(yb + off), (const float *)(D.h_res.data() + off), o.len(), *(const float *)beta); break;
-                    case BSM_F64: host_axpby((double *)(yb + off), (const double *)(D.h_res.data() + off), o.len(), *(const double *)beta); break;
-                    case BSM_C64: host_axpby((std::complex<float> *)(yb + off), (const std::complex<float> *)(D.h_res.data() + off), o.len(), *(const std::complex<float> *)beta); break;
-                    default: host_axpby((std::complex<double> *)(yb + off), (const std::complex<double> *)(D.h_res.data() + off), o.len(), *(const std::complex<double> *)beta); break;
+                for (int k = 0; k < K; k++) {
+                    char *yk = yb + ((size_t)k * ldy + o.lo) * es;
+                    const char *rk = D.h_res.data() + ((size_t)k * ylen + o.lo) * es;
+                    switch (D.dtype) {
+                        case BSM_F32: host_axpby((float *)yk, (const float *)rk, o.len(), *(const float *)beta); break;
+                        case BSM_F64: host_axpby((double *)yk, (const double *)rk, o.len(), *(const double *)beta); break;
+                        case BSM_C64: host_axpby((std::complex<float> *)yk, (const std::complex<float> *)rk, o.len(), *(const std::complex<float> *)beta); break;
+                        default: host_axpby((std::complex<double> *)yk, (const std::complex<double> *)rk, o.len(), *(const std::complex<double> *)beta); break;
+                    }
                 }
             }
         }
@@ -581,16 +626,39 @@ int dist_mul(bsm_matrix_s *A, int op, const void *x, void *y, const void *alpha,
         DCHECK(g.enter(sdev), "hipSetDevice");
         for (int q = 0; q < P; q++) DCHECK(hipStreamWaitEvent(stream, D.parts[q]->ev_done, 0), "hipStreamWaitEvent");
     }
-    if (!late.empty()) {
+    bool any_late = false;
+    for (int q = 0; q < P; q++) any_late |= late_flag[q] != 0;
+    if (any_late) {
         DeviceGuard g;
         DCHECK(g.enter(ydev), "hipSetDevice");
-        for (int q : late) {
+        for (int q = 0; q < P; q++) {
+            if (!late_flag[q]) continue;
             const Range o = pl.out[q];
-            const size_t off = (size_t)o.lo * es;
-            DCHECK(launch_vec_axpby(D.dtype, yb + off, (char *)D.d_res + off, o.len(), beta, stream), "y combine");
+            for (int k = 0; k < K; k++)
+                DCHECK(launch_vec_axpby(D.dtype, yb + ((size_t)k * ldy + o.lo) * es,
+                                        (char *)D.d_res + ((size_t)k * ylen + o.lo) * es, o.len(), beta, stream), "y combine");
         }
     }
 #undef DCHECK
+    return BSM_OK;
+}
+
+int dist_mul(bsm_matrix_s *A, int op, const void *x, void *y, const void *alpha, const void *beta,
+             int beta_strong_zero, int memspace, hipStream_t stream) {
+    return dist_mul_k(A, op, 1, x, 0, y, 0, alpha, beta, beta_strong_zero, memspace, stream);
+}
+
+// Y = alpha op(A) X + beta Y: every device streams its part of A ONCE per batch of up to 8 columns
+// (bsm_mul_multi's own batching), the exchange and the delivery move the batch's columns together
+int dist_mul_multi(bsm_matrix_s *A, int op, long long nrhs, const void *X, long long ldx, void *Y, long long ldy,
+                   const void *alpha, const void *beta, int beta_strong_zero, int memspace, hipStream_t stream) {
+    const size_t es = (size_t)A->dist->es;
+    for (long long k = 0; k < nrhs; k += 8) {
+        const int kb = (int)std::min<long long>(8, nrhs - k);
+        int rc = dist_mul_k(A, op, kb, (const char *)X + (size_t)k * ldx * es, ldx, (char *)Y + (size_t)k * ldy * es, ldy,
+                            alpha, beta, beta_strong_zero, memspace, stream);
+        if (rc != BSM_OK) return rc;
+    }
     return BSM_OK;
 }
 

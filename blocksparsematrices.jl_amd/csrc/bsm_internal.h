@@ -72,6 +72,8 @@ int dist_create(bsm_matrix_s *A, bsm_ctx_s *ctx, int mtype, int dtype, int64_t n
                 const std::vector<BlockIn> &in, const bsm_options &o);
 int dist_mul(bsm_matrix_s *A, int op, const void *x, void *y, const void *alpha, const void *beta,
              int beta_strong_zero, int memspace, hipStream_t stream);
+int dist_mul_multi(bsm_matrix_s *A, int op, long long nrhs, const void *X, long long ldx, void *Y, long long ldy,
+                   const void *alpha, const void *beta, int beta_strong_zero, int memspace, hipStream_t stream);
 void dist_destroy(bsm_matrix_s *A);
 int dist_part_info(bsm_matrix_s *A, int32_t part, bsm_part_info_t *out);
 int64_t dist_device_bytes(const bsm_matrix_s *A);

@@ -44,7 +44,7 @@ hipError_t launch_vec_axpby(int dtype, void *y, const void *r, long long n, cons
 // nrhs right-hand sides: X (ldx) and Y (ldy) column-major; A is streamed once per batch of <= 8.
 hipError_t launch_mul_multi(const DeviceImage &img, bool opT, bool conj, long long nrhs, const void *x,
                             long long ldx, void *y, long long ldy, const void *alpha, const void *beta,
-                            int strong_zero, hipStream_t stream);
+                            int strong_zero, hipStream_t stream, const long long *zrange = nullptr);
 
 // rowcolvals(A): COO triples (1-based int64 rows / cols, values of the image's element type) written from
 // the packed device image; d_out_off[w] = first output slot of wave descriptor w (host prefix sum of

@@ -947,7 +947,7 @@ static hipError_t launch_typed(const DeviceImage &img, bool opT, bool conj, cons
 template <typename T, int L, int K>
 static hipError_t launch_typed_multi(const DeviceImage &img, bool opT, bool conj, const T *xd, long long ldx,
                                      T *yd, long long ldy, T alpha, T beta, int strong_zero,
-                                     hipStream_t stream) {
+                                     hipStream_t stream, const long long *zrange) {
     int flags = 0;
     if (strong_zero) flags |= FLAG_STRONG_ZERO;
     if (conj) flags |= FLAG_CONJ;
@@ -969,6 +969,10 @@ static hipError_t launch_typed_multi(const DeviceImage &img, bool opT, bool conj
     if (!opT) {
         lo = img.own_lo;
         hi = img.own_hi;
+    }
+    if (zrange) {  // multi-device fan-out: see launch_typed
+        lo = zrange[0];
+        hi = zrange[1];
     }
     if (hi > lo && (strong_zero || !is_one(beta))) {
         long long nblk = (hi - lo + 255) / 256;
@@ -1002,7 +1006,7 @@ template <typename T>
 static hipError_t launch_multi_typed(const DeviceImage &img, bool opT, bool conj, long long nrhs,
                                      const void *x, long long ldx, void *y, long long ldy,
                                      const void *alpha_p, const void *beta_p, int strong_zero,
-                                     hipStream_t stream) {
+                                     hipStream_t stream, const long long *zrange) {
     const T alpha = load_scalar<T>(alpha_p, 1.0);
     const T beta = load_scalar<T>(beta_p, 0.0);
     const T *xd = (const T *)x;
@@ -1015,27 +1019,27 @@ static hipError_t launch_multi_typed(const DeviceImage &img, bool opT, bool conj
     // (fp64 fused: 143 -> 103 VGPRs; C3 3.0x -> 3.3x, 8-28-row blocks 2.0x -> 2.4x over 8 products).
     while (e == hipSuccess && nrhs - k >= 8) {
         e = launch_typed_multi<T, 4, 8>(img, opT, conj, xd + k * ldx, ldx, yd + k * ldy, ldy, alpha, beta,
-                                        strong_zero, stream);
+                                        strong_zero, stream, zrange);
         k += 8;
     }
     if (e == hipSuccess && nrhs - k >= 4) {
         e = launch_typed_multi<T, 8, 4>(img, opT, conj, xd + k * ldx, ldx, yd + k * ldy, ldy, alpha, beta,
-                                        strong_zero, stream);
+                                        strong_zero, stream, zrange);
         k += 4;
     }
     for (; e == hipSuccess && k < nrhs; ++k)
-        e = launch_typed<T, 8>(img, opT, conj, xd + k * ldx, yd + k * ldy, alpha_p, beta_p, strong_zero, stream);
+        e = launch_typed<T, 8>(img, opT, conj, xd + k * ldx, yd + k * ldy, alpha_p, beta_p, strong_zero, stream, false, zrange);
     return e;
 }
 
 hipError_t launch_mul_multi(const DeviceImage &img, bool opT, bool conj, long long nrhs, const void *x,
                             long long ldx, void *y, long long ldy, const void *alpha, const void *beta,
-                            int strong_zero, hipStream_t stream) {
+                            int strong_zero, hipStream_t stream, const long long *zrange) {
     switch (img.dtype) {
-        case 0: return launch_multi_typed<float>(img, opT, conj, nrhs, x, ldx, y, ldy, alpha, beta, strong_zero, stream);
-        case 1: return launch_multi_typed<double>(img, opT, conj, nrhs, x, ldx, y, ldy, alpha, beta, strong_zero, stream);
-        case 2: return launch_multi_typed<c64>(img, opT, conj, nrhs, x, ldx, y, ldy, alpha, beta, strong_zero, stream);
-        case 3: return launch_multi_typed<c128>(img, opT, conj, nrhs, x, ldx, y, ldy, alpha, beta, strong_zero, stream);
+        case 0: return launch_multi_typed<float>(img, opT, conj, nrhs, x, ldx, y, ldy, alpha, beta, strong_zero, stream, zrange);
+        case 1: return launch_multi_typed<double>(img, opT, conj, nrhs, x, ldx, y, ldy, alpha, beta, strong_zero, stream, zrange);
+        case 2: return launch_multi_typed<c64>(img, opT, conj, nrhs, x, ldx, y, ldy, alpha, beta, strong_zero, stream, zrange);
+        case 3: return launch_multi_typed<c128>(img, opT, conj, nrhs, x, ldx, y, ldy, alpha, beta, strong_zero, stream, zrange);
     }
     return hipErrorInvalidValue;
 }

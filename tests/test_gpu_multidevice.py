@@ -204,3 +204,49 @@ def test_concurrent_products_on_one_multi_device_handle(torch_cuda, bsm, oracle)
     for t in th:
         t.join(timeout=120)
     assert not errs, errs[:3]
+
+
+@pytest.mark.parametrize("kind", ["symmetric", "vbcrs", "fixture"])
+def test_multi_rhs_through_the_multi_device_handle(torch_cuda, bsm, oracle, kind):
+    """mul!(Y, A, X, a, b) with matrices on a handle spread over three parts: every device streams its
+    part once per batch of <= 8 columns, the halo and the delivery carry the batch's columns; 11 columns =
+    a batch of 8 + one of 3; padded leading dimensions; host and device memory; each column against the
+    oracle's single-vector product."""
+    torch = torch_cuda
+    if kind == "symmetric":
+        prob = bsm.synthetic.config5(n=20_000, lo=16, hi=96, halfband=3)
+    elif kind == "vbcrs":
+        prob = bsm.synthetic.config2(n=9000, nblocks=400)
+    else:
+        prob = fixture_problem("cuboid")
+    A = bsm.synthetic.build(prob, devices=[0, 0, 0])
+    dt = np.dtype(A.dtype)
+    n = prob["size"][0]
+    rng = np.random.default_rng(21)
+    K, ld = 11, n + 5
+    Xp = np.zeros((ld, K), dtype=dt, order="F")
+    Yp = np.zeros((ld, K), dtype=dt, order="F")
+    Xp[:n] = rng.standard_normal((n, K)) + (1j * rng.standard_normal((n, K)) if dt.kind == "c" else 0)
+    Y0 = rng.standard_normal((n, K)).astype(dt)
+    for op in (N, T):
+        Aop = wrap(bsm, A, op)
+        for alpha, beta in ((True, False), (0.5, -2.0)):
+            refs = [oracle_mul(oracle, prob, op, np.ascontiguousarray(Xp[:n, k]), Y0[:, k].copy(),
+                               1 if alpha is True else alpha, 0 if beta is False else beta, beta is False)
+                    for k in range(K)]
+            # device memory, padded leading dimension (views into a taller column-major matrix)
+            Xd = torch.from_numpy(np.ascontiguousarray(Xp.T)).cuda().t()[:n]
+            Yfull = torch.from_numpy(np.ascontiguousarray(Yp.T)).cuda().t()
+            Yfull[:n] = torch.from_numpy(Y0).cuda()
+            Yd = Yfull[:n]
+            bsm.mul(Yd, Aop, Xd, alpha, beta)
+            torch.cuda.synchronize()
+            got = Yd.cpu().numpy()
+            for k in range(K):
+                assert relerr(got[:, k], refs[k]) < 1e-12, ("device", op, alpha, k)
+            assert not bool(Yfull[n:].abs().max() > 0)  # the padding rows are not touched
+            # host memory
+            Yh = np.asfortranarray(Y0.copy())
+            bsm.mul(Yh, Aop, np.asfortranarray(Xp[:n]), alpha, beta)
+            for k in range(K):
+                assert relerr(Yh[:, k], refs[k]) < 1e-12, ("host", op, alpha, k)
