@@ -28,6 +28,8 @@ CONFIGS = [
 ]
 if "--full" in sys.argv:  # the complete 8-GPU configs on ONE MI355X (16.4 GB / 28.7 GB of HBM)
     sys.argv.remove("--full")
+    # (host generation: minutes per config and 45 GB of host memory.  `bench.py --gpus 1 --workload c5`
+    # times the same two operators generated in HBM in seconds -- without the oracle comparison)
     CONFIGS = [
         ("C4 VBCRS 2M^2, 250000x 128x128 fp32, FULL on one GPU", lambda: S.config4(), 1),
         ("C5 Symmetric 5M^2, sizes 16-256 fp64, FULL on one GPU", lambda: S.config5(), 1),
