@@ -1065,7 +1065,7 @@ extern "C" int bsm_stats(bsm_matrix_t A, bsm_stats_t *out) {
     out->device_bytes = A->dist ? dist_device_bytes(A) : A->img.device_bytes + (A->has_t ? A->img_t.device_bytes : 0);
     out->npanels = A->an.ngroups;
     out->ntasks = (int64_t)A->an.waves.size();
-    out->nworkgroups = A->img.nwg_total;
+    out->nworkgroups = A->img.nwg_total ? A->img.nwg_total : A->an.nwg_total;
     out->exclusive = A->img.exclusive_fwd ? 1 : 0;
     return BSM_OK;
 }

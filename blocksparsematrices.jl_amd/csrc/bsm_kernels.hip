@@ -206,6 +206,22 @@ template <typename T, int V, int P> struct Butterfly {
     }
 };
 
+#ifdef BSM_TRACE
+// developer build (make trace): per-wave phase timestamps for tools/wavetrace.py.  The stamps
+// (s_memtime) are parked in LDS and leave the wave once, at its end: a global store per stamp would
+// sit in the in-order vmcnt queue in front of the matrix loads and triple the kernel time.
+__device__ unsigned long long *g_trace = nullptr;
+__shared__ unsigned long long t_trace[kWavesPerWg][16];
+#define BSM_TSTAMP(slot)                                                   \
+    do {                                                                   \
+        if (lane == 0) t_trace[threadIdx.x >> 6][(slot)] = clock64();      \
+    } while (0)
+#else
+#define BSM_TSTAMP(slot) \
+    do {                 \
+    } while (0)
+#endif
+
 constexpr int FLAG_STRONG_ZERO = 1;
 constexpr int FLAG_DIRECT = 2;
 constexpr int FLAG_CONJ = 4;
@@ -268,7 +284,7 @@ __device__ __forceinline__ WaveD load_wave(const WaveWork *__restrict__ wp) {
 // staging their occupancy is bounded by LDS and by the registers of the unrolled staging loop
 // (fp64: 111 -> 80 VGPRs, 4 -> 6 waves per SIMD; +11 % on 3-28-row BEM panels).
 template <typename T, bool TRN = false> constexpr int x_chunk_cols() {
-    return TRN ? 2048 / (int)sizeof(T) : (sizeof(T) >= 16 ? 256 : 512);
+    return TRN ? 2048 / (int)sizeof(T) : (sizeof(T) >= 16 ? 128 : (sizeof(T) == 8 ? 256 : 512));
 }
 
 template <typename T, int L, int P, bool FWD, bool TRN, bool NT>
@@ -335,42 +351,78 @@ __device__ __forceinline__ T run_panel(const WaveD &wd, const uint4 *__restrict_
             return w + (w < s1w ? xbase : (w < s2w ? s1x : s2x));
         };
 
-        for (int c0 = 0; c0 < ncols; c0 += XCH) {
-            if (fwd_en) {
-                // x slice of this chunk: gathered ONCE per wave into LDS (contiguous range or
-                // through the merged column list) while the first matrix loads are in flight,
-                // then read back as 16-byte broadcasts by every iteration of the chunk
+        // L independent 16-byte loads per lane: 8 KB of the matrix per wave in flight
+        auto load_b = [&](Vec16<T>(&b)[L], int s0) {
 #pragma unroll
-                for (int k = 0; k < XCH / 64; ++k) {
-                    const int c = k * 64 + lane;
-                    const int w = c0 + c;
-                    if (w < ncols + NC) {  // zero the tail one iteration past the last column
-                        T xv = zero_of(T{});
-                        if (w < ncols) {
-                            bool off;
-                            const int xi = col_lookup(w, off);
-                            if (!opT || off) xv = x[xi];
-                        }
-                        xs[c] = xv;
-                    }
+            for (int l = 0; l < L; ++l) {
+                const int s = s0 + l * G + g;
+                if (row_ok && s < nstrips) {
+                    b[l] = NT ? load_stream16(&vb[(uint32_t)(s * m + i)]) : vb[(uint32_t)(s * m + i)];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < E; ++e) b[l].v[e] = zero_of(T{});
                 }
             }
+        };
+        // x slice of a chunk: gathered ONCE per wave into LDS (contiguous runs or through the merged
+        // column list), then read back as 16-byte broadcasts by every iteration of the chunk.  The
+        // gather is branch-free and batched -- all column-list loads, then all x loads, then the LDS
+        // stores: ONE memory round trip (two through the list) instead of a dependent load / wait /
+        // store per 64 columns, which tools/wavetrace.py showed as 0.9 us (median) to 3.4 us (p90) of
+        // a 9.7 us C2 launch.  A lane past the last column loads the last column's entry and stores
+        // zero (the tail one iteration past the end must read as zero).
+        auto stage_x = [&](int c0, auto kx_tag) {
+            constexpr int KX = decltype(kx_tag)::value;
+            const bool pool = xbase < 0;  // wave-uniform
+            int raw[KX];                  // column-list entries (pool) -- the only state kept per column
+            T xv[KX];
+            if (pool) {
+#pragma unroll
+                for (int k = 0; k < KX; ++k) raw[k] = cols[col_off + min(c0 + k * 64 + lane, ncols - 1)];
+#pragma unroll
+                for (int k = 0; k < KX; ++k) xv[k] = x[raw[k] & 0x7fffffff];
+            } else {
+#pragma unroll
+                for (int k = 0; k < KX; ++k) {
+                    bool off;
+                    raw[k] = 0;
+                    xv[k] = x[col_lookup(min(c0 + k * 64 + lane, ncols - 1), off)];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < KX; ++k) {
+                const int w = c0 + k * 64 + lane;
+                bool off;
+                if (pool)
+                    off = raw[k] >= 0 && (kinds & 3) == KIND_OFF;
+                else
+                    (void)col_lookup(w, off);
+                xs[k * 64 + lane] = (w < ncols && (!opT || off)) ? xv[k] : zero_of(T{});
+            }
+        };
+
+        for (int c0 = 0; c0 < ncols; c0 += XCH) {
+            if (fwd_en) {
+                constexpr int KXM = XCH / 64;
+                const int need = min(ncols - c0, XCH) + NC;  // columns the chunk's iterations read
+                if (KXM >= 4 && need <= (KXM / 4) * 64)
+                    stage_x(c0, std::integral_constant<int, (KXM >= 4 ? KXM / 4 : 1)>{});
+                else if (KXM >= 2 && need <= (KXM / 2) * 64)
+                    stage_x(c0, std::integral_constant<int, (KXM >= 2 ? KXM / 2 : 1)>{});
+                else
+                    stage_x(c0, std::integral_constant<int, KXM>{});
+            }
+#ifdef BSM_TRACE
+            if (c0 == 0) BSM_TSTAMP(2);  // x slice staged (loads issued and stored to LDS)
+#endif
             const int s_end = min(nstrips, (c0 + XCH) / E);
             for (int s0 = c0 / E; s0 < s_end; s0 += G * L) {
-                // L independent 16-byte loads per lane: 8 KB per wave in flight.  (A software-
-                // pipelined variant with the next iteration's loads already in flight was measured
-                // and did not help: occupancy already provides the memory-level parallelism.)
+                // (Software-pipelined variants -- every next iteration's loads already in flight, or
+                // only a chunk's first loads issued inside the x gather -- were measured and did not
+                // help: the memory system serves a short launch's requests first come, first served,
+                // and occupancy provides the parallelism of a long one.)
                 Vec16<T> b[L];
-#pragma unroll
-                for (int l = 0; l < L; ++l) {
-                    const int s = s0 + l * G + g;
-                    if (row_ok && s < nstrips) {
-                        b[l] = NT ? load_stream16(&vb[(uint32_t)(s * m + i)]) : vb[(uint32_t)(s * m + i)];
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < E; ++e) b[l].v[e] = zero_of(T{});
-                    }
-                }
+                load_b(b, s0);
                 if (fwd_en) {
                     const int cb = (s0 - c0 / E) * E;  // first column of this iteration inside the chunk
 #pragma unroll
@@ -380,6 +432,12 @@ __device__ __forceinline__ T run_panel(const WaveD &wd, const uint4 *__restrict_
                         for (int e = 0; e < E; ++e) acc[e] = madd(acc[e], cj(b[l].v[e], cjf), xv.v[e]);
                     }
                 }
+#ifdef BSM_TRACE
+                if (s0 == c0 / E && c0 == 0) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    BSM_TSTAMP(3);  // first iteration's matrix bytes have arrived
+                }
+#endif
                 if (trn_en) {
                     T vals[V];
 #pragma unroll
@@ -449,7 +507,7 @@ __device__ __forceinline__ T run_panel(const WaveD &wd, const uint4 *__restrict_
 //   complex128: capped at 80 (the fused instance compiles to 71: 7 waves).
 //   fp32 / complex64: capped at 96 = 5 waves (fp32 fused compiles to 80: 6), no scratch anywhere.
 template <typename T, int L, bool FWD, bool TRN, bool NT>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(
+__global__ void __launch_bounds__(64 * kWavesPerWg) __attribute__((amdgpu_waves_per_eu(
     (FWD && TRN && std::is_same<T, double>::value) ? 8 :
     (((!TRN && std::is_same<T, double>::value) || std::is_same<T, c128>::value) ? 6 : 5))))
     panel_kernel(const WaveWork *__restrict__ waves, const uint4 *__restrict__ values, const int *__restrict__ rows,
@@ -466,13 +524,23 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(
 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
+    BSM_TSTAMP(0);  // wave started
     const WaveD wd = load_wave(waves + ((size_t)(blockIdx.x + wg_base) * kWavesPerWg + wave));
     const int work = wd.work;
     const int m = wd.m;
+#ifdef BSM_TRACE
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    BSM_TSTAMP(1);  // descriptor arrived
+    if (lane == 0) {
+        t_trace[threadIdx.x >> 6][6] =
+            (unsigned long long)(wd.work == WORK_PANEL && wd.npieces ? (long long)wd.first.nstrips * wd.m * 16 : 0);
+        t_trace[threadIdx.x >> 6][7] = wall_clock64();
+    }
+#endif
     // workgroup-uniform (all 4 descriptors carry the same window; coloured launches keep plain RMW)
     const int win_n = (WIN && !(flags & FLAG_RMW)) ? wd.win_n : 0;
     if (WIN && win_n > 0) {
-        for (int e = threadIdx.x; e < win_n; e += 256) win[e] = zero_of(T{});
+        for (int e = threadIdx.x; e < win_n; e += 64 * kWavesPerWg) win[e] = zero_of(T{});
         __syncthreads();
     }
 
@@ -487,6 +555,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(
         else
             u = run_panel<T, L, 64, FWD, TRN, NT>(wd, values, rows, cols, x, y, alpha, flags, lane, xs[wave], vs[wave], win, win_n, ws);
     }
+    BSM_TSTAMP(4);  // the wave's piece is streamed
     const bool direct = (flags & FLAG_DIRECT) != 0;
     const bool sz = (flags & FLAG_STRONG_ZERO) != 0;
     if (FWD) {
@@ -520,7 +589,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(
         // every wave has parked its sums: the window leaves the CU once, 64 contiguous entries
         // per atomic wave-instruction
         __syncthreads();
-        for (int e = threadIdx.x; e < win_n; e += 256) {
+        for (int e = threadIdx.x; e < win_n; e += 64 * kWavesPerWg) {
             const T v = win[e];
             if (!is_zero(v)) atomic_acc(&y[wd.win_base + e], v);
         }
@@ -530,7 +599,20 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(
         for (int r = lane; r < cnt; r += 64)
             y[wd.rbase + r] = sz ? zero_of(T{}) : mul(beta, y[wd.rbase + r]);
     }
+#ifdef BSM_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    BSM_TSTAMP(5);  // everything stored
+    if (lane == 0) t_trace[threadIdx.x >> 6][8] = wall_clock64();
+    if (g_trace && lane < 16)
+        g_trace[((size_t)blockIdx.x * kWavesPerWg + (threadIdx.x >> 6)) * 16 + lane] = t_trace[threadIdx.x >> 6][lane];
+#endif
 }
+
+#ifdef BSM_TRACE
+extern "C" int bsm_debug_set_trace(void *buf) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_trace), &buf, sizeof(buf));
+}
+#endif
 
 // ========================================================================================
 // multi right-hand-side variant: Y = alpha*op(A)*X + beta*Y for K columns per pass.  A is
@@ -696,7 +778,7 @@ __device__ __forceinline__ void run_panel_multi(const WaveD &wd, const uint4 *__
 }
 
 template <typename T, int L, bool FWD, bool TRN, int K>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2)))
+__global__ void __launch_bounds__(64 * kWavesPerWg) __attribute__((amdgpu_waves_per_eu(2)))
     panel_kernel_multi(const WaveWork *__restrict__ waves, const uint4 *__restrict__ values,
                        const int *__restrict__ rows, const int *__restrict__ cols,
                        const T *__restrict__ x, long long ldx, T *__restrict__ y, long long ldy, T alpha,
@@ -874,7 +956,7 @@ static hipError_t launch_typed(const DeviceImage &img, bool opT, bool conj, cons
     const int *cols = (const int *)img.d_cols;
     const T *xd = (const T *)x;
     T *yd = (T *)y;
-    const dim3 block(256);
+    const dim3 block(64 * kWavesPerWg);
     const bool nt = stream_policy(img);
 
     if (!opT && img.exclusive_fwd) {
@@ -903,7 +985,7 @@ static hipError_t launch_typed(const DeviceImage &img, bool opT, bool conj, cons
     if (!gather && hi > lo && (strong_zero || !is_one(beta))) {
         long long nblk = (hi - lo + 255) / 256;
         if (nblk > 2048) nblk = 2048;
-        hipLaunchKernelGGL((scale_kernel<T>), dim3((unsigned)nblk), block, 0, stream, yd, 0LL, lo, hi, beta,
+        hipLaunchKernelGGL((scale_kernel<T>), dim3((unsigned)nblk), dim3(256), 0, stream, yd, 0LL, lo, hi, beta,
                            strong_zero);
     }
     // one launch over every workgroup (atomics), or one launch per colour class (plain RMW:
@@ -936,7 +1018,7 @@ static hipError_t launch_typed(const DeviceImage &img, bool opT, bool conj, cons
     if (gather && ylen > 0) {
         const int k = opT ? 1 : 0;
         const long long nblk = (ylen + 255) / 256;
-        hipLaunchKernelGGL((gather_kernel<T>), dim3((unsigned)nblk), block, 0, stream, yd, ylen, lo, hi,
+        hipLaunchKernelGGL((gather_kernel<T>), dim3((unsigned)nblk), dim3(256), 0, stream, yd, ylen, lo, hi,
                            (const long long *)img.d_inv_ptr[k], (const int *)img.d_inv_idx[k], (const T *)ws,
                            alpha, beta, strong_zero);
     }
@@ -956,7 +1038,7 @@ static hipError_t launch_typed_multi(const DeviceImage &img, bool opT, bool conj
     const uint4 *values = (const uint4 *)img.d_values;
     const int *rows = (const int *)img.d_rows;
     const int *cols = (const int *)img.d_cols;
-    const dim3 block(256);
+    const dim3 block(64 * kWavesPerWg);
     if (!opT && img.exclusive_fwd) {
         flags |= FLAG_DIRECT;
         if (img.nwg_total > 0)
@@ -977,7 +1059,7 @@ static hipError_t launch_typed_multi(const DeviceImage &img, bool opT, bool conj
     if (hi > lo && (strong_zero || !is_one(beta))) {
         long long nblk = (hi - lo + 255) / 256;
         if (nblk > 2048) nblk = 2048;
-        hipLaunchKernelGGL((scale_kernel<T>), dim3((unsigned)nblk, (unsigned)K), block, 0, stream, yd, ldy, lo,
+        hipLaunchKernelGGL((scale_kernel<T>), dim3((unsigned)nblk, (unsigned)K), dim3(256), 0, stream, yd, ldy, lo,
                            hi, beta, strong_zero);
     }
     const bool colored = !img.color_wg_ptr.empty();
@@ -1109,7 +1191,7 @@ hipError_t launch_vec_axpby(int dtype, void *y, const void *r, long long n, cons
 // order of the triples is fixed).  HBM-bound, one-off.
 // ========================================================================================
 template <typename T>
-__global__ void __launch_bounds__(256) export_coo_kernel(const WaveWork *__restrict__ waves, long long nwaves,
+__global__ void __launch_bounds__(64 * kWavesPerWg) export_coo_kernel(const WaveWork *__restrict__ waves, long long nwaves,
                                                          const long long *__restrict__ out_off,
                                                          const uint4 *__restrict__ values, const int *__restrict__ rows,
                                                          const int *__restrict__ cols, long long *__restrict__ orow,
@@ -1174,7 +1256,7 @@ hipError_t launch_export_coo(int dtype, const void *d_waves, long long nwaves, c
                              const void *d_values, const void *d_rows, const void *d_cols, void *orow, void *ocol,
                              void *oval, hipStream_t stream) {
     if (nwaves <= 0) return hipSuccess;
-    const dim3 grid((unsigned)((nwaves + kWavesPerWg - 1) / kWavesPerWg)), block(256);
+    const dim3 grid((unsigned)((nwaves + kWavesPerWg - 1) / kWavesPerWg)), block(64 * kWavesPerWg);
 #define BSM_EXPORT(T)                                                                                             \
     hipLaunchKernelGGL((export_coo_kernel<T>), grid, block, 0, stream, (const WaveWork *)d_waves, nwaves,         \
                        (const long long *)d_out_off, (const uint4 *)d_values, (const int *)d_rows,                \

@@ -230,14 +230,15 @@ def interpret_image(A, op, x, y0, alpha=1, beta=0, strong=True, timage=False):
         fbase = len(cols) if np.any(waves["work"] == WORK_PANEL) else 0
     elif not direct:
         y[:] = 0 if strong else beta * y
-    assert len(waves) % 4 == 0
+    wpw = int(st["ntasks"]) // max(int(st["nworkgroups"]), 1) if len(waves) else 4  # waves per workgroup
+    assert wpw in (4, 8) and len(waves) % wpw == 0
     pw = waves[waves["work"] == WORK_PANEL]
     has_off = bool(np.any(pw["first"]["kind"][pw["npieces"] > 0] & KIND_HAS_OFF))
     fwd_kernel = (not opT) or has_off  # the launcher's choice of the FWD template flag
-    for wg in range(len(waves) // 4):
-        us = [None] * 4
-        for w in range(4):
-            W = waves[wg * 4 + w]
+    for wg in range(len(waves) // wpw):
+        us = [None] * wpw
+        for w in range(wpw):
+            W = waves[wg * wpw + w]
             if W["work"] == WORK_SCALE:
                 if direct:
                     r0, cnt = int(W["rbase"]), int(W["first"]["ncols"])
@@ -284,7 +285,7 @@ def interpret_image(A, op, x, y0, alpha=1, beta=0, strong=True, timage=False):
                     else:
                         np.add.at(y, cidx[tcols], alpha * v)
             us[w] = (u, ridx, int(W["grp"]), int(W["lead"]))
-        for w in range(4):
+        for w in range(wpw):
             if us[w] is None or not us[w][3] or not fwd_kernel:
                 continue
             u, ridx, grp, _ = us[w]
@@ -294,7 +295,7 @@ def interpret_image(A, op, x, y0, alpha=1, beta=0, strong=True, timage=False):
                 assert np.array_equal(us[w + k][1], ridx)
                 u += us[w + k][0]
             if gather:
-                lead = waves[wg * 4 + w]
+                lead = waves[wg * wpw + w]
                 if (not opT) or (int(lead["first"]["kind"]) & KIND_GROUP_HAS_OFF):
                     ws[fbase + int(lead["win_base"]):fbase + int(lead["win_base"]) + len(ridx)] = u
             elif direct:

@@ -364,7 +364,8 @@ def test_lds_window_descriptors_cover_their_workgroup(bsm):
     p = bsm.synthetic.config5(n=20000, lo=8, hi=28, halfband=6)
     A = bsm.synthetic.build(p, device=NODEV)
     values, rows, cols, waves = get_image(A)
-    wg = waves.reshape(-1, 4)
+    st = A.stats()
+    wg = waves.reshape(-1, st["ntasks"] // st["nworkgroups"])  # waves per workgroup
     nwin = 0
     for quad in wg:
         assert len(set(quad["win_span8"])) == 1 and len(set(quad["win_base"])) == 1
