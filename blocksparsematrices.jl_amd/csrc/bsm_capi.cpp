@@ -853,6 +853,50 @@ extern "C" int bsm_part_info(bsm_matrix_t A, int32_t part, bsm_part_info_t *out)
     return dist_part_info(A, part, out);
 }
 
+// The gather workspace of an image (column sums + inverted indices) belongs to the handle and admits
+// ONE product in flight.  The enqueue is serialised; a caller that races on the same handle from
+// another thread, or whose predecessor may still be running on ANOTHER stream (same stream: stream
+// order protects it), does not get the claim and its product takes the atomic path.  Nothing is
+// enqueued for the bookkeeping (an event recorded per product costs 3 us between two 9 us launches):
+// the previous stream is queried only when the stream changes.  Not tracked while the stream is
+// being captured into a graph: replays of one graph are ordered by the caller.
+struct WorkspaceClaim {
+    bsm_matrix_s *A;
+    hipStream_t st;
+    std::unique_lock<std::mutex> lock;
+    bool held = false, track = false;
+    WorkspaceClaim(bsm_matrix_s *A_, const DeviceImage &img, hipStream_t st_)
+        : A(A_), st(st_), lock(A_->gather_mu, std::defer_lock) {
+        held = img.d_ws != nullptr && lock.try_lock();
+        if (!held) return;
+        if (A->ws_pending && A->ws_stream == st) {  // the common case: one stream, nothing to ask
+            track = true;
+            return;
+        }
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &cs) != hipSuccess) {
+            (void)hipGetLastError();
+            cs = hipStreamCaptureStatusNone;
+        }
+        track = (cs == hipStreamCaptureStatusNone);
+        if (track && A->ws_pending) {  // the stream changed: is the previous one idle?
+            const hipError_t q = hipStreamQuery(A->ws_stream);
+            if (q != hipSuccess) {
+                (void)hipGetLastError();  // hipErrorNotReady is not a failure
+                // (any other answer -- the stream may be gone -- is treated the same way once, then
+                // forgotten: work of a destroyed stream does not outlive a whole product by much)
+                if (q != hipErrorNotReady) A->ws_pending = false;
+                held = track = false;
+            }
+        }
+    }
+    void mark() {  // after the product has been enqueued
+        if (!held || !track) return;
+        A->ws_stream = st;
+        A->ws_pending = true;
+    }
+};
+
 extern "C" int bsm_mul(bsm_matrix_t A, int op, const void *x, void *y, const void *alpha,
                        const void *beta, int beta_strong_zero, int memspace, void *stream) {
     if (!A) return fail(BSM_ERR_INVALID, "null handle");
@@ -870,41 +914,9 @@ extern "C" int bsm_mul(bsm_matrix_t A, int op, const void *x, void *y, const voi
     hipError_t e = guard.enter(img.device);
     if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
     hipStream_t st = (hipStream_t)stream;
-    // gather mode: the workspace belongs to the handle, so the enqueue is serialised; a caller that
-    // races on the same handle from another thread gets the atomic path for that call
-    std::unique_lock<std::mutex> glock(A->gather_mu, std::defer_lock);
-    bool use_gather = img.d_ws != nullptr && glock.try_lock();
-    // ... and a product still in flight on ANOTHER stream owns the workspace too (same stream:
-    // stream order protects it).  Not tracked while the stream is being captured into a graph:
-    // replays of one graph are ordered by the caller.
-    bool track = false;
-    if (use_gather) {
-        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing(st, &cs) != hipSuccess) {
-            (void)hipGetLastError();
-            cs = hipStreamCaptureStatusNone;
-        }
-        track = (cs == hipStreamCaptureStatusNone);
-        if (track && A->ws_pending && A->ws_stream != st) {
-            if (hipEventQuery(A->ws_done) == hipSuccess)
-                A->ws_pending = false;
-            else {
-                (void)hipGetLastError();  // hipErrorNotReady is not a failure
-                use_gather = track = false;
-            }
-        }
-    }
-    auto mark_gather = [&]() {
-        if (!track) return;
-        if (!A->ws_done && hipEventCreateWithFlags(&A->ws_done, hipEventDisableTiming) != hipSuccess) {
-            A->ws_done = nullptr;
-            return;
-        }
-        if (hipEventRecord(A->ws_done, st) == hipSuccess) {
-            A->ws_stream = st;
-            A->ws_pending = true;
-        }
-    };
+    WorkspaceClaim claim(A, img, st);
+    const bool use_gather = claim.held;
+    auto mark_gather = [&]() { claim.mark(); };
     if (memspace == BSM_MEM_DEVICE) {
         e = launch_mul(img, opT, conj, x, y, alpha, beta, beta_strong_zero, st, use_gather);
         if (e != hipSuccess) return hip_fail(e, "kernel launch");
@@ -1107,7 +1119,6 @@ extern "C" int bsm_destroy(bsm_matrix_t A) {
         free_image(A->img_t);
         if (A->stage_x) (void)hipFree(A->stage_x);
         if (A->stage_y) (void)hipFree(A->stage_y);
-        if (A->ws_done) (void)hipEventDestroy(A->ws_done);
     }
     delete A;
     return BSM_OK;

@@ -30,9 +30,8 @@ struct bsm_matrix_s {
     bsm::Analysis an_t;
     bsm::DeviceImage img_t;
     std::mutex gather_mu;  // the gather workspace admits one product in flight per handle
-    hipEvent_t ws_done = nullptr;    // recorded after the last gather-mode product
-    hipStream_t ws_stream = nullptr;  // ... on this stream
-    bool ws_pending = false;
+    hipStream_t ws_stream = nullptr;  // stream of the last gather-mode product
+    bool ws_pending = false;          // ... which may still be running (see WorkspaceClaim)
     // device staging buffers of the BSM_MEM_HOST path, kept between calls (grow-only); a second
     // concurrent host call on the same handle falls back to temporary buffers
     std::mutex host_mu;

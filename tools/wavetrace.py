@@ -9,7 +9,9 @@ from bsm_amd import _lib
 which = sys.argv[1] if len(sys.argv) > 1 else "c2"
 S = bsm.synthetic
 p = {"c2": S.config2, "c2p": lambda: S.config2(n=100000, lo=32, hi=32, nblocks=6400),
-     "c2w": lambda: S.config2(n=100000, lo=64, hi=64, nblocks=1650)}[which]()
+     "c2w": lambda: S.config2(n=100000, lo=64, hi=64, nblocks=1650),
+     "bem": lambda: S.config5(n=400_000, lo=8, hi=28, halfband=8),
+     "c3s": lambda: S.config3(nseg=800)}[which]()
 A = S.build(p)
 st = A.stats()
 nw = st["nworkgroups"] * 4
