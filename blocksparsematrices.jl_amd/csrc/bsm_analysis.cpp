@@ -24,6 +24,9 @@ Tunables Tunables::from_env() {
     t.split2_bytes = geti("BSM_SPLIT2_BYTES", t.split2_bytes);
     t.split4_bytes = geti("BSM_SPLIT4_BYTES", t.split4_bytes);
     t.wgitem_max_bytes = geti("BSM_WGITEM_MAX_BYTES", t.wgitem_max_bytes);
+    t.wave_bytes = geti("BSM_WAVE_BYTES", t.wave_bytes);
+    t.target_waves = std::max<int64_t>(1, geti("BSM_TARGET_WAVES", t.target_waves));
+    if (const char *f = std::getenv("BSM_FAT_FILL_BELOW")) t.fat_fill_below = std::atof(f);
     t.pack_threads = (int)geti("BSM_PACK_THREADS", t.pack_threads);
     t.wg_order = (int)geti("BSM_ORDER", t.wg_order);
     t.deep_group_bytes = geti("BSM_DEEP_GROUP_BYTES", t.deep_group_bytes);
@@ -769,6 +772,24 @@ std::string Analysis::build(int mtype_, int dtype_, int64_t nrows_, int64_t ncol
     lap("pack values");
     // ---- work items ----------------------------------------------------------------------
     std::vector<Item> items;
+    {  // bytes per wave for this operator (bsm_analysis.h: Tunables::wave_bytes)
+        int64_t W = tun.wave_bytes;
+        if (W <= 0) {
+            // lane fill: rows of a group over the lanes its strips occupy (8, 16, 32 or 64 per strip)
+            double rows_b = 0, lanes_b = 0;
+            for (const Group &G : groups) {
+                rows_b += (double)G.mc * (double)G.strips;
+                lanes_b += (double)lanes_per_strip(G.mc) * (double)G.strips;
+            }
+            const bool low_fill = lanes_b > 0 && rows_b < tun.fat_fill_below * lanes_b;
+            W = tun.wave_bytes_min;
+            if (low_fill)
+                W = std::min(tun.wave_bytes_max, std::max(tun.wave_bytes_min, (int64_t)val_units * 16 / tun.target_waves));
+        }
+        if (tun.split2_bytes <= 0) tun.split2_bytes = W;
+        if (tun.split4_bytes <= 0) tun.split4_bytes = 3 * W;
+        if (tun.wgitem_max_bytes <= 0) tun.wgitem_max_bytes = 4 * W;
+    }
     for (int64_t g = 0; g < ngroups; g++) {
         const Group &G = groups[g];
         const int64_t strip_bytes = (int64_t)G.mc * 16;

@@ -52,9 +52,27 @@ struct BlockIn {
 };
 
 struct Tunables {
-    int64_t split2_bytes = 8 << 10;     // row groups at least this big get 2 waves
-    int64_t split4_bytes = 24 << 10;    // ... and 4 waves
-    int64_t wgitem_max_bytes = 32 << 10;   // non-exclusive groups are cut into items this big (4 waves x one 8 KB iteration)
+    // Bytes one wave streams (W).  A wave's life is a chain of memory round trips -- descriptor, x
+    // slice, one per 8 KB iteration, emission (tools/wavetrace.py: 9 us for the 8 KB waves of a
+    // BEM-shaped fused launch, of which 1.7 us stream the matrix) -- and a workgroup keeps its slot
+    // until its slowest wave is done.  W = 8 KB, one iteration per wave, puts every request of a
+    // launch in flight at once: right for short launches and for row groups that fill their lanes
+    // (64-row blocks stream at 6.5-6.9 TB/s that way; fatter waves cost them 2-3 %).  Row groups
+    // that do NOT fill their lanes (3-28-row BEM panels, mixed block sizes) move fewer bytes per
+    // iteration and pay the fixed part of the chain more often: a LONG launch of them is bound by
+    // wave slots x chain, and fewer, fatter waves amortise it (BEM fixture tiled to 0.7 GB: fused
+    // 4.4 -> 4.9 TB/s, forward-only 5.7 -> 6.2 TB/s).  So: W = 8 KB, unless the byte-weighted lane
+    // fill is below fat_fill_below, then W = clamp(operator bytes / target_waves, 8 KB, 32 KB)
+    // (target_waves = 4 rounds of the ~8 K resident waves; measured optimum 16-32 KB on 0.7-2.2 GB
+    // operators, 64 KB loses 2-3 % again).  Row groups of >= W get 2 waves, >= 3 W get 4;
+    // non-exclusive groups are cut into workgroup items of 4 W.  BSM_WAVE_BYTES fixes W.
+    int64_t wave_bytes = 0;              // 0: automatic
+    int64_t target_waves = 32768;        // BSM_TARGET_WAVES
+    double fat_fill_below = 0.9;         // BSM_FAT_FILL_BELOW
+    int64_t wave_bytes_min = 8 << 10, wave_bytes_max = 32 << 10;
+    int64_t split2_bytes = 0;     // row groups at least this big get 2 waves (0: W)
+    int64_t split4_bytes = 0;     // ... and 4 waves (0: 3 W)
+    int64_t wgitem_max_bytes = 0;   // non-exclusive groups are cut into items this big (0: 4 W)
     int chunk_rows = kMaxRowsPerChunk;  // blocks taller than this are cut into chunks
     int64_t deep_group_bytes = 128 << 10;  // auto mode: row groups above this are "deep" (BSM_DEEP_GROUP_BYTES)
     int64_t deep_total_bytes = 64 << 20;  // ... and only operators at least this big are split (BSM_DEEP_TOTAL_BYTES)

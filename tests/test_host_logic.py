@@ -203,6 +203,24 @@ def test_image_symmetric_fixture(bsm, oracle, key, dtype, part):
     _check_image(bsm, oracle, p, A, dtype)
 
 
+@pytest.mark.parametrize("wave_bytes", ["65536", "20000"])
+def test_image_with_fat_waves_of_long_launches(bsm, oracle, monkeypatch, wave_bytes):
+    # operators of hundreds of MB give every wave up to 64 KB (bsm_analysis.h Tunables::wave_bytes);
+    # forced here on small ones: pieces of several 8 KB iterations and several x chunks per wave
+    monkeypatch.setenv("BSM_WAVE_BYTES", wave_bytes)
+    p = bsm.synthetic.config5(n=4000, lo=16, hi=160, halfband=3)
+    A = bsm.synthetic.build(p, device=NODEV)
+    monkeypatch.delenv("BSM_WAVE_BYTES")
+    B = bsm.synthetic.build(p, device=NODEV)
+    assert A.stats()["ntasks"] < B.stats()["ntasks"]
+    _check_image(bsm, oracle, p, A, np.float64)
+    monkeypatch.setenv("BSM_WAVE_BYTES", wave_bytes)
+    q = bsm.synthetic.config2(n=6000, lo=20, hi=64, nblocks=400, dtype=np.float32)
+    _check_image(bsm, oracle, q, bsm.synthetic.build(q, device=NODEV, transpose_image=True), np.float32)
+    r = fixture_problem("cuboid")
+    _check_image(bsm, oracle, r, bsm.synthetic.build(r, device=NODEV, accumulate="gather"), np.complex128)
+
+
 @pytest.mark.parametrize("key", ["cuboid", "sphere"])
 def test_image_blocksparse_fixture(bsm, oracle, key):
     p = fixture_as_blocksparse(key)
