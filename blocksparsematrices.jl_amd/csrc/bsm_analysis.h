@@ -62,14 +62,16 @@ struct Tunables {
     // iteration and pay the fixed part of the chain more often: a LONG launch of them is bound by
     // wave slots x chain, and fewer, fatter waves amortise it (BEM fixture tiled to 0.7 GB: fused
     // 4.4 -> 4.9 TB/s, forward-only 5.7 -> 6.2 TB/s).  So: W = 8 KB, unless the byte-weighted lane
-    // fill is below fat_fill_below, then W = clamp(operator bytes / target_waves, 8 KB, 32 KB)
-    // (target_waves = 4 rounds of the ~8 K resident waves; measured optimum 16-32 KB on 0.7-2.2 GB
-    // operators, 64 KB loses 2-3 % again).  Row groups of >= W get 2 waves, >= 3 W get 4;
-    // non-exclusive groups are cut into workgroup items of 4 W.  BSM_WAVE_BYTES fixes W.
+    // fill is below fat_fill_below and the operator is long enough (operator bytes / target_waves >=
+    // 10 KB, i.e. >= 0.33 GB), then W = min(operator bytes / target_waves, 24 KB), a row group gets its
+    // second wave only from 2 W on and never four (target_waves = 4 rounds of the ~8 K resident
+    // waves; measured on 0.3-2.2 GB operators: waves of 20-45 KB are the optimum, 64 KB lose again).
+    // Otherwise row groups of >= W get 2 waves, >= 3 W get 4.  Non-exclusive groups are cut into
+    // workgroup items of 4 W.  BSM_WAVE_BYTES fixes W.
     int64_t wave_bytes = 0;              // 0: automatic
     int64_t target_waves = 32768;        // BSM_TARGET_WAVES
     double fat_fill_below = 0.9;         // BSM_FAT_FILL_BELOW
-    int64_t wave_bytes_min = 8 << 10, wave_bytes_max = 32 << 10;
+    int64_t wave_bytes_min = 8 << 10, wave_bytes_max = 24 << 10;
     int64_t split2_bytes = 0;     // row groups at least this big get 2 waves (0: W)
     int64_t split4_bytes = 0;     // ... and 4 waves (0: 3 W)
     int64_t wgitem_max_bytes = 0;   // non-exclusive groups are cut into items this big (0: 4 W)

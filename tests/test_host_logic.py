@@ -221,6 +221,21 @@ def test_image_with_fat_waves_of_long_launches(bsm, oracle, monkeypatch, wave_by
     _check_image(bsm, oracle, r, bsm.synthetic.build(r, device=NODEV, accumulate="gather"), np.complex128)
 
 
+def test_bytes_per_wave_follow_lane_fill_and_operator_size(bsm, monkeypatch):
+    # long launches of row groups that do not fill their lanes get fat waves (Tunables::wave_bytes):
+    # "long" is scaled down to test size through BSM_TARGET_WAVES
+    low = bsm.synthetic.config5(n=6000, lo=8, hi=28, halfband=6)    # 8-28 rows in 8 / 16 / 32 lanes
+    full = bsm.synthetic.config5(n=6000, lo=64, hi=64, halfband=2)   # 64 rows in 64 lanes
+    def tasks(p):
+        return bsm.synthetic.build(p, device=NODEV).stats()["ntasks"]
+    thin_low, thin_full = tasks(low), tasks(full)
+    monkeypatch.setenv("BSM_TARGET_WAVES", "64")
+    assert tasks(low) < 0.7 * thin_low
+    assert tasks(full) == thin_full
+    monkeypatch.setenv("BSM_TARGET_WAVES", "1000000")  # too short to pay
+    assert tasks(low) == thin_low
+
+
 @pytest.mark.parametrize("key", ["cuboid", "sphere"])
 def test_image_blocksparse_fixture(bsm, oracle, key):
     p = fixture_as_blocksparse(key)
