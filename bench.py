@@ -386,6 +386,20 @@ def run_c2(args, bsm, torch, dist, np, rank, world, barrier, reduce_scalars):
         cold.sort()
         extra["cold_median_us"] = round(cold[len(cold) // 2] * 1e6, 2)
         extra["cold_GBps"] = round(alg_bytes / cold[len(cold) // 2] / 1e9, 1)
+        # the same with a READ sweep of 512 MiB as the flush: the operator is out of every cache, but
+        # the launch does not have to evict 256 MiB of dirty lines first
+        cold = []
+        for _ in range(20):
+            flush.sum()
+            a, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            plan()
+            b_.record()
+            torch.cuda.synchronize()
+            cold.append(a.elapsed_time(b_) * 1e-3)
+        cold.sort()
+        extra["cold_clean_median_us"] = round(cold[len(cold) // 2] * 1e6, 2)
+        extra["cold_clean_GBps"] = round(alg_bytes / cold[len(cold) // 2] / 1e9, 1)
         del flush
         # driver-timed HBM-streaming legs (operators far larger than the 256 MiB Infinity Cache),
         # generated in HBM and packed by the device-side packer
