@@ -21,6 +21,7 @@ prob = {"c2": lambda: S.config2(), "c3": lambda: S.config3(), "c3s": lambda: S.c
         "c2u": lambda: S.config2(n=100000, lo=36, hi=36, nblocks=5000),
         "c2p": lambda: S.config2(n=100000, lo=32, hi=32, nblocks=6400),
         "c2w": lambda: S.config2(n=100000, lo=64, hi=64, nblocks=1650), "c5s": lambda: S.config5(n=600_000),
+        "c2x20": lambda: S.config2(n=2_000_000, nblocks=100_000),
         "c5u64": lambda: S.config5(n=600_000, lo=64, hi=64),
         "c5u128": lambda: S.config5(n=600_000, lo=128, hi=128),
         "c5u40": lambda: S.config5(n=300_000, lo=40, hi=40),

@@ -11,6 +11,8 @@ S = bsm.synthetic
 p = {"c2": S.config2, "c2p": lambda: S.config2(n=100000, lo=32, hi=32, nblocks=6400),
      "c2w": lambda: S.config2(n=100000, lo=64, hi=64, nblocks=1650),
      "bem": lambda: S.config5(n=400_000, lo=8, hi=28, halfband=8),
+     "c2x20": lambda: S.config2(n=2_000_000, nblocks=100_000),
+     "c4s": lambda: S.config4(row_lo=0, row_hi=1953),
      "c3s": lambda: S.config3(nseg=800)}[which]()
 A = S.build(p)
 st = A.stats()
