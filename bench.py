@@ -115,31 +115,39 @@ def main():
     dev_index = local_rank if args.device is None else args.device
     torch.cuda.set_device(dev_index)
     dist = None
-    red_dev = "cuda"  # where the scalar reductions over ranks live
+    # comm: the process group the data path and the scalar reductions use.  `fallback` is a gloo group
+    # over the same ranks: if the first RCCL exchange of a workload RAISES on any rank (this path has
+    # never met real multi-GPU hardware before the driver's run), every rank switches to it together
+    # and the JSON line says so -- a slow measured line instead of none.
+    comm = {"group": None, "dev": "cuda", "name": args.backend, "fallback": None}
     if world > 1:
+        import datetime
         import torch.distributed as dist
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index),
+                                    timeout=datetime.timedelta(minutes=10))
         else:
             dist.init_process_group(args.backend)
-            red_dev = "cpu"
+            comm["dev"] = "cpu"
+        comm["fallback"] = dist.new_group(backend="gloo")
     workload = args.workload
     if workload == "auto":
         workload = "c2" if world == 1 else "c5"
 
     def barrier():
         if dist is not None:
-            dist.barrier()
+            dist.barrier(group=comm["group"])
         torch.cuda.synchronize()
 
     def reduce_scalars(elapsed, nbytes):
         if dist is None:
             return elapsed, float(nbytes)
-        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        b = torch.tensor([float(nbytes)], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(b, op=dist.ReduceOp.SUM)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=comm["dev"])
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=comm["group"])
+        b = torch.tensor([float(nbytes)], dtype=torch.float64, device=comm["dev"])
+        dist.all_reduce(b, op=dist.ReduceOp.SUM, group=comm["group"])
         return float(t.item()), float(b.item())
+    reduce_scalars.comm = comm
 
     if workload == "c5":
         out = run_partitioned(args, bsm, torch, dist, np, rank, world, barrier, reduce_scalars)
@@ -148,7 +156,7 @@ def main():
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:
-        dist.barrier()
+        dist.barrier(group=comm["group"])
         dist.destroy_process_group()
 
 
@@ -209,12 +217,33 @@ def run_partitioned(args, bsm, torch, dist, np, rank, world, barrier, reduce_sca
             x.fill_(float("nan"))
             x[own[0] - 1:own[1]] = keep
         y = torch.full((n,), float("nan"), dtype=x.dtype, device="cuda")
-        P = D.RowPartitioned(A, own, touched, gather=False, symmetric=sym, xneed=touched if sym else None)
+        comm = reduce_scalars.comm
+        P = D.RowPartitioned(A, own, touched, group=comm["group"], gather=False, symmetric=sym,
+                             xneed=touched if sym else None)
 
         def step():
             # symmetric: x halo send/recv -> fused local product -> partial-y halo send/recv + add;
             # VBCRS (scattered columns): all-gather of the x slices -> local product
             P.mul(y, x, x_distributed=True)
+
+        if dist is not None and comm["fallback"] is not None and comm["group"] is None:
+            # first exchange of this workload, guarded (see `comm` in main)
+            err = None
+            try:
+                if os.environ.get("BSM_BENCH_FAIL_FIRST"):  # rehearsal of the fallback (every rank raises:
+                    # a rank that raised while its peers are inside the exchange would leave them waiting)
+                    raise RuntimeError("simulated failure of the first exchange (BSM_BENCH_FAIL_FIRST)")
+                step()
+                torch.cuda.synchronize()
+            except Exception as e:  # noqa: BLE001 -- anything the collective layer throws
+                err = repr(e)
+            ok = torch.tensor([0.0 if err else 1.0], dtype=torch.float64)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=comm["fallback"])
+            if ok.item() < 1.0:
+                comm.update(group=comm["fallback"], dev="cpu",
+                            name="gloo (the %s exchange raised on a rank%s)" % (args.backend, ": " + err[:200] if err else ""))
+                P = D.RowPartitioned(A, own, touched, group=comm["group"], gather=False, symmetric=sym,
+                                     xneed=touched if sym else None)
 
         for _ in range(warmup):
             step()
@@ -277,7 +306,7 @@ def run_partitioned(args, bsm, torch, dist, np, rank, world, barrier, reduce_sca
                                "generated in HBM (SplitMix64 seed 0xB5A5)" % world,
                    "global_rows": r5["n"], "alg_bytes_total": int(r5["total_bytes"]),
                    "partition": "diagonal segments by stored bytes (bsm_partition_rows)",
-                   "collectives": "ncclSend/ncclRecv (x halo, partial-y halo)" if args.backend == "nccl" else args.backend,
+                   "collectives": "ncclSend/ncclRecv (x halo, partial-y halo)" if reduce_scalars.comm["name"] == "nccl" else reduce_scalars.comm["name"],
                    "frac_of_hbm_peak": round(value / (HBM_PEAK_GBPS * world), 4)},
         "roofline": roofline,
     }
