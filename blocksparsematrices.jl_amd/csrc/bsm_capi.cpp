@@ -360,6 +360,8 @@ std::string build_transpose_image(bsm_matrix_s *A, const std::vector<BlockIn> &i
 // strip-packed value stream is written by a kernel straight from the caller's device blocks.
 hipError_t device_pack(Analysis &an, void **d_values) {
     hipError_t e = hipMalloc(d_values, (size_t)std::max<int64_t>(an.value_bytes, 16));
+    if (e == hipSuccess && std::getenv("BSM_TIMING"))
+        std::fprintf(stderr, "[bsm] values at %p (%lld bytes)\n", *d_values, (long long)an.value_bytes);
     if (e != hipSuccess) return e;
     e = hipMemsetAsync(*d_values, 0, (size_t)std::max<int64_t>(an.value_bytes, 16), nullptr);  // strip tails
     void *d_plan = nullptr, *d_cp = nullptr;
