@@ -431,6 +431,30 @@ def test_degenerate_shapes_and_scalars(torch_cuda, bsm, oracle):
     assert np.array_equal(np.isfinite(yn), np.isfinite(refn))
 
 
+@pytest.mark.parametrize("wave_bytes", ["24576", "11000"])
+def test_fat_waves_of_long_low_fill_launches(torch_cuda, bsm, oracle, monkeypatch, wave_bytes):
+    # long launches of row groups that do not fill their lanes get 10-24 KB waves (several 8 KB
+    # iterations and several x chunks per wave, one or two waves per row group); forced here through
+    # BSM_WAVE_BYTES on operators the oracle finishes in seconds: every op, every accumulate mode,
+    # several right-hand sides, the reference's fixture included
+    monkeypatch.setenv("BSM_WAVE_BYTES", wave_bytes)
+    p = bsm.synthetic.config5(n=20000, lo=8, hi=28, halfband=6)
+    thin = None
+    for acc in ("auto", "colored", "gather"):
+        A = bsm.synthetic.build(p, accumulate=acc)
+        check_all(torch_cuda, bsm, oracle, p, A, np.float64, host_too=False)
+        thin = thin or A.stats()["ntasks"]
+    _check_multi(torch_cuda, bsm, oracle, p, bsm.synthetic.build(p), np.float64, nrhs_list=(8, 3), ops=[N, T])
+    q = fixture_problem("cuboid")
+    check_all(torch_cuda, bsm, oracle, q, bsm.synthetic.build(q), np.complex128, host_too=False)
+    r = fixture_as_blocksparse("cuboid")
+    check_all(torch_cuda, bsm, oracle, r, bsm.synthetic.build(r), np.complex128, host_too=False)
+    v = bsm.synthetic.config2(n=20000, lo=20, hi=64, nblocks=1500, dtype=np.float32)
+    check_all(torch_cuda, bsm, oracle, v, bsm.synthetic.build(v, transpose_image=True), np.float32, host_too=False)
+    monkeypatch.delenv("BSM_WAVE_BYTES")
+    assert bsm.synthetic.build(p).stats()["ntasks"] > thin  # (the default for an operator this small: 8 KB)
+
+
 def test_vbcrs_wide_block_row_many_blocks(torch_cuda, bsm, oracle):
     # a block row with many blocks (> 3 column runs -> cols pool path) and unsorted input order
     rng = np.random.default_rng(42)
