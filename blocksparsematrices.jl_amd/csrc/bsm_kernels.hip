@@ -501,7 +501,8 @@ __device__ __forceinline__ T run_panel(const WaveD &wd, const uint4 *__restrict_
 // Occupancy is what the small-panel (BEM-shaped) products live on: a small panel is a chain of
 // dependent memory round trips, hidden only by other resident waves.
 //   fp64 forward-only: capped at 80 VGPRs (>= 6 waves per SIMD = 1536 resident workgroups: every
-//     workgroup of a C2-sized launch is resident at once); compiles to 72.
+//     workgroup of a C2-sized launch is resident at once); compiles to 78 (a cap of 72 = 7 waves
+//     compiles to 70 without scratch and measures the same: C2, 1 GB VBCRS, BEM forward).
 //   fp64 fused: capped at 64 VGPRs = 8 waves per SIMD, no scratch; with 20 KB of LDS per workgroup
 //     exactly 8 workgroups fit a CU (+11-13 % on 3-28-row fp64 panels over 6 waves).
 //   complex128: capped at 80 (the fused instance compiles to 71: 7 waves).
