@@ -279,10 +279,10 @@ __device__ __forceinline__ WaveD load_wave(const WaveWork *__restrict__ wp) {
 // ----------------------------------------------------------------------------------------
 // one wave streams its pieces; returns the forward partial sum of row (lane % P)
 // ----------------------------------------------------------------------------------------
-// x slice staged per wave in LDS.  Forward-only kernels: 512 columns (256 for complex128), <= 4 KB.
-// Fused kernels: 2 KB (512 fp32 ... 128 complex128 columns) -- with the y window and the emission
-// staging their occupancy is bounded by LDS and by the registers of the unrolled staging loop
-// (fp64: 111 -> 80 VGPRs, 4 -> 6 waves per SIMD; +11 % on 3-28-row BEM panels).
+// x slice staged per wave in LDS.  Forward-only kernels: 2 KB (512 fp32 / 256 fp64, complex64 / 128
+// complex128 columns): the batched gather keeps one x entry per 64 columns in registers.
+// Fused kernels: 2 KB too (512 fp32 ... 128 complex128 columns) -- with the y window and the emission
+// staging their occupancy is bounded by LDS and by the registers of the gather.
 template <typename T, bool TRN = false> constexpr int x_chunk_cols() {
     return TRN ? 2048 / (int)sizeof(T) : (sizeof(T) >= 16 ? 128 : (sizeof(T) == 8 ? 256 : 512));
 }
