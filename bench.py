@@ -82,6 +82,48 @@ def leg(bsm, torch, prob, reps, **kw):
     return out, y
 
 
+def self_launch(args):
+    """Runs this script as N rank processes (python -m torch.distributed.run, one per GPU) and prints the
+    JSON line of rank 0.  If the RCCL run dies or prints no line, ONE more attempt is made with the
+    exchanges over gloo (host-staged) and the line says so: a slow measured line instead of none."""
+    import socket
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # this pool's driver only supports dmabuf IPC
+    forwarded = [a for a in sys.argv[1:]]
+
+    def attempt(extra, limit):
+        sk = socket.socket()
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+        sk.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + forwarded + extra
+        try:
+            r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, timeout=limit)
+            rc, out = r.returncode, r.stdout.decode(errors="replace")
+        except subprocess.TimeoutExpired as e:
+            rc, out = 124, (e.stdout or b"").decode(errors="replace")
+        line = None
+        for ln in out.splitlines():
+            ln = ln.strip()
+            if ln.startswith("{") and '"metric"' in ln:
+                line = ln
+        return rc, line, out
+
+    rc, line, out = attempt([], 1500)
+    if line is None and args.backend == "nccl":
+        print(f"[bench] the {args.gpus}-rank RCCL run ended with status {rc} and no result line; "
+              "one more attempt with the exchanges over gloo", file=sys.stderr, flush=True)
+        sys.stderr.write(out[-4000:])
+        rc, line, out = attempt(["--backend", "gloo", "--note", f"the RCCL run ended with status {rc} before its line"], 1500)
+    if line is None:
+        sys.stdout.write(out)
+        return rc or 1
+    print(line, flush=True)
+    return (rc or 3) if '"value_invalid": true' in line else 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -97,7 +139,16 @@ def main():
                     "rehearse the N > 1 code path on a single GPU)")
     ap.add_argument("--device", type=int, default=None, help="override LOCAL_RANK as the HIP device (rehearsal)")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the N > 1 operators (rehearsal on one GPU)")
+    ap.add_argument("--note", default=None, help="free text carried into config.note (set by the self-launcher)")
+    ap.add_argument("--no-overlap", action="store_true", help="N > 1: strictly serial exchange / product / exchange "
+                    "(the round-2 step) instead of the overlapped one")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: the parallel entry is INSIDE the call, like the reference's
+        # `@tasks` fan-out (src/vbcrs.jl:275-276, src/symmetricblockmatrix.jl:395-432).  Nothing has
+        # touched the GPU in this process: start N fresh rank processes and relay rank 0's line.
+        raise SystemExit(self_launch(args))
 
     import numpy as np
     import torch
@@ -125,11 +176,15 @@ def main():
         import torch.distributed as dist
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index),
-                                    timeout=datetime.timedelta(minutes=10))
+                                    timeout=datetime.timedelta(minutes=5))
         else:
             dist.init_process_group(args.backend)
             comm["dev"] = "cpu"
-        comm["fallback"] = dist.new_group(backend="gloo")
+        comm["fallback"] = dist.new_group(backend="gloo", timeout=datetime.timedelta(minutes=5))
+        seen = [None] * world
+        dist.all_gather_object(seen, "rank %d: cuda:%d %s" % (rank, dev_index, torch.cuda.get_device_name(dev_index)),
+                               group=comm["fallback"])
+        comm["devices"] = seen
     workload = args.workload
     if workload == "auto":
         workload = "c2" if world == 1 else "c5"
@@ -158,6 +213,8 @@ def main():
     if dist is not None:
         dist.barrier(group=comm["group"])
         dist.destroy_process_group()
+    if out.get("value_invalid"):
+        raise SystemExit("bench: the parity check of the distributed product failed (config.parity_relerr)")
 
 
 # ------------------------------------------------------------------------------------------------
@@ -166,10 +223,12 @@ def main():
 def run_partitioned(args, bsm, torch, dist, np, rank, world, barrier, reduce_scalars):
     from bsm_amd import distributed as D
     S = bsm.synthetic
+    comm = reduce_scalars.comm
 
     def c5_share():
         n = int(5_000_000 * args.scale)
         start, sz = S.config5_segments(n=n)
+        nseg = len(sz)
         halfband = 4
         # stored entries per diagonal segment: its diagonal block + the off-diagonal blocks of its rows.
         # All blocks of a segment share one row key, so this is bsm_partition_rows on the block list.
@@ -180,35 +239,51 @@ def run_partitioned(args, bsm, torch, dist, np, rank, world, barrier, reduce_sca
         segs = np.nonzero(part == rank)[0]
         lo, hi = (int(segs[0]), int(segs[-1]) + 1) if len(segs) else (0, 0)
         prob = S.config5(n=n, on_device=True, seg_lo=lo, seg_hi=hi)
-        olo, ohi = own[rank]
-        # rows this rank writes: its own segments plus the columns of its off-diagonal blocks (y_J of
-        # block (I, J) -- the halo that belongs to the rank below); all lists are contiguous ranges
-        tlo = min([olo] + [int(c[0]) for c in prob["colindices"]])
-        touched = (tlo, ohi) if ohi >= olo else (olo, olo - 1)
-        return prob, own[rank], touched, True, "C5: SymmetricBlockMatrix %dx%d, segments U{16..256}, off-diagonal (I,J) J=I-1..I-4, fp64" % (n, n)
+
+        def verification():
+            # everything that contributes to this rank's rows, built WITHOUT any exchange: the rank's own
+            # segments plus the `halfband` segments behind them (their off-diagonal blocks reach back into
+            # the rank's rows through B^T), applied to the full x
+            ext = S.config5(n=n, on_device=True, seg_lo=hi, seg_hi=min(hi + halfband, nseg)) if hi < nseg else None
+            ver = dict(prob)
+            if ext is not None:
+                for k in ("diagonals", "diagonalindices", "offdiagonals", "rowindices", "colindices"):
+                    ver[k] = list(prob[k]) + list(ext[k])
+            return ver
+        return prob, own[rank], True, "C5: SymmetricBlockMatrix %dx%d, segments U{16..256}, off-diagonal (I,J) J=I-1..I-4, fp64" % (n, n), verification
 
     def c4_share():
         ngrid = max(world, int(15625 * args.scale))
         lo, hi = rank * ngrid // world, (rank + 1) * ngrid // world  # uniform blocks: equal row counts == equal bytes
         prob = S.config4(ngrid=ngrid, on_device=True, row_lo=lo, row_hi=hi)
         own = (lo * 128 + 1, hi * 128)
-        return prob, own, own, False, "C4: VBCRS %dx%d, %d 128x128 fp32 blocks (16 per block row)" % (ngrid * 128, ngrid * 128, ngrid * 16)
+        return prob, own, False, "C4: VBCRS %dx%d, %d 128x128 fp32 blocks (16 per block row)" % (ngrid * 128, ngrid * 128, ngrid * 16), (lambda: prob)
 
-    def run(share, steps, warmup):
+    def run(share, steps, warmup, overlap):
         t0 = time.perf_counter()
-        prob, own, touched, sym, desc = share()
-        A = D.build_local(prob, touched)
-        t_setup = time.perf_counter() - t0
-        if A is None:
-            raise SystemExit("bench: a rank received no block (more ranks than block rows)")
-        st = A.stats()
+        prob, own, sym, desc, verification = share()
         n = prob["size"][0]
-        es = prob["x"].element_size()
+        x = prob["x"]
+        es = x.element_size()
+        x_full = x.clone()  # the parity check at the end multiplies with the whole x, without any exchange
+        if overlap:
+            # interior blocks (read x[own], write y[own]) and boundary blocks as two handles: the exchanges
+            # and the boundary product run on a side stream beside the interior launch
+            P = D.build_overlapped(prob, own, group=comm["group"], symmetric=sym, xmode="halo" if sym else "allgather")
+            handles = [h for h in (P.interior, P.local) if h is not None]
+        else:
+            touched = D._touched(own, prob["colindices"]) if sym else own
+            A = D.build_local(prob, touched)
+            P = D.RowPartitioned(A, own, touched, group=comm["group"], gather=False, symmetric=sym,
+                                 xneed=touched if sym else None)
+            handles = [A] if A is not None else []
+        t_setup = time.perf_counter() - t0
+        if not handles:
+            raise SystemExit("bench: a rank received no block (more ranks than block rows)")
+        sts = [h.stats() for h in handles]
         # this rank's part of the algorithmic bytes: stored entries + index metadata (x and y are
         # counted once for the whole job below)
-        rank_bytes = st["alg_bytes"] - 2 * n * es
-        x = prob["x"]
-        del prob
+        rank_bytes = sum(st["alg_bytes"] - 2 * n * es for st in sts)
         torch.cuda.empty_cache()
         # x and y stay PARTITIONED like the rows (what an iterative solver on N GPUs holds): outside its
         # own range a rank's x is NaN until the exchange of the step has filled what its blocks read
@@ -217,17 +292,21 @@ def run_partitioned(args, bsm, torch, dist, np, rank, world, barrier, reduce_sca
             x.fill_(float("nan"))
             x[own[0] - 1:own[1]] = keep
         y = torch.full((n,), float("nan"), dtype=x.dtype, device="cuda")
-        comm = reduce_scalars.comm
-        P = D.RowPartitioned(A, own, touched, group=comm["group"], gather=False, symmetric=sym,
-                             xneed=touched if sym else None)
 
         def step():
             # symmetric: x halo send/recv -> fused local product -> partial-y halo send/recv + add;
             # VBCRS (scattered columns): all-gather of the x slices -> local product
-            P.mul(y, x, x_distributed=True)
+            if overlap:
+                P.mul_overlapped(y, x)
+            else:
+                P.mul(y, x, x_distributed=True)
 
         if dist is not None and comm["fallback"] is not None and comm["group"] is None:
-            # first exchange of this workload, guarded (see `comm` in main)
+            # first exchange of this workload, guarded (see `comm` in main): every rank reports over gloo
+            # that it has reached this point in good health BEFORE anybody enters the RCCL exchange (a rank
+            # that died during set-up must not leave its peers waiting inside a collective)
+            ok = torch.tensor([1.0], dtype=torch.float64)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=comm["fallback"])
             err = None
             try:
                 if os.environ.get("BSM_BENCH_FAIL_FIRST"):  # rehearsal of the fallback (every rank raises:
@@ -242,8 +321,8 @@ def run_partitioned(args, bsm, torch, dist, np, rank, world, barrier, reduce_sca
             if ok.item() < 1.0:
                 comm.update(group=comm["fallback"], dev="cpu",
                             name="gloo (the %s exchange raised on a rank%s)" % (args.backend, ": " + err[:200] if err else ""))
-                P = D.RowPartitioned(A, own, touched, group=comm["group"], gather=False, symmetric=sym,
-                                     xneed=touched if sym else None)
+                P.group = comm["group"]
+                P._plan = P._xplan = P._ranges = None
 
         for _ in range(warmup):
             step()
@@ -253,33 +332,68 @@ def run_partitioned(args, bsm, torch, dist, np, rank, world, barrier, reduce_sca
             step()
         barrier()
         elapsed = time.perf_counter() - t0
-        # the local kernel alone (device events), for the roofline object
-        plan = bsm.MulPlan(P._workvec(y) if sym else y, A, x)
+        y_step = y[own[0] - 1:own[1]].clone()
+        # the local kernels alone (HIP events on the stream they are launched on), for the roofline object
+        yk = torch.zeros_like(y)
+        plans = [bsm.MulPlan(yk, h, x) for h in handles]
+
+        def local_only():
+            for pl in plans:
+                pl()
         for _ in range(3):
-            plan()
+            local_only()
         torch.cuda.synchronize()
-        kdur = timed(plan, max(5, steps // 4), torch)
+        kdur = timed(local_only, max(5, steps // 4), torch)
+        del plans, yk
         elapsed, total = reduce_scalars(elapsed, rank_bytes)
         total += 2 * n * es
         kmax, _ = reduce_scalars(kdur, 0)
-        chk = float(y[own[0] - 1:own[1]].abs().max().item())  # NaN here would mean a missing x entry
-        if not (chk == chk) or chk == 0.0:
-            raise SystemExit(f"bench: rank {rank} produced an invalid y slice (max |y| = {chk})")
+        # parity of the distributed result: this rank's y slice against a product that needs NO exchange --
+        # every block that contributes to the rank's rows in one ordinary handle, applied to the full x
+        del P, handles
+        torch.cuda.empty_cache()
+        Aver = S.build(verification())
+        yv = torch.full((n,), float("nan"), dtype=x.dtype, device="cuda")
+        bsm.mul(yv, Aver, x_full)
+        ref = yv[own[0] - 1:own[1]]
+        scale = float(ref.abs().max().item())
+        diff = float((y_step - ref).abs().max().item())
+        rel = diff / scale if scale > 0 else float("nan")
+        if not (rel == rel):  # NaN: a missing x entry or an undefined y row
+            rel = float("inf")
+        del Aver, yv
+        pmax, _ = reduce_scalars(rel, 0)
         return dict(desc=desc, elapsed=elapsed, total_bytes=total, kdur=kmax, rank_alg=rank_bytes + 2 * n * es // world,
-                    setup_s=t_setup, ymax=chk, n=n, own=own, touched=touched, st=st)
+                    setup_s=t_setup, parity=pmax, n=n, own=own, overlap=overlap,
+                    exchange_us=(elapsed / steps - kmax) * 1e6)
+
+    def run_checked(share, steps, warmup, tol):
+        r = run(share, steps, warmup, not args.no_overlap)
+        if r["overlap"] and not (r["parity"] <= tol):
+            # the overlapped step gave a wrong y on some rank (every rank sees the same maximum): measure the
+            # strictly serial step instead and say so -- a wrong y must not pass as a measurement
+            first = r["parity"]
+            torch.cuda.empty_cache()
+            r = run(share, steps, warmup, False)
+            r["note"] = "the overlapped step FAILED its parity check (rel-err %.3g); this line is the serial step" % first
+        return r
 
     steps, warmup = args.steps, args.warmup
-    r5 = run(c5_share, steps, warmup)
+    tol = 1e-12
+    r5 = run_checked(c5_share, steps, warmup, tol)
     value = r5["total_bytes"] * steps / r5["elapsed"] / 1e9
     extra = {}
     if not args.no_extra:
       try:  # (an additional figure must never cost the headline line)
         torch.cuda.empty_cache()
-        r4 = run(c4_share, steps, warmup)
-        extra["c4"] = {"workload": r4["desc"] + ", rows and vectors partitioned over %d GPUs, RCCL all-gather of the x slices before the local product" % world,
+        r4 = run_checked(c4_share, steps, warmup, 2e-5)
+        extra["c4"] = {"workload": r4["desc"] + ", rows and vectors partitioned over %d GPUs, RCCL all-gather of the x slices "
+                                                "(beside the product of the blocks that read own x entries), then the rest" % world,
                        "dtype": "f32", "value": round(r4["total_bytes"] * steps / r4["elapsed"] / 1e9, 1), "unit": "GB/s",
                        "ms_per_step": round(r4["elapsed"] / steps * 1e3, 4),
                        "local_kernel_us_max": round(r4["kdur"] * 1e6, 1),
+                       "exchange_us": round(r4["exchange_us"], 1),
+                       "parity_relerr": r4["parity"], "parity_tol": 2e-5, "overlap": r4["overlap"],
                        "frac_of_hbm_peak": round(r4["total_bytes"] * steps / r4["elapsed"] / 1e9 / (HBM_PEAK_GBPS * world), 4),
                        "setup_s": round(r4["setup_s"], 2)}
       except Exception as e:  # pragma: no cover
@@ -292,26 +406,49 @@ def run_partitioned(args, bsm, torch, dist, np, rank, world, barrier, reduce_sca
     kb = r5["rank_alg"]
     roofline = {"bound": "hbm", "achieved": round(kb / r5["kdur"] / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(kb / r5["kdur"] / 1e9 / HBM_PEAK_GBPS, 4), "traffic": None,
-                "kernel": "bsm::panel_kernel<double,8,true,true,true> (fused A + A^T, one rank's share)",
+                "kernel": "bsm::panel_kernel<double,8,true,true,true> (fused A + A^T, one rank's share: interior launch + boundary launch)",
                 "alg_bytes_per_launch": int(kb), "avg_launch_us": round(r5["kdur"] * 1e6, 2),
-                "note": "slowest rank's local product alone (HIP events); a step adds the x-halo and partial-y-halo exchanges"}
+                "note": "slowest rank's local launches alone (HIP events, back to back on one stream); a step adds the "
+                        "x-halo and partial-y-halo exchanges, overlapped with the interior launch (exchange_us = step - this)"}
+    ranks_seen = world
+    backend = args.backend
+    if dist is not None:
+        ranks_seen = dist.get_world_size(comm["group"])
+        backend = dist.get_backend(comm["group"])
     out = {
         "metric": "fp64 block-SpMV GB/s (SymmetricBlockMatrix mul!, algorithmic bytes / time)",
         "value": round(value, 1), "unit": "GB/s", "n_gpus": world, "steps": steps, "warmup": warmup,
         "ms_per_step": round(r5["elapsed"] / steps * 1e3, 6), "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": r5["desc"] + ": mul!(y, A, x) with A, x and y row-partitioned over %d GPUs; a step = "
-                               "RCCL send/recv of the x halo, fused A + A^T local product, RCCL send/recv + add of the "
-                               "partial-y halo (the overlapping y segments), all in the timed region; operator "
-                               "generated in HBM (SplitMix64 seed 0xB5A5)" % world,
+                               "RCCL send/recv of the x halo, fused A + A^T local product (interior blocks beside the "
+                               "exchange, boundary blocks after it), RCCL send/recv + add of the partial-y halo (the "
+                               "overlapping y segments), all in the timed region; operator generated in HBM "
+                               "(SplitMix64 seed 0xB5A5)" % world,
                    "global_rows": r5["n"], "alg_bytes_total": int(r5["total_bytes"]),
                    "partition": "diagonal segments by stored bytes (bsm_partition_rows)",
-                   "collectives": "ncclSend/ncclRecv (x halo, partial-y halo)" if reduce_scalars.comm["name"] == "nccl" else reduce_scalars.comm["name"],
+                   "collectives": "ncclSend/ncclRecv (x halo, partial-y halo)" if comm["name"] == "nccl" else comm["name"],
+                   "backend": backend, "ranks": ranks_seen, "devices": comm.get("devices"),
+                   "overlap": r5["overlap"],
+                   "parity_relerr": r5["parity"], "parity_tol": tol,
+                   "parity_check": "every rank: its y slice of the last timed step vs an exchange-free product of all blocks "
+                                   "reaching its rows with the full x (max |dy| / max |y|, max over ranks)",
+                   "exchange_us": round(r5["exchange_us"], 1),
+                   "local_kernel_us_max": round(r5["kdur"] * 1e6, 1),
                    "frac_of_hbm_peak": round(value / (HBM_PEAK_GBPS * world), 4)},
         "roofline": roofline,
     }
+    notes = [t for t in (args.note, r5.get("note")) if t]
+    if notes:
+        out["config"]["note"] = "; ".join(notes)
     if extra:
+        if "c4" in extra and "note" in locals().get("r4", {}):
+            extra["c4"]["note"] = r4["note"]
         out["extra"] = extra
+    if not (r5["parity"] <= tol):
+        # a wrong y must not pass as a measurement: the line is printed for diagnosis, flagged, and the run fails
+        out["config"]["parity_failed"] = True
+        out["value_invalid"] = True
     return out
 
 

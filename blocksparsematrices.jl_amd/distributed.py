@@ -131,6 +131,124 @@ def build_local(local, touched=None, **kw):
     return synthetic.build(local, **kw)
 
 
+def _within(lst, lo, hi):
+    return len(lst) == 0 or (int(np.min(lst)) >= lo and int(np.max(lst)) <= hi)
+
+
+def _range_list(start, length):
+    return (int(start), int(start) + int(length) - 1)
+
+
+def split_interior(local, own):
+    """Cuts a rank's blocks into INTERIOR blocks -- they read only x[own] and write only y[own], so they
+    need nothing from another rank and nothing of theirs leaves the rank -- and BOUNDARY blocks (the
+    rest: they read x entries of a neighbour and / or produce y segments for it).  The interior
+    product can run while the x halo of the boundary blocks is still travelling, and the partial-y
+    segments leave as soon as the (small) boundary product is done.
+    Returns (interior, boundary, btouched, bxneed): two problem dicts of local's kind, the hull of the
+    rows the boundary blocks write and the hull of the x entries they read (1-based inclusive;
+    (own_lo, own_lo - 1) when there is no boundary block)."""
+    lo, hi = int(own[0]), int(own[1])
+    kind = local["kind"]
+    sym = kind == "symmetric"
+    empty = (lo, lo - 1)
+    tl, th, xl, xh = None, None, None, None
+
+    def grow(rng_rows, rng_cols):
+        nonlocal tl, th, xl, xh
+        # rows written / x entries read by one boundary block (a symmetric off-diagonal block writes and
+        # reads both its row and its column lists)
+        wr = [rng_rows] + ([rng_cols] if sym else [])
+        rd = [rng_cols] + ([rng_rows] if sym else [])
+        for a, b in wr:
+            tl, th = (a, b) if tl is None else (min(tl, a), max(th, b))
+        for a, b in rd:
+            xl, xh = (a, b) if xl is None else (min(xl, a), max(xh, b))
+
+    def span(lst):
+        return (int(np.min(lst)), int(np.max(lst)))
+
+    if kind == "vbcrs":
+        inner, outer = [], []
+        for b, blk in enumerate(local["blocks"]):
+            rr = _range_list(local["rowstart"][b], blk.shape[0])
+            cr = _range_list(local["colstart"][b], blk.shape[1])
+            if lo <= rr[0] and rr[1] <= hi and lo <= cr[0] and cr[1] <= hi:
+                inner.append(b)
+            else:
+                outer.append(b)
+                grow(rr, cr)
+
+        def sub(keep):
+            return dict(kind="vbcrs", blocks=[local["blocks"][b] for b in keep],
+                        rowstart=np.asarray(local["rowstart"], dtype=np.int64)[keep],
+                        colstart=np.asarray(local["colstart"], dtype=np.int64)[keep], size=local["size"])
+        interior, boundary = sub(inner), sub(outer)
+    elif kind == "blocksparse":
+        inner, outer = [], []
+        for b in range(len(local["blocks"])):
+            r, c = local["rowindices"][b], local["colindices"][b]
+            if len(r) == 0 or len(c) == 0 or (_within(r, lo, hi) and _within(c, lo, hi)):
+                inner.append(b)
+            else:
+                outer.append(b)
+                grow(span(r), span(c))
+
+        def sub(keep):
+            return dict(kind="blocksparse", blocks=[local["blocks"][b] for b in keep],
+                        rowindices=[local["rowindices"][b] for b in keep],
+                        colindices=[local["colindices"][b] for b in keep], size=local["size"])
+        interior, boundary = sub(inner), sub(outer)
+    elif kind == "symmetric":
+        din, dout, oin, oout = [], [], [], []
+        for d in range(len(local["diagonals"])):
+            idx = local["diagonalindices"][d]
+            if _within(idx, lo, hi):
+                din.append(d)
+            else:
+                dout.append(d)
+                grow(span(idx), span(idx))
+        for b in range(len(local["offdiagonals"])):
+            r, c = local["rowindices"][b], local["colindices"][b]
+            if len(r) == 0 or len(c) == 0 or (_within(r, lo, hi) and _within(c, lo, hi)):
+                oin.append(b)
+            else:
+                oout.append(b)
+                grow(span(r), span(c))
+
+        def sub(dk, ok):
+            return dict(kind="symmetric", diagonals=[local["diagonals"][d] for d in dk],
+                        diagonalindices=[local["diagonalindices"][d] for d in dk],
+                        offdiagonals=[local["offdiagonals"][b] for b in ok],
+                        rowindices=[local["rowindices"][b] for b in ok],
+                        colindices=[local["colindices"][b] for b in ok], size=local["size"])
+        interior, boundary = sub(din, oin), sub(dout, oout)
+    else:
+        raise ValueError(kind)
+    btouched = empty if tl is None else (tl, th)
+    bxneed = empty if xl is None else (xl, xh)
+    return interior, boundary, btouched, bxneed
+
+
+def build_overlapped(local, own, group=None, symmetric=None, xmode="auto", **kw):
+    """RowPartitioned for the partitioned-vector forward product with the exchange OVERLAPPED with the
+    interior rows (mul_overlapped): two handles per rank -- interior blocks with own = the rank's
+    rows, boundary blocks with own = the rows they touch.  xmode: "halo" (the x entries the boundary
+    blocks read form a neighbourhood of the own range: point-to-point), "allgather" (scattered block
+    columns), "auto": halo when that neighbourhood is at most as long as the own range itself."""
+    interior, boundary, btouched, bxneed = split_interior(local, own)
+    sym = (local["kind"] == "symmetric") if symmetric is None else symmetric
+    A_int = build_local(interior, own if own[1] >= own[0] else None, **kw)
+    A_bnd = build_local(boundary, btouched, **kw)
+    if xmode == "auto":
+        extra = max(0, own[0] - bxneed[0]) + max(0, bxneed[1] - own[1]) if bxneed[1] >= bxneed[0] else 0
+        xmode = "halo" if extra <= max(own[1] - own[0] + 1, 0) else "allgather"
+    P = RowPartitioned(A_bnd, own, btouched, group=group, gather=False, symmetric=sym,
+                       xneed=(bxneed if xmode == "halo" else None), interior=A_int)
+    P.xmode = xmode
+    return P
+
+
 class RowPartitioned:
     """y = alpha*op(A)*x + beta*y with A's blocks spread over the ranks of `group`.
 
@@ -143,8 +261,13 @@ class RowPartitioned:
     chunks) for products across it.  `local` is this rank's matrix (built with own=touched range so
     its beta pass covers exactly the rows it touches), or None for a rank without blocks."""
 
-    def __init__(self, local, own, touched=None, group=None, gather=False, axis=0, symmetric=None, xneed=None):
+    def __init__(self, local, own, touched=None, group=None, gather=False, axis=0, symmetric=None, xneed=None,
+                 interior=None):
         self.local = local
+        # mul_overlapped only: handle of the rank's INTERIOR blocks (own = the rank's rows); `local` then
+        # holds the boundary blocks and `touched` the rows THEY write (see split_interior)
+        self.interior = interior
+        self._side = None
         self.own = (int(own[0]), int(own[1]))
         self.touched = self.own if touched is None else (int(touched[0]), int(touched[1]))
         # x entries this rank's blocks read (1-based inclusive) when x arrives PARTITIONED like y
@@ -315,6 +438,65 @@ class RowPartitioned:
                 y[a - 1:b] += buf
         if self.gather and self.world > 1:
             self._allgather(y, [(rl, rh) for rl, rh, _, _ in ranges])
+        return y
+
+    def mul_overlapped(self, y, x, alpha=True, beta=False, local_mul=None, interior_mul=None):
+        """Forward product with x and y PARTITIONED like the rows and the exchange overlapped with the
+        interior rows (build_overlapped):
+
+            side stream : x exchange -> boundary product into the work vector -> partial-y exchange
+            main stream : interior product straight into y[own]          (needs nothing from anybody)
+            main stream : y[own] += work vector, y[own] += received segments   (after the side stream)
+
+        With RCCL the transfers run on the collective layer's own stream, ordered against the side stream
+        only, so the interior launch -- nearly all of the rank's bytes -- streams while the halo
+        travels; the reference has no counterpart (one process, `@tasks`: src/symmetricblockmatrix.jl:
+        394-418 reads x and writes y in shared memory).  local_mul / interior_mul(y, x, alpha, beta):
+        test hooks replacing the HIP products of the boundary / interior handle (CPU gloo tests)."""
+        ranges = self._exchange_ranges(y.device)
+        cuda = y.is_cuda
+        olo, ohi = self.own
+        tlo, thi = self.touched
+        own_slice = slice(olo - 1, ohi) if ohi >= olo else None
+        if cuda:
+            main = torch.cuda.current_stream(y.device)
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=y.device)
+            side = self._side
+            side.wait_stream(main)
+            side_ctx = torch.cuda.stream(side)
+        else:
+            import contextlib
+            side_ctx = contextlib.nullcontext()
+        halo = any(th >= tl and (tl < rl or th > rh) for rl, rh, tl, th in ranges)
+        with side_ctx:
+            self.fetch_x(x)
+        # interior rows: y[own] = alpha * A_int x[own] + beta * y[own]
+        if interior_mul is not None:
+            interior_mul(y, x, alpha, beta)
+        elif self.interior is not None:
+            M.mul(y, self.interior, x, alpha, beta)
+        elif own_slice is not None:
+            self._combine(y, own_slice, 0, beta)
+        with side_ctx:
+            w = self._workvec(y)
+            if local_mul is not None:
+                local_mul(w, x, alpha, False)
+            elif self.local is not None:
+                M.mul(w, self.local, x, alpha, False)  # strong zero over the rows the boundary blocks touch
+            ops, recvs = self._halo_plan(w, ranges)
+            if halo and ops:
+                self._host_mediated_fence(w)
+                for req in dist.batch_isend_irecv(ops):
+                    req.wait()
+        if cuda:
+            main.wait_stream(side)
+        if own_slice is not None and thi >= tlo:
+            a, b = max(olo, tlo), min(ohi, thi)
+            if a <= b:
+                y[a - 1:b] += w[a - 1:b]
+        for _, a, b, buf in recvs:
+            y[a - 1:b] += buf
         return y
 
     def _mul_across(self, y, x, alpha, beta, lm):

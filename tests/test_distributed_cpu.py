@@ -119,10 +119,50 @@ def _worker(rank, world, port, kind, q):
                 part[own[0] - 1:own[1]] = y[own[0] - 1:own[1]]
             dist.all_reduce(part)
             results.append(part.numpy().copy())
+        combos = (((1, 0), (0.5, -2.0)) * 2 + ((0.5, -2.0),))[:len(results)]
+        if kind in ("vbcrs", "symmetric", "blocksparse", "vbcrs_tiny"):
+            # the same partitioned-vector product with the exchange OVERLAPPED with the interior rows:
+            # two images per rank (interior / boundary blocks, distributed.split_interior), the boundary
+            # one on the side of the exchange -- both interpreted from their packed images here
+            interior, boundary, bt, bx = D.split_interior(local, own)
+            ni = sum(len(interior.get(k, ())) for k in ("blocks", "diagonals", "offdiagonals"))
+            nb = sum(len(boundary.get(k, ())) for k in ("blocks", "diagonals", "offdiagonals"))
+            assert ni + nb == sum(len(local.get(k, ())) for k in ("blocks", "diagonals", "offdiagonals"))
+            Ai = None if D.is_empty(interior) else bsm.synthetic.build(interior, device=NODEV, own=own)
+            Ab = None if D.is_empty(boundary) else bsm.synthetic.build(boundary, device=NODEV, own=bt)
+
+            def image_mul(H, rng):
+                def f(yy, xx, alpha, beta):
+                    strong = beta is False
+                    a = 1 if alpha is True else alpha
+                    b = 0 if strong else (1 if beta is True else beta)
+                    out = interpret_image(H, N, xx.numpy(), yy.numpy(), a, b, strong)
+                    yy[rng[0] - 1:rng[1]] = torch.from_numpy(out[rng[0] - 1:rng[1]])  # the handle's own range
+                    return yy
+                return f
+            sym = kind == "symmetric"
+            for xmode in (("halo", "allgather") if kind != "blocksparse" else ("allgather",)):
+                P = D.RowPartitioned(Ab, own, bt, gather=False, symmetric=sym,
+                                     xneed=(bx if xmode == "halo" else None), interior=Ai)
+                for alpha, beta in ((True, False), (0.5, -2.0)):
+                    for _ in range(2):  # second pass: cached plans and buffers
+                        xd = torch.full_like(x, float("nan"))
+                        if own[1] >= own[0]:
+                            xd[own[0] - 1:own[1]] = x[own[0] - 1:own[1]]
+                        y = torch.from_numpy(y0.copy())
+                        P.mul_overlapped(y, xd, alpha, beta,
+                                         local_mul=image_mul(Ab, bt) if Ab is not None else None,
+                                         interior_mul=image_mul(Ai, own) if Ai is not None else (lambda yy, xx, a, b: P._combine(yy, slice(own[0] - 1, own[1]), 0, b) if own[1] >= own[0] else None))
+                    part = torch.zeros_like(y)
+                    if own[1] >= own[0]:
+                        part[own[0] - 1:own[1]] = y[own[0] - 1:own[1]]
+                    dist.all_reduce(part)
+                    results.append(part.numpy().copy())
+                    combos = combos + (((1, 0) if beta is False else (alpha, beta)),)
         if rank == 0:
             orc = load_oracle()
             errs = []
-            for (alpha, beta), got in zip(((1, 0), (0.5, -2.0)) * 2 + ((0.5, -2.0),), results):
+            for (alpha, beta), got in zip(combos, results):
                 ref = oracle_mul(orc, prob, op, prob["x"], y0, alpha, beta, strong=(beta == 0))
                 errs.append(relerr(got, ref))
             q.put(("ok", errs, own, touched))
