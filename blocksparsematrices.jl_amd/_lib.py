@@ -36,7 +36,8 @@ class BsmPartInfo(C.Structure):
 class BsmStats(C.Structure):
     _fields_ = [("nnz", C.c_int64), ("stored_entries", C.c_int64), ("alg_bytes", C.c_int64),
                 ("device_bytes", C.c_int64), ("npanels", C.c_int64), ("ntasks", C.c_int64),
-                ("nworkgroups", C.c_int64), ("exclusive", C.c_int64), ("reserved", C.c_int64 * 8)]
+                ("nworkgroups", C.c_int64), ("exclusive", C.c_int64), ("win_emissions", C.c_int64),
+                ("win_inside", C.c_int64), ("win_flushed", C.c_int64), ("reserved", C.c_int64 * 5)]
 
 
 class BsmError(RuntimeError):

@@ -29,6 +29,7 @@ Tunables Tunables::from_env() {
     if (const char *f = std::getenv("BSM_FAT_FILL_BELOW")) t.fat_fill_below = std::atof(f);
     t.pack_threads = (int)geti("BSM_PACK_THREADS", t.pack_threads);
     t.wg_order = (int)geti("BSM_ORDER", t.wg_order);
+    t.balance_run = (int)geti("BSM_BALANCE_RUN", t.balance_run);
     t.deep_group_bytes = geti("BSM_DEEP_GROUP_BYTES", t.deep_group_bytes);
     t.deep_total_bytes = geti("BSM_DEEP_TOTAL_BYTES", t.deep_total_bytes);
     t.window_bytes = (size_t)geti("BSM_UPLOAD_WINDOW_BYTES", (int64_t)t.window_bytes);
@@ -320,6 +321,28 @@ uint64_t hash_list(const int64_t *p, int64_t n) {
 
 }  // namespace
 
+// Working state shared by the stages of Analysis::build (each stage below is one step of the host
+// analysis; the CPU image-interpreter tests of tests/test_host_logic.py check their combined result).
+struct Analysis::BuildState {
+    bool sym = false;      // symmetric operator (or the symmetric view of a VBCRS)
+    bool colored = false;  // BSM_ACC_COLORED
+    int64_t nb = 0;
+    int64_t own_lo = 0, own_hi = 0;  // 0-based [lo, hi): rows this handle scales by beta
+    std::vector<Chunk> chunks;
+    std::vector<Group> groups;
+    std::vector<const int64_t *> glist;  // representative index list of indexed groups
+    std::vector<int32_t> colpos;         // merged panel column of every column in chunk order
+    std::vector<uint8_t> ckind;          // kind of every merged panel column (parallel to cols)
+    std::vector<uint8_t> group_perm;     // 1: the group's merged columns were re-ordered (sorted by x index)
+    std::vector<int64_t> layout;         // row groups in the order their panels lie in the value stream
+    uint64_t val_units = 0;              // 16-byte units of the whole value stream
+    std::vector<uint8_t> cover;          // rows some group produces
+    std::vector<int32_t> group_color;
+    int32_t ncolors_fused = 1;
+    std::vector<Item> items;
+    bool use_window = false;
+};
+
 std::string Analysis::build(int mtype_, int dtype_, int64_t nrows_, int64_t ncols_,
                             const std::vector<BlockIn> &blocks, const AnalysisOptions &opt_) {
     mtype = mtype_;
@@ -337,20 +360,63 @@ std::string Analysis::build(int mtype_, int dtype_, int64_t nrows_, int64_t ncol
                      std::chrono::duration<double, std::milli>(now - t_last).count());
         t_last = now;
     };
+    BuildState st;
+    std::string err = stage_validate(blocks, st);
+    if (!err.empty()) return err;
+    lap("validate");
+    // the reference colourings are independent of everything the GPU path needs (they only read the
+    // caller's index lists and fill `colors`): they run on their own thread while the values are packed
+    // and uploaded
+    bool colour_oom = false;
+    if (opt.meta_only) {  // whole-operator bookkeeping of a multi-device handle: no image
+        reference_colourings(blocks, colour_oom);
+        return colour_oom ? "out of host memory (colouring)" : "";
+    }
+    if (!(err = stage_row_groups(blocks, st)).empty()) return err;
+    if (!(err = stage_merge_columns(blocks, st)).empty()) return err;
+    lap("groups + column lists");
+    if (!(err = stage_accumulation(blocks, st)).empty()) return err;
+    lap("exclusivity / fused colours");
+    std::thread colour_thread([&] { reference_colourings(blocks, colour_oom); });
+    struct Joiner {
+        std::thread &t;
+        ~Joiner() {
+            if (t.joinable()) t.join();
+        }
+    } colour_join{colour_thread};  // also on the error returns below
+    stage_work_items(st);
+    stage_place_values(st);
+    lap("work items + value placement");
+    if (!(err = stage_pack_values(blocks, st)).empty()) return err;
+    lap("pack values");
+    stage_waves(st);
+    stage_windows(st);
+    if (!(err = stage_gather_index(st)).empty()) return err;
+    lap("schedule");
+    colour_thread.join();
+    lap("reference colourings (tail not hidden by packing)");
+    if (colour_oom) return "out of host memory (colouring)";
+    return "";
+}
+
+// ---- validation, statistics ----------------------------------------------------------------------
+std::string Analysis::stage_validate(const std::vector<BlockIn> &blocks, BuildState &st) {
     static const int kEs[4] = {4, 8, 8, 16};
     if (dtype < 0 || dtype > 3) return "unknown dtype";
     es = kEs[dtype];
     E = 16 / es;
     if (nrows < 0 || ncols < 0) return "negative matrix size";
     if (nrows > INT32_MAX - 64 || ncols > INT32_MAX - 64) return "matrix dimension exceeds int32 range";
-    const int64_t nb = (int64_t)blocks.size();
+    const int64_t nb = st.nb = (int64_t)blocks.size();
     bool sym = (mtype == MT_SYMMETRIC);
     for (const BlockIn &B : blocks) sym |= (B.kind != KIND_PLAIN);  // symmetric view of a VBCRS
+    st.sym = sym;
+    st.own_lo = (opt.own_lo > 0) ? opt.own_lo - 1 : 0;
+    st.own_hi = (opt.own_hi > 0) ? std::min(opt.own_hi, nrows) : nrows;  // exclusive
     // rows index y for op N and x for op T; for a symmetric matrix every list indexes both
     const int64_t rlim = sym ? std::min(nrows, ncols) : nrows;
     const int64_t clim = sym ? std::min(nrows, ncols) : ncols;
 
-    // ---- validation ------------------------------------------------------------------
     nnz = 0;
     stored_entries = 0;
     int64_t idx_meta = 0;
@@ -388,12 +454,13 @@ std::string Analysis::build(int mtype_, int dtype_, int64_t nrows_, int64_t ncol
         alg_bytes = stored_entries * es + meta + ncols * es + nrows * es;
     }
 
-    lap("validate");
-    // ---- colouring (reference bookkeeping) ---------------------------------------------------
-    // Independent of everything the GPU path needs (it only reads the caller's index lists and
-    // fills `colors`): runs on its own thread while the values are packed and uploaded.
-    bool colour_oom = false;
-    auto reference_colourings = [&]() {
+    return "";
+}
+
+// ---- colouring (reference bookkeeping): `colors` as the reference's constructors compute them ---------
+void Analysis::reference_colourings(const std::vector<BlockIn> &blocks, bool &colour_oom) {
+    const int64_t nb = (int64_t)blocks.size();
+    {
         try {
             for (auto &c : colors) c.clear();
             if (opt.skip_colors) return;
@@ -445,17 +512,18 @@ std::string Analysis::build(int mtype_, int dtype_, int64_t nrows_, int64_t ncol
         } catch (const std::bad_alloc &) {
             colour_oom = true;
         }
-    };
-    if (opt.meta_only) {  // whole-operator bookkeeping of a multi-device handle: no image
-        reference_colourings();
-        return colour_oom ? "out of host memory (colouring)" : "";
     }
-    // ---- chunks (<= 64 rows) and row groups ------------------------------------------
+}
+
+// ---- chunks (<= 64 rows) and row groups ------------------------------------------------------------
+std::string Analysis::stage_row_groups(const std::vector<BlockIn> &blocks, BuildState &st) {
+    const int64_t nb = st.nb;
+    auto &chunks = st.chunks;
+    auto &groups = st.groups;
+    auto &glist = st.glist;
     const int chunk_rows = tun.chunk_rows;
-    std::vector<Chunk> chunks;
-    std::vector<Group> groups;
     std::unordered_map<uint64_t, std::vector<int64_t>> gmap;  // hash -> candidate groups
-    std::vector<const int64_t *> glist;  // representative index list of indexed groups
+
     rows.clear();
     cols.clear();
     for (int64_t b = 0; b < nb; b++) {
@@ -526,8 +594,18 @@ std::string Analysis::build(int mtype_, int dtype_, int64_t nrows_, int64_t ncol
         }
     }
     ngroups = (int64_t)groups.size();
-    // merged column lists + value offsets
+    return "";
+}
+
+// ---- merged column list of every row group -----------------------------------------------------------
+std::string Analysis::stage_merge_columns(const std::vector<BlockIn> &blocks, BuildState &st) {
+    auto &chunks = st.chunks;
+    auto &groups = st.groups;
+    auto &colpos = st.colpos;
+    auto &ckind = st.ckind;
+    auto &group_perm = st.group_perm;
     uint64_t val_units = 0;
+
     {
         int64_t total_cols = 0;
         for (const Group &G : groups) total_cols += G.width + E;
@@ -538,9 +616,7 @@ std::string Analysis::build(int mtype_, int dtype_, int64_t nrows_, int64_t ncol
     // the columns inside a panel is free (a sum), so the merged column list is kept SORTED by x
     // index: neighbouring lanes then gather neighbouring x entries and emit neighbouring y
     // entries, and scattered index lists (BEM near-field panels) collapse into contiguous runs.
-    std::vector<int32_t> colpos;
-    std::vector<uint8_t> ckind;  // kind of every merged panel column (parallel to cols)
-    std::vector<uint8_t> group_perm(groups.size(), 0);
+    group_perm.assign(groups.size(), 0);
     colpos.reserve(cols.capacity());
     ckind.reserve(cols.capacity());
     {
@@ -578,17 +654,24 @@ std::string Analysis::build(int mtype_, int dtype_, int64_t nrows_, int64_t ncol
                 std::copy(sorted.begin(), sorted.end(), gc);
                 std::copy(sortedk.begin(), sortedk.end(), gk);
             }
-            G.val_off = val_units;
             val_units += (uint64_t)G.mc * (uint64_t)G.strips;
             gi++;
         }
     }
+    st.val_units = val_units;
+    value_bytes = (int64_t)val_units * 16;
+    return "";
+}
 
-    lap("groups + column lists");
-    // ---- forward exclusivity + coverage ------------------------------------------------
-    const int64_t own_lo = (opt.own_lo > 0) ? opt.own_lo - 1 : 0;
-    const int64_t own_hi = (opt.own_hi > 0) ? std::min(opt.own_hi, nrows) : nrows;  // exclusive
-    std::vector<uint8_t> cover(nrows, 0);
+// ---- forward exclusivity, coverage, accumulation mode ---------------------------------------------------
+std::string Analysis::stage_accumulation(const std::vector<BlockIn> &blocks, BuildState &st) {
+    auto &groups = st.groups;
+    auto &cover = st.cover;
+    auto &group_color = st.group_color;
+    const bool sym = st.sym;
+    const uint64_t val_units = st.val_units;
+    cover.assign((size_t)nrows, 0);
+
     bool excl = true;
     for (const Group &G : groups) {
         for (int i = 0; i < G.mc; i++) {
@@ -619,10 +702,11 @@ std::string Analysis::build(int mtype_, int dtype_, int64_t nrows_, int64_t ncol
         }
         if ((int64_t)val_units * 16 >= tun.deep_total_bytes && 2 * deep_units > (int64_t)val_units) exclusive_fwd = false;
     }
-    const bool colored = (opt.accumulate == 2);
+    const bool colored = st.colored = (opt.accumulate == 2);
     gather = (opt.accumulate == 3);
-    std::vector<int32_t> group_color(groups.size(), 0);
-    int32_t ncolors_fused = 1;
+    group_color.assign(groups.size(), 0);
+    int32_t &ncolors_fused = st.ncolors_fused;
+    ncolors_fused = 1;
     if (colored) {
         exclusive_fwd = false;
         // fused conflict lists: a row group writes its rows (forward) and its columns (transposed)
@@ -660,17 +744,130 @@ std::string Analysis::build(int mtype_, int dtype_, int64_t nrows_, int64_t ncol
         for (size_t c = 0; c < classes.size(); c++)
             for (int64_t id : classes[c]) group_color[id - 1] = (int32_t)c;
     }
+    return "";
+}
 
-    lap("exclusivity / fused colours");
-    std::thread colour_thread(reference_colourings);
-    struct Joiner {
-        std::thread &t;
-        ~Joiner() {
-            if (t.joinable()) t.join();
+// ---- work items: how many waves stream which strips of which row group, in dispatch order ---------------
+void Analysis::stage_work_items(BuildState &st) {
+    auto &groups = st.groups;
+    auto &group_color = st.group_color;
+    auto &items = st.items;
+    const bool colored = st.colored, sym = st.sym;
+    const uint64_t val_units = st.val_units;
+    items.clear();
+
+    {  // bytes per wave for this operator (bsm_analysis.h: Tunables::wave_bytes)
+        int64_t W = tun.wave_bytes;
+        if (W <= 0) {
+            // lane fill: rows of a group over the lanes its strips occupy (8, 16, 32 or 64 per strip)
+            double rows_b = 0, lanes_b = 0;
+            for (const Group &G : groups) {
+                rows_b += (double)G.mc * (double)G.strips;
+                lanes_b += (double)lanes_per_strip(G.mc) * (double)G.strips;
+            }
+            const bool low_fill = lanes_b > 0 && rows_b < tun.fat_fill_below * lanes_b;
+            W = tun.wave_bytes_min;
+            if (low_fill) {
+                W = std::min(tun.wave_bytes_max, (int64_t)val_units * 16 / tun.target_waves);
+                if (4 * W < 5 * tun.wave_bytes_min) W = tun.wave_bytes_min;  // not long enough to pay
+            }
+            fat_waves = W > tun.wave_bytes_min;
+            if (W > tun.wave_bytes_min) {
+                // fat waves: a row group gets a second wave only from 2 W on and never four -- every
+                // extra wave of a group is another fixed chain plus a workgroup barrier (tiled BEM
+                // fixture: 4.84 TB/s with the W / 3 W rule, 5.0 with this one)
+                if (tun.split2_bytes <= 0) tun.split2_bytes = 2 * W;
+                if (tun.split4_bytes <= 0) tun.split4_bytes = INT64_MAX / 4;
+            }
         }
-    } colour_join{colour_thread};  // also on the error returns below
-    // ---- pack values ---------------------------------------------------------------------
-    value_bytes = (int64_t)val_units * 16;
+        if (tun.split2_bytes <= 0) tun.split2_bytes = W;
+        if (tun.split4_bytes <= 0) tun.split4_bytes = 3 * W;
+        if (tun.wgitem_max_bytes <= 0) tun.wgitem_max_bytes = 4 * W;
+    }
+    for (int64_t g = 0; g < ngroups; g++) {
+        const Group &G = groups[g];
+        const int64_t strip_bytes = (int64_t)G.mc * 16;
+        int64_t per_item = G.strips;
+        if (!exclusive_fwd && !colored) {
+            int64_t maxs = std::max<int64_t>(1, tun.wgitem_max_bytes / strip_bytes);
+            int64_t nitem = (G.strips + maxs - 1) / maxs;
+            per_item = (G.strips + nitem - 1) / nitem;
+        }
+        for (int64_t s = 0; s < G.strips; s += per_item) {
+            Item it;
+            it.group = g;
+            it.s_begin = s;
+            it.s_end = std::min(G.strips, s + per_item);
+            it.bytes = (it.s_end - it.s_begin) * strip_bytes;
+            it.nw = it.bytes >= tun.split4_bytes ? 4 : (it.bytes >= tun.split2_bytes ? 2 : 1);
+            it.color = group_color[g];
+            items.push_back(it);
+        }
+    }
+    // symmetric operators: small items (1 or 2 waves) are ordered by LOCALITY (first row of their
+    // group) so that the waves of one workgroup touch neighbouring y entries and can share an LDS
+    // accumulation window; everything else largest-first
+    const bool use_window = st.use_window = sym && !colored && !gather && !exclusive_fwd && tun.lds_window;
+    auto locality = [&](const Item &it) -> int64_t {
+        const Group &G = groups[it.group];
+        return (G.rbase >= 0) ? G.rbase : rows[G.row_off];
+    };
+    std::stable_sort(items.begin(), items.end(), [&](const Item &a, const Item &b) {
+        if (a.color != b.color) return a.color < b.color;
+        if (a.nw != b.nw) return a.nw > b.nw;
+        if (use_window && a.nw < 4) return locality(a) < locality(b);
+        return a.bytes > b.bytes;
+    });
+    // A workgroup keeps its slot until its SLOWEST wave is done.  Locality order puts waves of very
+    // different sizes side by side (BEM leaves: 3-28 rows, 10-140 columns); inside every run of
+    // `balance_run` neighbouring one-wave items the items are therefore re-ordered by size, so that the
+    // four waves of a workgroup are neighbours AND of similar length.
+    if (use_window && tun.balance_run > 1) {
+        size_t a = 0;
+        while (a < items.size()) {
+            if (items[a].nw != 1) {
+                a++;
+                continue;
+            }
+            size_t b = a;
+            while (b < items.size() && items[b].nw == 1 && items[b].color == items[a].color && b - a < (size_t)tun.balance_run) b++;
+            std::stable_sort(items.begin() + a, items.begin() + b, [](const Item &x, const Item &y) { return x.bytes > y.bytes; });
+            a = b;
+        }
+    }
+}
+
+// ---- value stream layout: the panels lie in the order in which the launch reaches them --------------------
+// Workgroups are dispatched in index order, so the waves in flight at any moment stream NEIGHBOURING
+// addresses when the value stream follows the dispatch order (a stream laid out in creation order and
+// walked in locality or size order lost a third of its rate on the tiled BEM fixture).
+void Analysis::stage_place_values(BuildState &st) {
+    auto &groups = st.groups;
+    std::vector<uint8_t> placed(groups.size(), 0);
+    st.layout.clear();
+    st.layout.reserve(groups.size());
+    for (const Item &it : st.items)
+        if (!placed[it.group]) {
+            placed[it.group] = 1;
+            st.layout.push_back(it.group);
+        }
+    for (size_t g = 0; g < groups.size(); g++)
+        if (!placed[g]) st.layout.push_back((int64_t)g);
+    uint64_t off = 0;
+    for (int64_t g : st.layout) {
+        groups[g].val_off = off;
+        off += (uint64_t)groups[g].mc * (uint64_t)groups[g].strips;
+    }
+}
+
+// ---- pack values: every stored entry once, strip order (bsm_layout.h) ---------------------------------------
+std::string Analysis::stage_pack_values(const std::vector<BlockIn> &blocks, BuildState &st) {
+    auto &chunks = st.chunks;
+    auto &groups = st.groups;
+    auto &colpos = st.colpos;
+    auto &group_perm = st.group_perm;
+    const uint64_t val_units = st.val_units;
+
     auto pack_one = [&](const Chunk &c, char *dst) {  // dst: first byte of the chunk's row group panel
         const BlockIn &B = blocks[c.blk];
         if (group_perm[c.group]) {
@@ -738,23 +935,24 @@ std::string Analysis::build(int mtype_, int dtype_, int64_t nrows_, int64_t ncol
     if (opt.blocks_on_device) {
         // nothing to pack here
     } else if (streamed) {
-        // row groups are laid out in index order: windows of consecutive groups, packed into the
-        // sink's staging buffer by all threads, shipped while the next window is being packed
+        // windows of consecutive row groups of the stream (layout order), packed into the sink's staging
+        // buffer by all threads, shipped while the next window is being packed
+        const std::vector<int64_t> &lay = st.layout;
         std::vector<int32_t> ids;
         size_t g0 = 0;
-        while (g0 < groups.size()) {
-            const size_t wbase = (size_t)groups[g0].val_off * 16;
+        while (g0 < lay.size()) {
+            const size_t wbase = (size_t)groups[lay[g0]].val_off * 16;
             size_t g1 = g0, wbytes = 0;
-            while (g1 < groups.size() && (g1 == g0 || wbytes + (size_t)groups[g1].mc * groups[g1].strips * 16 <= tun.window_bytes)) {
-                wbytes += (size_t)groups[g1].mc * (size_t)groups[g1].strips * 16;
+            while (g1 < lay.size() && (g1 == g0 || wbytes + (size_t)groups[lay[g1]].mc * groups[lay[g1]].strips * 16 <= tun.window_bytes)) {
+                wbytes += (size_t)groups[lay[g1]].mc * (size_t)groups[lay[g1]].strips * 16;
                 g1++;
             }
             char *buf = opt.sink->window(wbytes);
             if (!buf) return "value sink: no staging buffer";
             ids.clear();
             for (size_t g = g0; g < g1; g++) {
-                zero_tail(groups[g], buf, wbase);
-                ids.insert(ids.end(), groups[g].chunks.begin(), groups[g].chunks.end());
+                zero_tail(groups[lay[g]], buf, wbase);
+                ids.insert(ids.end(), groups[lay[g]].chunks.begin(), groups[lay[g]].chunks.end());
             }
             pack_many(&ids, ids.size(), buf, wbase);
             std::string err = opt.sink->commit(wbase, wbytes);
@@ -768,73 +966,19 @@ std::string Analysis::build(int mtype_, int dtype_, int64_t nrows_, int64_t ncol
         for (const Group &G : groups) zero_tail(G, values.data(), 0);
         pack_many(nullptr, chunks.size(), values.data(), 0);
     }
+    return "";
+}
 
-    lap("pack values");
-    // ---- work items ----------------------------------------------------------------------
-    std::vector<Item> items;
-    {  // bytes per wave for this operator (bsm_analysis.h: Tunables::wave_bytes)
-        int64_t W = tun.wave_bytes;
-        if (W <= 0) {
-            // lane fill: rows of a group over the lanes its strips occupy (8, 16, 32 or 64 per strip)
-            double rows_b = 0, lanes_b = 0;
-            for (const Group &G : groups) {
-                rows_b += (double)G.mc * (double)G.strips;
-                lanes_b += (double)lanes_per_strip(G.mc) * (double)G.strips;
-            }
-            const bool low_fill = lanes_b > 0 && rows_b < tun.fat_fill_below * lanes_b;
-            W = tun.wave_bytes_min;
-            if (low_fill) {
-                W = std::min(tun.wave_bytes_max, (int64_t)val_units * 16 / tun.target_waves);
-                if (4 * W < 5 * tun.wave_bytes_min) W = tun.wave_bytes_min;  // not long enough to pay
-            }
-            if (W > tun.wave_bytes_min) {
-                // fat waves: a row group gets a second wave only from 2 W on and never four -- every
-                // extra wave of a group is another fixed chain plus a workgroup barrier (tiled BEM
-                // fixture: 4.84 TB/s with the W / 3 W rule, 5.0 with this one)
-                if (tun.split2_bytes <= 0) tun.split2_bytes = 2 * W;
-                if (tun.split4_bytes <= 0) tun.split4_bytes = INT64_MAX / 4;
-            }
-        }
-        if (tun.split2_bytes <= 0) tun.split2_bytes = W;
-        if (tun.split4_bytes <= 0) tun.split4_bytes = 3 * W;
-        if (tun.wgitem_max_bytes <= 0) tun.wgitem_max_bytes = 4 * W;
-    }
-    for (int64_t g = 0; g < ngroups; g++) {
-        const Group &G = groups[g];
-        const int64_t strip_bytes = (int64_t)G.mc * 16;
-        int64_t per_item = G.strips;
-        if (!exclusive_fwd && !colored) {
-            int64_t maxs = std::max<int64_t>(1, tun.wgitem_max_bytes / strip_bytes);
-            int64_t nitem = (G.strips + maxs - 1) / maxs;
-            per_item = (G.strips + nitem - 1) / nitem;
-        }
-        for (int64_t s = 0; s < G.strips; s += per_item) {
-            Item it;
-            it.group = g;
-            it.s_begin = s;
-            it.s_end = std::min(G.strips, s + per_item);
-            it.bytes = (it.s_end - it.s_begin) * strip_bytes;
-            it.nw = it.bytes >= tun.split4_bytes ? 4 : (it.bytes >= tun.split2_bytes ? 2 : 1);
-            it.color = group_color[g];
-            items.push_back(it);
-        }
-    }
-    // symmetric operators: small items (1 or 2 waves) are ordered by LOCALITY (first row of their
-    // group) so that the waves of one workgroup touch neighbouring y entries and can share an LDS
-    // accumulation window; everything else largest-first
-    const bool use_window = sym && !colored && !gather && !exclusive_fwd && tun.lds_window;
-    auto locality = [&](const Item &it) -> int64_t {
-        const Group &G = groups[it.group];
-        return (G.rbase >= 0) ? G.rbase : rows[G.row_off];
-    };
-    std::stable_sort(items.begin(), items.end(), [&](const Item &a, const Item &b) {
-        if (a.color != b.color) return a.color < b.color;
-        if (a.nw != b.nw) return a.nw > b.nw;
-        if (use_window && a.nw < 4) return locality(a) < locality(b);
-        return a.bytes > b.bytes;
-    });
+// ---- waves: every wave streams ONE piece (a strip range of a merged panel) --------------------------------
+void Analysis::stage_waves(BuildState &st) {
+    auto &groups = st.groups;
+    auto &ckind = st.ckind;
+    auto &cover = st.cover;
+    auto &items = st.items;
+    const bool colored = st.colored;
+    const int32_t ncolors_fused = st.ncolors_fused;
+    const int64_t own_lo = st.own_lo, own_hi = st.own_hi;
 
-    // ---- waves: every wave streams ONE piece (a strip range of a merged panel) -----------
     waves.clear();
     auto emit_nop = [&]() {
         WaveWork w;
@@ -967,12 +1111,36 @@ std::string Analysis::build(int mtype_, int dtype_, int64_t nrows_, int64_t ncol
         for (int w = 0; w < kWavesPerWg; w++) sync |= (waves[wg + w].work == WORK_PANEL && waves[wg + w].grp > 1);
         for (int w = 0; w < kWavesPerWg; w++) waves[wg + w].wg_sync = sync;
     }
+    if (rows.empty()) rows.push_back(0);
+    if (cols.empty()) cols.push_back(0);
+    if (values.empty()) {
+        values.allocate(16);
+        std::memset(values.data(), 0, 16);
+    }
+}
+
+// ---- LDS y windows of workgroups that pack neighbouring small row groups of a symmetric operator ------------
+void Analysis::stage_windows(BuildState &st) {
+    auto &ckind = st.ckind;
+    const bool use_window = st.use_window;
+    win_emissions = win_inside = win_flushed = 0;
+
     if (use_window) {
+        // The waves of such a workgroup stream NEIGHBOURING row groups: their forward rows and their
+        // transposed (KIND_OFF) columns largely coincide (BEM near-field panels: 4 neighbouring leaves
+        // name every y entry twice on average), so sums that fall into one dense index range are added
+        // up in LDS and leave the CU once, as contiguous atomics.  The range need not hold EVERYTHING
+        // the workgroup emits -- a panel usually has a few far columns -- it is the best-filled range
+        // of at most window_entries(es) indices (sliding window over the sorted emissions); what falls
+        // outside goes to y directly.
+        const int64_t cap = window_entries(es);
+        std::vector<int64_t> em;
+        win_emissions = win_inside = win_flushed = 0;
         for (size_t wg = 0; wg + kWavesPerWg <= (size_t)nwg_main * kWavesPerWg; wg += kWavesPerWg) {
-            int64_t lo = INT64_MAX, hi = -1, touched = 0;
             int npanel = 0;
             int32_t first_rbase = INT32_MIN, first_rowoff = INT32_MIN;
             bool distinct = false;
+            em.clear();
             for (int w = 0; w < kWavesPerWg; w++) {
                 const WaveWork &W = waves[wg + w];
                 if (W.work != WORK_PANEL || W.npieces == 0) continue;
@@ -983,36 +1151,42 @@ std::string Analysis::build(int mtype_, int dtype_, int64_t nrows_, int64_t ncol
                     distinct = true;
                 }
                 npanel++;
-                for (int i = 0; i < W.m; i++) {
-                    const int64_t r = (W.rbase >= 0) ? (int64_t)W.rbase + i : rows[W.row_off + i];
-                    lo = std::min(lo, r);
-                    hi = std::max(hi, r);
-                }
-                touched += W.m + W.first.ncols;
-                for (int32_t k = 0; k < W.first.ncols; k++) {
-                    const int64_t c = cols[W.first.col_off + k];
-                    lo = std::min(lo, c);
-                    hi = std::max(hi, c);
-                }
+                if (W.lead)
+                    for (int i = 0; i < W.m; i++) em.push_back((W.rbase >= 0) ? (int64_t)W.rbase + i : rows[W.row_off + i]);
+                for (int32_t k = 0; k < W.first.ncols; k++)
+                    if (ckind[(size_t)W.first.col_off + k] == KIND_OFF) em.push_back(cols[W.first.col_off + k]);
             }
-            // worth it only when different groups meet and the window is reasonably dense
-            if (!distinct || hi < lo) continue;
-            const int64_t span = hi - lo + 1;
-            if (span > window_entries(es) || touched < span) continue;
+            win_emissions += (int64_t)em.size();
+            // worth it only when different groups meet
+            if (!distinct || em.empty()) continue;
+            std::sort(em.begin(), em.end());
+            size_t best_j = 0, best_k = 0, j = 0;
+            for (size_t k = 0; k < em.size(); k++) {
+                while (em[k] - em[j] >= cap) j++;
+                if (k - j > best_k - best_j || k == 0) best_j = j, best_k = k;
+            }
+            const int64_t inside = (int64_t)(best_k - best_j + 1);
+            int64_t uniq = 1;
+            for (size_t k = best_j + 1; k <= best_k; k++) uniq += em[k] != em[k - 1];
+            // the flush costs a barrier and ceil(span / 64) atomic wave-instructions: take the window
+            // when it merges at least a fifth of what passes through it
+            if (inside < 32 || 5 * uniq > 4 * inside) continue;
+            const int64_t lo = em[best_j], span = em[best_k] - lo + 1;
             for (int w = 0; w < kWavesPerWg; w++) {
                 waves[wg + w].win_base = (int32_t)lo;
                 waves[wg + w].win_span8 = (uint8_t)((span + 7) / 8);
             }
+            win_inside += inside;
+            win_flushed += uniq;
         }
     }
-    if (rows.empty()) rows.push_back(0);
-    if (cols.empty()) cols.push_back(0);
-    if (values.empty()) {
-        values.allocate(16);
-        std::memset(values.data(), 0, 16);
-    }
+}
 
-    // ---- gather mode: workspace slots + inverted indices ------------------------------------------
+// ---- gather mode: workspace slots + inverted indices; kind flags of the cols pool ---------------------------
+std::string Analysis::stage_gather_index(BuildState &st) {
+    auto &groups = st.groups;
+    auto &ckind = st.ckind;
+
     inv_ptr[0].clear();
     inv_ptr[1].clear();
     inv_idx[0].clear();
@@ -1084,10 +1258,6 @@ std::string Analysis::build(int mtype_, int dtype_, int64_t nrows_, int64_t ncol
         if (G.has_off && G.has_diag)
             for (int64_t q = 0; q < G.width; q++)
                 if (ckind[G.col_off + q] == KIND_DIAG) cols[G.col_off + q] = (int32_t)((uint32_t)cols[G.col_off + q] | kColDiagBit);
-    lap("schedule");
-    colour_thread.join();
-    lap("reference colourings (tail not hidden by packing)");
-    if (colour_oom) return "out of host memory (colouring)";
     return "";
 }
 

@@ -81,6 +81,7 @@ struct Tunables {
     int pack_threads = 8;
     size_t window_bytes = 64u << 20;  // staging window of a streamed upload (BSM_UPLOAD_WINDOW_BYTES)
     int lds_window = 1;  // LDS y window for locality-packed small symmetric row groups
+    int balance_run = 0;  // locality-ordered one-wave items: re-order runs of this many by size (BSM_BALANCE_RUN; 0: off)
     int wg_order = -1;  // workgroup dispatch order (BSM_ORDER): -1 auto (snake for exclusive images), 0 plain largest first
     static Tunables from_env();
 };
@@ -162,6 +163,7 @@ class Analysis {
     int64_t nwg_total = 0;  // + workgroups of scale work (exclusive forward launch only)
     int64_t ngroups = 0;
     bool exclusive_fwd = false;  // every y row is produced by at most one row group
+    bool fat_waves = false;      // the operator got more than wave_bytes_min per wave (see Tunables::wave_bytes)
     // coloured mode: workgroups [color_wg_ptr[c], color_wg_ptr[c+1]) form launch c; the row groups
     // of one launch touch pairwise disjoint y entries (rows and columns), for every op
     std::vector<int64_t> color_wg_ptr;
@@ -169,6 +171,9 @@ class Analysis {
     // slot col_off + q (its position in the cols pool); forward partial sums of a workgroup item:
     // slots ws_fbase + WaveWork::win_base + row.  inv_ptr/inv_idx[k]: CSR over the y entries of
     // op N (k = 0) and op T / C (k = 1) listing the slots that contribute, in ascending order.
+    // LDS y window (symmetric operators): y contributions of op N in all (forward rows + transposed
+    // columns), those that pass through a workgroup's window, and what the windows flush to y
+    int64_t win_emissions = 0, win_inside = 0, win_flushed = 0;
     bool gather = false;
     int64_t ws_fbase = 0, ws_slots = 0;
     std::vector<int64_t> inv_ptr[2];
@@ -181,6 +186,21 @@ class Analysis {
     // Fills perm / rowptr / colindices / rowindices exactly as src/vbcrs.jl:84-117 and returns the
     // sorted order (0-based input positions).
     std::vector<int64_t> vbcrs_bookkeeping(int64_t nblocks, const int64_t *rowstart, const int64_t *colstart);
+
+  private:
+    // the stages of build(), in the order they run (bsm_analysis.cpp)
+    struct BuildState;
+    std::string stage_validate(const std::vector<BlockIn> &blocks, BuildState &st);
+    void reference_colourings(const std::vector<BlockIn> &blocks, bool &colour_oom);
+    std::string stage_row_groups(const std::vector<BlockIn> &blocks, BuildState &st);
+    std::string stage_merge_columns(const std::vector<BlockIn> &blocks, BuildState &st);
+    std::string stage_accumulation(const std::vector<BlockIn> &blocks, BuildState &st);
+    void stage_work_items(BuildState &st);
+    void stage_place_values(BuildState &st);
+    std::string stage_pack_values(const std::vector<BlockIn> &blocks, BuildState &st);
+    void stage_waves(BuildState &st);
+    void stage_windows(BuildState &st);
+    std::string stage_gather_index(BuildState &st);
 };
 
 }  // namespace bsm

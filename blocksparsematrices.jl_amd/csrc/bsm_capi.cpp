@@ -231,6 +231,7 @@ void fill_image(const Analysis &an, const bsm_options &o, bool use_own, DeviceIm
     img.nwg_total = an.nwg_total;
     img.exclusive_fwd = an.exclusive_fwd && (o.accumulate == BSM_ACC_AUTO || o.accumulate == BSM_ACC_DIRECT);
     img.has_off = false;
+    img.fat_waves = an.fat_waves;
     for (const WaveWork &w : an.waves)
         if (w.work == WORK_PANEL && w.npieces > 0 && (w.first.kind & kKindHasOff)) img.has_off = true;
     if (!img.exclusive_fwd) img.nwg_total = img.nwg_main;
@@ -1081,6 +1082,9 @@ extern "C" int bsm_stats(bsm_matrix_t A, bsm_stats_t *out) {
     out->ntasks = (int64_t)A->an.waves.size();
     out->nworkgroups = A->img.nwg_total ? A->img.nwg_total : A->an.nwg_total;
     out->exclusive = A->img.exclusive_fwd ? 1 : 0;
+    out->win_emissions = A->an.win_emissions;
+    out->win_inside = A->an.win_inside;
+    out->win_flushed = A->an.win_flushed;
     return BSM_OK;
 }
 

@@ -228,6 +228,19 @@ constexpr int FLAG_CONJ = 4;
 constexpr int FLAG_OPT = 8;
 constexpr int FLAG_RMW = 16;     // coloured launch: conflict-free by construction, plain read-modify-write
 constexpr int FLAG_GATHER = 32;  // contributions are stored in the workspace, gather_kernel sums them
+#ifdef BSM_EXPERIMENT
+// developer build (make exp): timing-only ablations of the fused kernel, selected by BSM_DEBUG_FLAGS
+// (results are WRONG with any bit set; tools/ablate.py)
+constexpr int DBG_NO_GLOBAL_ATOMICS = 1 << 16;  // transposed emission: sums outside the window are dropped
+constexpr int DBG_NO_WINDOW_ADD = 1 << 17;      // ... sums inside the window are dropped
+constexpr int DBG_NO_BUTTERFLY = 1 << 18;       // lane-local values are parked instead of the group sums
+constexpr int DBG_NO_EMISSION = 1 << 19;        // the emission loop is skipped altogether
+constexpr int DBG_NO_XGATHER = 1 << 20;         // the x slice is a constant (no column-list / x loads)
+constexpr int DBG_NO_FWD_OUT = 1 << 21;         // forward sums are not written
+#define BSM_DBG(bit) ((flags & (bit)) != 0)
+#else
+#define BSM_DBG(bit) false
+#endif
 
 // ----------------------------------------------------------------------------------------
 // descriptors: fetched as whole 16-byte words through a wave-uniform address (scalar loads),
@@ -317,6 +330,9 @@ __device__ __forceinline__ T run_panel(const WaveD &wd, const uint4 *__restrict_
     for (int e = 0; e < E; ++e) acc[e] = zero_of(T{});
     T xr = zero_of(T{});
     if (TRN && row_ok) {
+        // (issuing this second round trip together with the x gather of the first chunk's columns, so that
+        // the rows -> x and columns -> x chains overlap, changed nothing on the tiled BEM fixture and costs
+        // the fp64 / fp32 fused instances a register they do not have)
         const int ri = (wd.rbase >= 0) ? wd.rbase + i : rows[wd.row_off + i];
         xr = x[ri];
     }
@@ -401,90 +417,108 @@ __device__ __forceinline__ T run_panel(const WaveD &wd, const uint4 *__restrict_
             }
         };
 
-        for (int c0 = 0; c0 < ncols; c0 += XCH) {
-            if (fwd_en) {
-                constexpr int KXM = XCH / 64;
-                const int need = min(ncols - c0, XCH) + NC;  // columns the chunk's iterations read
-                if (KXM >= 4 && need <= (KXM / 4) * 64)
-                    stage_x(c0, std::integral_constant<int, (KXM >= 4 ? KXM / 4 : 1)>{});
-                else if (KXM >= 2 && need <= (KXM / 2) * 64)
-                    stage_x(c0, std::integral_constant<int, (KXM >= 2 ? KXM / 2 : 1)>{});
-                else
-                    stage_x(c0, std::integral_constant<int, KXM>{});
+        // the x slice of the chunk that starts at column c0
+        auto stage_chunk = [&](int c0) {
+            if (!fwd_en) return;
+            if (BSM_DBG(DBG_NO_XGATHER)) {
+#pragma unroll
+                for (int k = 0; k < XCH / 64; ++k) xs[k * 64 + lane] = alpha;
+                return;
             }
+            constexpr int KXM = XCH / 64;
+            const int need = min(ncols - c0, XCH) + NC;  // columns the chunk's iterations read
+            if (KXM >= 4 && need <= (KXM / 4) * 64)
+                stage_x(c0, std::integral_constant<int, (KXM >= 4 ? KXM / 4 : 1)>{});
+            else if (KXM >= 2 && need <= (KXM / 2) * 64)
+                stage_x(c0, std::integral_constant<int, (KXM >= 2 ? KXM / 2 : 1)>{});
+            else
+                stage_x(c0, std::integral_constant<int, KXM>{});
+        };
+        // one iteration on the L loaded strips-per-group starting at strip s0 of the chunk [c0, c0 + XCH)
+        auto iteration = [&](Vec16<T>(&b)[L], int s0, int c0, int s_end) {
+            if (fwd_en) {
+                const int cb = (s0 - c0 / E) * E;  // first column of this iteration inside the chunk
+#pragma unroll
+                for (int l = 0; l < L; ++l) {
+                    const Vec16<T> xv = *reinterpret_cast<const Vec16<T> *>(&xs[cb + (l * G + g) * E]);
+#pragma unroll
+                    for (int e = 0; e < E; ++e) acc[e] = madd(acc[e], cj(b[l].v[e], cjf), xv.v[e]);
+                }
+            }
+#ifdef BSM_TRACE
+            if (s0 == 0) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                BSM_TSTAMP(3);  // first iteration's matrix bytes have arrived
+            }
+#endif
+            if (trn_en) {
+                T vals[V];
+#pragma unroll
+                for (int l = 0; l < L; ++l)
+#pragma unroll
+                    for (int e = 0; e < E; ++e) vals[l * E + e] = mul(cj(b[l].v[e], cjf), xr);
+                int pos = 0, dup = 0;
+                if (!BSM_DBG(DBG_NO_BUTTERFLY)) Butterfly<T, V, P>::run(vals, i, pos, dup);
+                constexpr int CF = (V / P) > 1 ? (V / P) : 1;
+                // the column sums of the chunk's iterations are parked in LDS and leave the wave
+                // together (64 busy lanes per atomic wave-instruction instead of NC)
+                const int slot = (s0 - c0 / E) / (G * L);
+                if ((i & dup) == 0) {
+#pragma unroll
+                    for (int j = 0; j < CF; ++j) {
+                        const int q = pos + j;  // original value index l*E + e
+                        const int l = q / E, e = q % E;
+                        vs[slot * NC + (l * G + g) * E + e] = vals[j];
+                    }
+                }
+                const bool last_it = (s0 + G * L >= s_end);
+                if ((slot == BF - 1 || last_it) && !BSM_DBG(DBG_NO_EMISSION)) {
+                    const int sb = s0 - slot * (G * L);  // first strip of the batch
+#pragma unroll 1
+                    for (int k = 0; k < (BF * NC + 63) / 64; ++k) {
+                        const int c = k * 64 + lane;
+                        const int w = sb * E + c;
+                        if (c < (slot + 1) * NC && w < ncols) {
+                            bool off;
+                            const int yi = col_lookup(w, off);
+                            if (!(opT || off)) continue;  // a diagonal column in op N: forward only
+                            if (flags & FLAG_GATHER) {  // one plain, coalesced store per column sum
+                                ws[col_off + w] = vs[c];
+                                continue;
+                            }
+                            const T val = mul(alpha, vs[c]);
+                            const unsigned wi = (unsigned)(yi - wd.win_base);
+                            if (wi < (unsigned)win_n) {
+                                if (!BSM_DBG(DBG_NO_WINDOW_ADD)) lds_acc(&win[wi], val);  // leaves the CU once, with the window
+                            } else if (flags & FLAG_RMW) {
+                                y[yi] = add(y[yi], val);
+                            } else if (!BSM_DBG(DBG_NO_GLOBAL_ATOMICS)) {
+                                atomic_acc(&y[yi], val);
+                            }
+                        }
+                    }
+                }
+            }
+        };
+
+        for (int c0 = 0; c0 < ncols; c0 += XCH) {
+            stage_chunk(c0);
 #ifdef BSM_TRACE
             if (c0 == 0) BSM_TSTAMP(2);  // x slice staged (loads issued and stored to LDS)
 #endif
             const int s_end = min(nstrips, (c0 + XCH) / E);
             for (int s0 = c0 / E; s0 < s_end; s0 += G * L) {
-                // (Software-pipelined variants -- every next iteration's loads already in flight, or
-                // only a chunk's first loads issued inside the x gather -- were measured and did not
-                // help: the memory system serves a short launch's requests first come, first served,
-                // and occupancy provides the parallelism of a long one.)
+                // (Software-pipelined variants -- two register buffers of L / 2 loads with the next
+                // iteration's loads issued before the butterfly / emission of the current one and the
+                // first ones before the x gather; every next iteration's loads already in flight; only a
+                // chunk's first loads issued inside the x gather -- were measured on forward AND fused
+                // kernels and lost every time (tiled BEM fixture, fused: ComplexF64 153 -> 160 us, fp64
+                // 82 -> 117 us with 36 B of scratch): the memory system serves requests first come, first
+                // served, occupancy provides the parallelism of a long launch, and the extra iterations
+                // cost issue slots.)
                 Vec16<T> b[L];
                 load_b(b, s0);
-                if (fwd_en) {
-                    const int cb = (s0 - c0 / E) * E;  // first column of this iteration inside the chunk
-#pragma unroll
-                    for (int l = 0; l < L; ++l) {
-                        const Vec16<T> xv = *reinterpret_cast<const Vec16<T> *>(&xs[cb + (l * G + g) * E]);
-#pragma unroll
-                        for (int e = 0; e < E; ++e) acc[e] = madd(acc[e], cj(b[l].v[e], cjf), xv.v[e]);
-                    }
-                }
-#ifdef BSM_TRACE
-                if (s0 == c0 / E && c0 == 0) {
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    BSM_TSTAMP(3);  // first iteration's matrix bytes have arrived
-                }
-#endif
-                if (trn_en) {
-                    T vals[V];
-#pragma unroll
-                    for (int l = 0; l < L; ++l)
-#pragma unroll
-                        for (int e = 0; e < E; ++e) vals[l * E + e] = mul(cj(b[l].v[e], cjf), xr);
-                    int pos = 0, dup = 0;
-                    Butterfly<T, V, P>::run(vals, i, pos, dup);
-                    constexpr int CF = (V / P) > 1 ? (V / P) : 1;
-                    // the column sums of the chunk's iterations are parked in LDS and leave the wave
-                    // together (64 busy lanes per atomic wave-instruction instead of NC)
-                    const int slot = (s0 - c0 / E) / (G * L);
-                    if ((i & dup) == 0) {
-#pragma unroll
-                        for (int j = 0; j < CF; ++j) {
-                            const int q = pos + j;  // original value index l*E + e
-                            const int l = q / E, e = q % E;
-                            vs[slot * NC + (l * G + g) * E + e] = vals[j];
-                        }
-                    }
-                    const bool last_it = (s0 + G * L >= s_end);
-                    if (slot == BF - 1 || last_it) {
-                        const int sb = s0 - slot * (G * L);  // first strip of the batch
-#pragma unroll 1
-                        for (int k = 0; k < (BF * NC + 63) / 64; ++k) {
-                            const int c = k * 64 + lane;
-                            const int w = sb * E + c;
-                            if (c < (slot + 1) * NC && w < ncols) {
-                                bool off;
-                                const int yi = col_lookup(w, off);
-                                if (!(opT || off)) continue;  // a diagonal column in op N: forward only
-                                if (flags & FLAG_GATHER) {  // one plain, coalesced store per column sum
-                                    ws[col_off + w] = vs[c];
-                                    continue;
-                                }
-                                const T val = mul(alpha, vs[c]);
-                                const unsigned wi = (unsigned)(yi - wd.win_base);
-                                if (wi < (unsigned)win_n)
-                                    lds_acc(&win[wi], val);  // leaves the CU once, with the window
-                                else if (flags & FLAG_RMW)
-                                    y[yi] = add(y[yi], val);
-                                else
-                                    atomic_acc(&y[yi], val);
-                            }
-                        }
-                    }
-                }
+                iteration(b, s0, c0, s_end);
             }
         }
     }
@@ -511,6 +545,9 @@ template <typename T, int L, bool FWD, bool TRN, bool NT>
 __global__ void __launch_bounds__(64 * kWavesPerWg) __attribute__((amdgpu_waves_per_eu(
     (FWD && TRN && std::is_same<T, double>::value) ? 8 :
     (((!TRN && std::is_same<T, double>::value) || std::is_same<T, c128>::value) ? 6 : 5))))
+    // <= 96 SGPRs: a CU admits 7 workgroups of 256 threads (the ComplexF64 fused instance compiled to 106 =
+    // 6 workgroups; tiled BEM fixture 147.7 -> 143.9 us with the cap, nothing else changes)
+    __attribute__((amdgpu_num_sgpr(96)))
     panel_kernel(const WaveWork *__restrict__ waves, const uint4 *__restrict__ values, const int *__restrict__ rows,
                  const int *__restrict__ cols, const T *__restrict__ x, T *__restrict__ y, T alpha,
                  T beta, int flags, unsigned wg_base, T *__restrict__ ws, long long ws_fbase) {
@@ -564,7 +601,7 @@ __global__ void __launch_bounds__(64 * kWavesPerWg) __attribute__((amdgpu_waves_
             xs[wave][lane] = u;
             __syncthreads();
         }
-        if (work == WORK_PANEL && wd.lead) {
+        if (work == WORK_PANEL && wd.lead && !BSM_DBG(DBG_NO_FWD_OUT)) {
             for (int k = 1; k < wd.grp; ++k) u = add(u, xs[wave + k][lane]);
             if (flags & FLAG_GATHER) {
                 // forward partial sums of this workgroup item: slots ws_fbase + win_base + row
@@ -951,6 +988,9 @@ static hipError_t launch_typed(const DeviceImage &img, bool opT, bool conj, cons
     if (strong_zero) flags |= FLAG_STRONG_ZERO;
     if (conj) flags |= FLAG_CONJ;
     if (opT) flags |= FLAG_OPT;
+#ifdef BSM_EXPERIMENT
+    if (const char *v = std::getenv("BSM_DEBUG_FLAGS")) flags |= std::atoi(v) << 16;
+#endif
     const WaveWork *waves = (const WaveWork *)img.d_waves;
     const uint4 *values = (const uint4 *)img.d_values;
     const int *rows = (const int *)img.d_rows;

@@ -284,7 +284,12 @@ typedef struct {
     int64_t device_bytes;   /* bytes of the packed device image (values + metadata) */
     int64_t npanels, ntasks, nworkgroups;
     int64_t exclusive;      /* 1: forward product needs no atomics and no pre-scale pass */
-    int64_t reserved[8];
+    /* SymmetricBlockMatrix, op N: y contributions the fused launch produces (forward rows + transposed
+     * columns of every wave), how many of them are added up in a workgroup's LDS window first, and how
+     * many entries those windows then add to y -- global atomics per product =
+     * win_emissions - win_inside + win_flushed */
+    int64_t win_emissions, win_inside, win_flushed;
+    int64_t reserved[5];
 } bsm_stats_t;
 int bsm_stats(bsm_matrix_t A, bsm_stats_t *out);
 

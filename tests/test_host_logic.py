@@ -392,34 +392,66 @@ def test_second_ordering_transposed_image(bsm, oracle):
 
 def test_lds_window_descriptors_cover_their_workgroup(bsm):
     # workgroups of a symmetric operator that pack neighbouring small row groups carry an LDS
-    # accumulation window: it must be workgroup-uniform and hold at most window_entries(8) = 512 entries
-    from _common import WORK_PANEL, get_image
+    # accumulation window: workgroup-uniform, at most window_entries(8) = 512 entries, placed on the
+    # best-filled index range of what the workgroup emits in op N (forward rows of its leading waves +
+    # KIND_OFF columns); it need not hold everything, but must merge at least a fifth of what it holds
+    from _common import KIND_OFF, WORK_PANEL, get_image
+
+    def check(p, cap, dt=np.float64):
+        A = bsm.synthetic.build(p, device=NODEV)
+        values, rows, cols, waves = get_image(A)
+        st = A.stats()
+        wg = waves.reshape(-1, st["ntasks"] // st["nworkgroups"])  # waves per workgroup
+        nwin = tot = inside = flushed = 0
+        for quad in wg:
+            assert len(set(quad["win_span8"])) == 1 and len(set(quad["win_base"])) == 1
+            span = int(quad["win_span8"][0]) * 8
+            assert span <= cap
+            base = int(quad["win_base"][0])
+            groups, em = set(), []
+            for W in quad[(quad["work"] == WORK_PANEL) & (quad["npieces"] > 0)]:
+                m = int(W["m"])
+                r = np.arange(W["rbase"], W["rbase"] + m) if W["rbase"] >= 0 else rows[W["row_off"]:W["row_off"] + m]
+                pool = cols[W["first"]["col_off"]:W["first"]["col_off"] + W["first"]["ncols"]]
+                kinds = int(W["first"]["kind"])
+                nc = len(pool)
+                if W["first"]["xbase"] >= 0:
+                    wv = np.arange(nc)
+                    ck = np.where(wv < W["seg1_w"], kinds & 3, np.where(wv < W["seg2_w"], (kinds >> 2) & 3, (kinds >> 4) & 3))
+                else:
+                    ck = np.where(pool < 0, 1, kinds & 3)
+                if W["lead"]:
+                    em += list(r)
+                em += list((pool & 0x7fffffff)[ck == KIND_OFF])
+                groups.add((int(W["rbase"]), int(W["row_off"])))
+            tot += len(em)
+            if span == 0:
+                continue
+            nwin += 1
+            em = np.array(em)
+            inw = em[(em >= base) & (em < base + span)]
+            assert len(groups) >= 2 and len(inw) >= 32 and 5 * len(np.unique(inw)) <= 4 * len(inw)
+            assert inw.min() == base and inw.max() >= base + span - 8
+            inside += len(inw)
+            flushed += len(np.unique(inw))
+        assert nwin > 0
+        assert (st["win_emissions"], st["win_inside"], st["win_flushed"]) == (tot, inside, flushed)
+        return A, (tot - inside + flushed) / tot
+
     p = bsm.synthetic.config5(n=20000, lo=8, hi=28, halfband=6)
-    A = bsm.synthetic.build(p, device=NODEV)
-    values, rows, cols, waves = get_image(A)
-    st = A.stats()
-    wg = waves.reshape(-1, st["ntasks"] // st["nworkgroups"])  # waves per workgroup
-    nwin = 0
-    for quad in wg:
-        assert len(set(quad["win_span8"])) == 1 and len(set(quad["win_base"])) == 1
-        span = int(quad["win_span8"][0]) * 8
-        assert span <= 512
-        if span == 0:
-            continue
-        nwin += 1
-        base = int(quad["win_base"][0])
-        groups = set()
-        for W in quad[(quad["work"] == WORK_PANEL) & (quad["npieces"] > 0)]:
-            m = int(W["m"])
-            r = np.arange(W["rbase"], W["rbase"] + m) if W["rbase"] >= 0 else rows[W["row_off"]:W["row_off"] + m]
-            c = cols[W["first"]["col_off"]:W["first"]["col_off"] + W["first"]["ncols"]] & 0x7fffffff
-            assert r.min() >= base and r.max() < base + span and c.min() >= base and c.max() < base + span
-            groups.add((int(W["rbase"]), int(W["row_off"])))
-        assert len(groups) >= 2
-    assert nwin > 0
+    check(p, 512)
     # coloured handles never use the window (plain RMW per colour class)
     B = bsm.synthetic.build(p, device=NODEV, accumulate="colored")
     assert not np.any(get_image(B)[3]["win_span8"])
+    # the reference's BEM fixture (ComplexF64: 256 entries): panels with a few far columns still get a
+    # window over their dense part, and fewer than 0.7 of the contributions leave a CU as atomics
+    # (one wave per leaf, as the operator-dependent wave size gives a long launch of such panels)
+    os.environ["BSM_WAVE_BYTES"] = "24576"
+    try:
+        _, frac = check(fixture_problem("cuboid"), 256)
+    finally:
+        del os.environ["BSM_WAVE_BYTES"]
+    assert frac < 0.7, frac
 
 
 @pytest.mark.parametrize("key", ["cuboid", "sphere"])

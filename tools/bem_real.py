@@ -36,9 +36,13 @@ def run(problem, name, **kw):
     b.record()
     torch.cuda.synchronize()
     t = a.elapsed_time(b) * 1e-3 / 20
+    em = st.get("win_emissions", 0)
+    atom = (em - st.get("win_inside", 0) + st.get("win_flushed", 0)) / em if em else float("nan")
     print(f"{name}: {t*1e6:.1f} us, {st['alg_bytes']/t/1e9:.0f} GB/s algorithmic, stored {st['stored_entries']*dt.itemsize/1e6:.0f} MB, "
-          f"wgs {st['nworkgroups']}, excl {st['exclusive']}", flush=True)
+          f"wgs {st['nworkgroups']}, excl {st['exclusive']}, y contributions leaving as atomics {atom:.2f}", flush=True)
 run(prob, "fused symmetric")
+if os.environ.get("BEM_GATHER"):
+    run(prob, "fused symmetric, gather mode (no atomics)", accumulate="gather")
 fwd = dict(kind="blocksparse", blocks=prob["diagonals"] + prob["offdiagonals"],
            rowindices=prob["diagonalindices"] + prob["rowindices"],
            colindices=prob["diagonalindices"] + prob["colindices"], size=prob["size"])
