@@ -41,8 +41,8 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("OMP_NUM_THREADS", str(min(len(os.sched_getaffinity(0)), 16)))
 
 HBM_PEAK_GBPS = 8000.0  # MI355X spec (MI355X_MICROARCH.md); measured-copy ceiling 6290
-PMC_FILE = os.path.join(ROOT, "profiles", "r02_c2_pmc.json")  # written by tools/pmc_summary.py
-MFMA_FILE = os.path.join(ROOT, "profiles", "r02_c4_mfma.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r03_c2_pmc.json")  # written by tools/pmc_summary.py, stamped with the build id
+MFMA_FILE = os.path.join(ROOT, "profiles", "r03_c4_mfma.json")
 
 
 def read_json(path):
@@ -51,6 +51,83 @@ def read_json(path):
             return json.load(f)
     except Exception:
         return None
+
+
+def counter_file(path, build, kernel=None, alg_bytes=None):
+    """A rocprofv3 counter summary under profiles/ -- only if it was taken with THIS build of the kernels
+    (and, where given, this kernel and byte count); else (None, why)."""
+    d = read_json(path)
+    if d is None:
+        return None, "no counter file " + os.path.relpath(path, ROOT)
+    if d.get("build") != build:
+        return None, "%s was taken with build %s, this is %s" % (os.path.relpath(path, ROOT), d.get("build"), build)
+    if kernel is not None and d.get("kernel") not in kernel:
+        return None, "%s is for kernel %s" % (os.path.relpath(path, ROOT), d.get("kernel"))
+    if alg_bytes is not None and d.get("alg_bytes_per_launch") != alg_bytes:
+        return None, "%s is for %s algorithmic bytes per launch, this run has %d" % (os.path.relpath(path, ROOT), d.get("alg_bytes_per_launch"), alg_bytes)
+    return d, None
+
+
+def graph_timed(fn, steps, torch):
+    """Device time per call of `fn` when `steps` calls are captured into ONE hipGraph and replayed (HIP
+    events around the replay, on the stream it runs on); None when capture is not available."""
+    try:
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=s):
+                for _ in range(steps):
+                    fn()
+        torch.cuda.current_stream().wait_stream(s)
+        g.replay()
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        g.replay()
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) * 1e-3 / steps
+    except Exception:  # pragma: no cover
+        return None
+
+
+class StreamFloor:
+    """Bare streaming read of a buffer (include/bsm_synth.h: bsm_bench_stream): the product kernels' request
+    shape and nothing else -- what the memory system gives a launch of that size."""
+
+    def __init__(self, torch, nbytes):
+        import ctypes as C
+        from bsm_amd import _lib
+        self.C, self.torch, self.L = C, torch, _lib.lib()
+        self.nbytes = int(nbytes) // 16 * 16
+        self.buf = torch.zeros(self.nbytes // 8, dtype=torch.float64, device="cuda")
+        nwaves = ((self.nbytes // 16 + 2047) // 2048) * 4
+        self.scratch = torch.zeros((8192 + 64 * nwaves) // 8, dtype=torch.float64, device="cuda")
+        self(1)  # uploads the record table of the hop variant
+        torch.cuda.synchronize()
+
+    def __call__(self, hop=0):
+        C = self.C
+        rc = self.L.bsm_bench_stream(C.c_void_p(self.buf.data_ptr()), self.nbytes, C.c_void_p(self.scratch.data_ptr()),
+                                     self.scratch.numel() * 8, hop, C.c_void_p(self.torch.cuda.current_stream().cuda_stream))
+        if rc:
+            raise RuntimeError("bsm_bench_stream failed")
+
+
+def cold_median(fn, flush, reps, torch):
+    """median device time of fn() right after flush() (every cache holds something else)"""
+    ts = []
+    for _ in range(reps):
+        flush()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        fn()
+        b.record()
+        torch.cuda.synchronize()
+        ts.append(a.elapsed_time(b) * 1e-3)
+    ts.sort()
+    return ts[len(ts) // 2]
 
 
 def timed(fn, reps, torch):
@@ -78,6 +155,8 @@ def leg(bsm, torch, prob, reps, **kw):
     out = {"us": round(t * 1e6, 2), "GBps": round(st["alg_bytes"] / t / 1e9, 1),
            "frac_of_hbm_peak": round(st["alg_bytes"] / t / 1e9 / HBM_PEAK_GBPS, 4),
            "alg_MB": round(st["alg_bytes"] / 1e6, 1), "device_MB": round(st["device_bytes"] / 1e6, 1)}
+    if st.get("win_emissions"):  # fused symmetric launch: share of the y contributions that leave a CU as global atomics
+        out["y_contributions_as_atomics"] = round((st["win_emissions"] - st["win_inside"] + st["win_flushed"]) / st["win_emissions"], 3)
     del plan, A
     return out, y
 
@@ -400,9 +479,6 @@ def run_partitioned(args, bsm, torch, dist, np, rank, world, barrier, reduce_sca
         extra["c4"] = {"error": repr(e)}
         if dist is not None:
             raise  # a rank that skipped collectives would hang the others: fail loudly instead
-    mf = read_json(MFMA_FILE)
-    if mf:
-        extra["c4_mfma"] = mf
     kb = r5["rank_alg"]
     roofline = {"bound": "hbm", "achieved": round(kb / r5["kdur"] / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(kb / r5["kdur"] / 1e9 / HBM_PEAK_GBPS, 4), "traffic": None,
@@ -455,7 +531,30 @@ def run_partitioned(args, bsm, torch, dist, np, rank, world, barrier, reduce_sca
 # ------------------------------------------------------------------------------------------------
 # N = 1 (and --workload c2 at N > 1: weak scaling, no collective): C2
 # ------------------------------------------------------------------------------------------------
+def bem_tiled_problem(torch, np, K=400):
+    """The reference's own workload: its BEM test fixture (test/assets/symmetricblockexamples.jld2 "cuboid",
+    decoded to tests/golden/symmetric_cuboid.bin: ComplexF64, 96 leaves of 3-28 rows, wide near-field panels
+    with scattered columns) tiled K times along the diagonal -- the true block shapes at a size that
+    streams from HBM (SURVEY.md 8d, C3').  The 188 blocks are uploaded once and referenced K times."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from _common import fixture_problem
+    p = fixture_problem("cuboid", np.complex128, "full")
+    n0 = p["size"][0]
+    dd = [torch.from_numpy(np.ascontiguousarray(b.T)).cuda().t() for b in p["diagonals"]]   # column-major on the GPU
+    oo = [torch.from_numpy(np.ascontiguousarray(b.T)).cuda().t() for b in p["offdiagonals"]]
+    tile = lambda lists: [l + k * n0 for k in range(K) for l in lists]
+    prob = dict(kind="symmetric", diagonals=dd * K, diagonalindices=tile(p["diagonalindices"]),
+                offdiagonals=oo * K, rowindices=tile(p["rowindices"]), colindices=tile(p["colindices"]),
+                size=(n0 * K, n0 * K))
+    rng = np.random.default_rng(0)
+    xh = (rng.standard_normal(n0 * K) + 1j * rng.standard_normal(n0 * K)).astype(np.complex128)
+    prob["x"] = torch.from_numpy(xh).cuda()
+    return prob, p, n0
+
+
 def run_c2(args, bsm, torch, dist, np, rank, world, barrier, reduce_scalars):
+    from bsm_amd import _lib
+    build = _lib.lib().bsm_version().decode().split("build ")[-1]
     prob = bsm.synthetic.config2(part=(rank, world) if world > 1 else None)
     A = bsm.VariableBlockCompressedRowStorage(prob["blocks"], prob["rowstart"], prob["colstart"],
                                               prob["size"], own=prob.get("own"))
@@ -520,17 +619,36 @@ def run_c2(args, bsm, torch, dist, np, rank, world, barrier, reduce_scalars):
     # one step == one launch of bsm::panel_kernel<double,8,true,false,true> (forward-only, non-temporal
     # matrix loads); its average duration is the HIP-event time of the timed region / K (back-to-back
     # launches on one stream; the rocprofv3 --kernel-trace average in profiles/ must agree).
+    KERNEL = "bsm::panel_kernel<double,8,true,false,true>"
     kdur = dev_elapsed / args.steps
     achieved = alg_bytes / kdur / 1e9
-    pmc = read_json(PMC_FILE) or {}
+    pmc, why = counter_file(PMC_FILE, build, kernel=KERNEL, alg_bytes=int(alg_bytes))
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": pmc.get("traffic_bytes_per_launch"),
-                "kernel": "bsm::panel_kernel<double,8,true,false,true>",
+                "frac": round(achieved / HBM_PEAK_GBPS, 4),
+                "traffic": pmc["traffic_bytes_per_launch"] if pmc else None,
+                "kernel": KERNEL, "build": build,
                 "alg_bytes_per_launch": int(alg_bytes), "avg_launch_us": round(kdur * 1e6, 3),
-                "note": "warm: the 54 MB operator stays in the 256 MiB Infinity Cache between launches (see "
-                        "extra.hbm_vbcrs_fp64 / extra.c3_fused for HBM-streaming legs); traffic = rocprofv3 "
-                        "FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE per launch, read from "
-                        + os.path.relpath(PMC_FILE, ROOT)}
+                "note": "warm: the 54 MB operator stays in the 256 MiB Infinity Cache between launches, so `frac` divides "
+                        "a cache-resident launch by the HBM peak -- stream_floor_us is what a BARE streaming read of the "
+                        "same byte count takes in the same state (same request shape, nothing else to do) and "
+                        "frac_of_stream_floor the honest distance; extra.hbm_vbcrs_fp64 / extra.c3_fused / "
+                        "extra.bem_tiled are HBM-streaming legs.  traffic = rocprofv3 FETCH_SIZE x2 (gfx950 "
+                        "correction) + WRITE_SIZE per launch from " + os.path.relpath(PMC_FILE, ROOT)
+                        + (" -- NOT used: " + why if why else " (same build, kernel and byte count)")}
+    floor = None
+    if rank == 0:
+        try:
+            floor = StreamFloor(torch, alg_bytes)
+            for _ in range(20):
+                floor()
+            torch.cuda.synchronize()
+            f_us = graph_timed(floor, args.steps, torch) if launch == "graph" else None
+            if f_us is None:
+                f_us = timed(floor, args.steps, torch)
+            roofline["stream_floor_us"] = round(f_us * 1e6, 3)
+            roofline["frac_of_stream_floor"] = round(f_us / kdur, 4)
+        except Exception as e:  # pragma: no cover
+            roofline["stream_floor_error"] = repr(e)
 
     extra = {}
     if rank == 0 and launch == "graph":
@@ -540,32 +658,24 @@ def run_c2(args, bsm, torch, dist, np, rank, world, barrier, reduce_scalars):
         extra["eager_us_per_step"] = round(timed(plan, args.steps, torch) * 1e6, 3)
     if rank == 0 and world == 1 and not args.no_extra:
         flush = torch.empty(512 << 20, dtype=torch.uint8, device="cuda")
-        cold = []
-        for _ in range(20):
-            flush.fill_(1)
-            a, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record()
-            plan()
-            b_.record()
-            torch.cuda.synchronize()
-            cold.append(a.elapsed_time(b_) * 1e-3)
-        cold.sort()
-        extra["cold_median_us"] = round(cold[len(cold) // 2] * 1e6, 2)
-        extra["cold_GBps"] = round(alg_bytes / cold[len(cold) // 2] / 1e9, 1)
+        dirty = lambda: flush.fill_(1)
+        clean = lambda: flush.sum()
+        c = cold_median(plan, dirty, 20, torch)
+        extra["cold_median_us"] = round(c * 1e6, 2)
+        extra["cold_GBps"] = round(alg_bytes / c / 1e9, 1)
         # the same with a READ sweep of 512 MiB as the flush: the operator is out of every cache, but
         # the launch does not have to evict 256 MiB of dirty lines first
-        cold = []
-        for _ in range(20):
-            flush.sum()
-            a, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record()
-            plan()
-            b_.record()
-            torch.cuda.synchronize()
-            cold.append(a.elapsed_time(b_) * 1e-3)
-        cold.sort()
-        extra["cold_clean_median_us"] = round(cold[len(cold) // 2] * 1e6, 2)
-        extra["cold_clean_GBps"] = round(alg_bytes / cold[len(cold) // 2] / 1e9, 1)
+        cc = cold_median(plan, clean, 20, torch)
+        extra["cold_clean_median_us"] = round(cc * 1e6, 2)
+        extra["cold_clean_GBps"] = round(alg_bytes / cc / 1e9, 1)
+        if floor is not None:
+            # the cold FLOOR: the bare streaming read of the same byte count right after the same flush, and
+            # the same with the one dependent descriptor load every product wave starts with
+            f0 = cold_median(lambda: floor(0), dirty, 20, torch)
+            f1 = cold_median(lambda: floor(1), dirty, 20, torch)
+            extra["cold_floor_us"] = round(f0 * 1e6, 2)
+            extra["cold_floor_hop_us"] = round(f1 * 1e6, 2)
+            extra["cold_over_floor_hop"] = round(c / f1, 3)
         del flush
         # driver-timed HBM-streaming legs (operators far larger than the 256 MiB Infinity Cache),
         # generated in HBM and packed by the device-side packer
@@ -578,38 +688,32 @@ def run_c2(args, bsm, torch, dist, np, rank, world, barrier, reduce_scalars):
         except Exception as e:  # pragma: no cover
             extra["legs_error"] = repr(e)
         torch.cuda.empty_cache()
-    mf = read_json(MFMA_FILE)
-    if mf and rank == 0:
-        extra["c4_mfma"] = mf
-
-    # ---- CPU baseline: the oracle (reference loop structure, C port), rank 0, N = 1 only -------------
-    cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from oracle.oracle import load_oracle_native
-        orc = load_oracle_native()  # -O3 -march=native build of oracle/bsm_oracle.c, compiled on this box
-        perm, rowptr, colind, rowind = orc.vbcrs_build(prob["rowstart"], prob["colstart"])
-        blocks = [prob["blocks"][p - 1] for p in perm]
-        xh = prob["x"]
-        yh = np.zeros(n)
-        # everything is marshalled once; the repetitions and the clock are inside C (orc_vbcrs_bench_f64)
-        reps, dt = orc.vbcrs_bench(blocks, rowptr, colind, rowind, xh, yh, seconds=10.0)
-        err = float(np.max(np.abs(y.cpu().numpy() - yh)) / np.max(np.abs(yh)))
-        cpu = {"value": round(st["alg_bytes"] * reps / dt / 1e9, 3), "unit": "GB/s", "cores": 1, "kind": "port",
-               "sample": f"{reps} full C2 mul! calls of oracle/bsm_oracle.c (orc_vbcrs_mul_f64, gcc -O3 "
-                         f"-march=native, loop timed in C, no marshalling) in {dt:.1f} s on one host core",
-               "gpu_vs_oracle_relerr": err}
-        # all host cores: one OpenMP task per block row == the reference's `@tasks for browidx` with
-        # DynamicScheduler() (src/vbcrs.jl:275-276); reported beside, not as the baseline
         try:
-            ncores = int(os.environ.get("OMP_NUM_THREADS", "1"))
-            yp = np.zeros(n)
-            preps, dtp = orc.vbcrs_bench(blocks, rowptr, colind, rowind, xh, yp, seconds=5.0, parallel=True)
-            extra["cpu_allcores"] = {"value": round(st["alg_bytes"] * preps / dtp / 1e9, 3), "unit": "GB/s",
-                                     "cores": ncores, "kind": "port (OpenMP over block rows)",
-                                     "sample": f"{preps} C2 mul! calls in {dtp:.1f} s, timed in C",
-                                     "relerr_vs_1core": float(np.max(np.abs(yp - yh)) / np.max(np.abs(yh)))}
+            bp, fx, n0 = bem_tiled_problem(torch, np)
+            extra["bem_tiled"], yb = leg(bsm, torch, bp, 50)
+            extra["bem_tiled"]["workload"] = ("the reference's BEM fixture (test/assets/symmetricblockexamples.jld2 'cuboid', ComplexF64, "
+                                              "3-28-row leaves, scattered near-field columns) tiled 400 x along the diagonal, fused A + A^T mul!")
+            extra["bem_tiled"]["dtype"] = "c128"
+            # parity of the leg: tile 0 of y against the fixture's own product through an independent COO sum
+            import scipy.sparse as sp
+            rr, cc_, vv = [], [], []
+            for blk, idx in zip(fx["diagonals"], fx["diagonalindices"]):
+                R, Cq = np.meshgrid(idx - 1, idx - 1, indexing="ij")
+                rr.append(R.ravel()); cc_.append(Cq.ravel()); vv.append(blk.ravel())
+            for blk, ri, ci in zip(fx["offdiagonals"], fx["rowindices"], fx["colindices"]):
+                R, Cq = np.meshgrid(ri - 1, ci - 1, indexing="ij")
+                rr += [R.ravel(), Cq.ravel()]; cc_ += [Cq.ravel(), R.ravel()]; vv += [blk.ravel(), blk.ravel()]
+            M0 = sp.coo_matrix((np.concatenate(vv), (np.concatenate(rr), np.concatenate(cc_))), shape=(n0, n0)).tocsr()
+            ref = M0 @ bp["x"][:n0].cpu().numpy()
+            got = yb[:n0].cpu().numpy()
+            extra["bem_tiled"]["relerr_vs_coo"] = float(np.max(np.abs(got - ref)) / np.max(np.abs(ref)))
+            del bp, yb
         except Exception as e:  # pragma: no cover
-            extra["cpu_allcores"] = {"error": str(e)}
+            extra["bem_tiled"] = {"error": repr(e)}
+        torch.cuda.empty_cache()
+    mf, why_mf = counter_file(MFMA_FILE, build)
+    if rank == 0:
+        extra["c4_mfma"] = mf if mf else {"unavailable": why_mf}
 
     out = {
         "metric": "fp64 block-SpMV GB/s (VBCRS mul!, algorithmic bytes / time)",
@@ -625,10 +729,39 @@ def run_c2(args, bsm, torch, dist, np, rank, world, barrier, reduce_scalars):
                    "frac_of_hbm_peak": round(value / (HBM_PEAK_GBPS * world), 4)},
         "roofline": roofline,
     }
-    if cpu is not None:
-        out["cpu_baseline"] = cpu
     if extra:
         out["extra"] = extra
+
+    # ---- CPU baseline: the oracle (reference loop structure, C port), rank 0, N = 1 only -------------
+    # LAST: every GPU figure above is complete (and kept on stderr) before these ~15 s of host work start
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        print("[bench] GPU legs complete, CPU baseline next: " + json.dumps(out), file=sys.stderr, flush=True)
+        from oracle.oracle import load_oracle_native
+        orc = load_oracle_native()  # -O3 -march=native build of oracle/bsm_oracle.c, compiled on this box
+        perm, rowptr, colind, rowind = orc.vbcrs_build(prob["rowstart"], prob["colstart"])
+        blocks = [prob["blocks"][p - 1] for p in perm]
+        xh = prob["x"]
+        yh = np.zeros(n)
+        # everything is marshalled once; the repetitions and the clock are inside C (orc_vbcrs_bench_f64)
+        reps, dt = orc.vbcrs_bench(blocks, rowptr, colind, rowind, xh, yh, seconds=10.0)
+        err = float(np.max(np.abs(y.cpu().numpy() - yh)) / np.max(np.abs(yh)))
+        out["cpu_baseline"] = {"value": round(st["alg_bytes"] * reps / dt / 1e9, 3), "unit": "GB/s", "cores": 1, "kind": "port",
+                               "sample": f"{reps} full C2 mul! calls of oracle/bsm_oracle.c (orc_vbcrs_mul_f64, gcc -O3 "
+                                         f"-march=native, loop timed in C, no marshalling) in {dt:.1f} s on one host core",
+                               "gpu_vs_oracle_relerr": err}
+        # all host cores: one OpenMP task per block row == the reference's `@tasks for browidx` with
+        # DynamicScheduler() (src/vbcrs.jl:275-276); reported beside, not as the baseline
+        try:
+            ncores = int(os.environ.get("OMP_NUM_THREADS", "1"))
+            yp = np.zeros(n)
+            preps, dtp = orc.vbcrs_bench(blocks, rowptr, colind, rowind, xh, yp, seconds=5.0, parallel=True)
+            out.setdefault("extra", {})["cpu_allcores"] = {
+                "value": round(st["alg_bytes"] * preps / dtp / 1e9, 3), "unit": "GB/s",
+                "cores": ncores, "kind": "port (OpenMP over block rows)",
+                "sample": f"{preps} C2 mul! calls in {dtp:.1f} s, timed in C",
+                "relerr_vs_1core": float(np.max(np.abs(yp - yh)) / np.max(np.abs(yh)))}
+        except Exception as e:  # pragma: no cover
+            out.setdefault("extra", {})["cpu_allcores"] = {"error": str(e)}
     return out
 
 

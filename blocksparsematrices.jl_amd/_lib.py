@@ -58,7 +58,7 @@ EXPORTS = ["bsm_options_default", "bsm_vbcrs_create", "bsm_vbcrs_create_from_sym
 
 
 # include/bsm_synth.h (bench / test utility: synthetic operators generated in HBM)
-SYNTH_EXPORTS = ["bsm_synth_blocks", "bsm_synth_vector"]
+SYNTH_EXPORTS = ["bsm_synth_blocks", "bsm_synth_vector", "bsm_bench_stream"]
 
 
 def lib():
@@ -118,6 +118,8 @@ def lib():
     L.bsm_synth_blocks.argtypes = [C.c_int, C.c_uint64, C.c_int64, _I64P, _I64P, _I64P, _I32P, _PP, C.c_void_p]
     L.bsm_synth_vector.argtypes = [C.c_int, C.c_uint64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]
     L.bsm_synth_blocks.restype = L.bsm_synth_vector.restype = C.c_int
+    L.bsm_bench_stream.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
+    L.bsm_bench_stream.restype = C.c_int
     L.bsm_mul.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                           C.c_int, C.c_int, C.c_void_p]
     L.bsm_mul_multi.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,

@@ -90,7 +90,10 @@ DeviceGuard::~DeviceGuard() {
 
 extern "C" const char *bsm_last_error(void) { return g_err.c_str(); }
 
-extern "C" const char *bsm_version(void) { return "bsmrocm 0.1 gfx950"; }
+#ifndef BSM_BUILD_ID
+#define BSM_BUILD_ID "unknown"
+#endif
+extern "C" const char *bsm_version(void) { return "bsmrocm 0.3 gfx950 build " BSM_BUILD_ID; }
 
 extern "C" void bsm_options_default(bsm_options *o) {
     if (!o) return;

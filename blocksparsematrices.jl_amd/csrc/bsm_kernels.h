@@ -64,6 +64,9 @@ struct SynthBlockDesc {
     uint64_t dst, stream;
     int32_t m, n, symmetrise, pad;
 };
+// bare streaming read of `bytes` at src (bsm_bench_stream): sink >= 8 KB of scratch, hop = optional table of one
+// 64-byte record per wave whose first int64 is the wave's position (a dependent scalar load per wave)
+hipError_t launch_stream_floor(const void *src, long long bytes, void *sink, const void *hop, hipStream_t stream);
 hipError_t launch_synth_blocks(int dtype, const void *d_desc, long long nblocks, int tiles, hipStream_t stream);
 hipError_t launch_synth_vector(int dtype, void *dst, long long n, unsigned long long stream_seed, hipStream_t stream);
 

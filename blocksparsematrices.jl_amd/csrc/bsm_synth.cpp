@@ -65,3 +65,34 @@ extern "C" int bsm_synth_vector(int dtype, uint64_t seed, int64_t first, int64_t
     if (e != hipSuccess) return hip_fail(e, "bsm_synth_vector");
     return BSM_OK;
 }
+
+// One launch of the bare streaming read (stream_floor_kernel) over buf[0, bytes).  `scratch` must hold 8 KB +
+// (hop ? 64 bytes per 8 KB of `bytes` : 0): with hop != 0 its tail is filled (once per call signature: every
+// call, it is cheap) with the identity table the waves read their position from.
+extern "C" int bsm_bench_stream(const void *buf, int64_t bytes, void *scratch, int64_t scratch_bytes, int hop,
+                                void *stream) {
+    if (!buf || bytes < 16 || !scratch) return fail(BSM_ERR_INVALID, "bad argument");
+    const int64_t nwaves = ((bytes / 16 + 2047) / 2048) * 4;
+    const int64_t need = 8192 + (hop ? nwaves * 64 : 0);
+    if (scratch_bytes < need) return fail(BSM_ERR_INVALID, "scratch too small: " + std::to_string(need) + " bytes needed");
+    hipStream_t st = (hipStream_t)stream;
+    const void *table = nullptr;
+    if (hop) {
+        // the table is written by the host once per scratch buffer: its first word tells whether it is there
+        static thread_local const void *filled = nullptr;
+        static thread_local int64_t filled_waves = 0;
+        char *t = (char *)scratch + 8192;
+        if (filled != scratch || filled_waves < nwaves) {
+            std::vector<int64_t> h((size_t)nwaves * 8, 0);
+            for (int64_t w = 0; w < nwaves; w++) h[(size_t)w * 8] = w;
+            hipError_t e = hipMemcpy(t, h.data(), h.size() * 8, hipMemcpyHostToDevice);
+            if (e != hipSuccess) return hip_fail(e, "hop table upload");
+            filled = scratch;
+            filled_waves = nwaves;
+        }
+        table = t;
+    }
+    hipError_t e = launch_stream_floor(buf, bytes, scratch, table, st);
+    if (e != hipSuccess) return hip_fail(e, "bsm_bench_stream");
+    return BSM_OK;
+}

@@ -327,7 +327,8 @@ int bsm_destroy(bsm_matrix_t A);
 /* thread-local message of the last failing call in this thread ("" if none) */
 const char *bsm_last_error(void);
 
-/* library / build identification, e.g. "bsmrocm 0.1 gfx950" */
+/* library / build identification, e.g. "bsmrocm 0.3 gfx950 build 1a2b3c4d5e6f": the build id is a hash of the
+ * kernel and schedule sources, so that a measurement can be tied to what actually ran */
 const char *bsm_version(void);
 
 #ifdef __cplusplus

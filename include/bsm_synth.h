@@ -33,6 +33,15 @@ int bsm_synth_blocks(int dtype, uint64_t seed, int64_t nblocks, const int64_t *i
 /* the right-hand side x of configuration `seed`: entries [first, first + count) into dst */
 int bsm_synth_vector(int dtype, uint64_t seed, int64_t first, int64_t count, void *dst, void *stream);
 
+/* Measurement utility (bench.py: roofline.stream_floor_us, extra.cold_floor_us): ONE launch of a bare
+ * streaming read of buf[0, bytes) with the request shape of the product kernels -- 8 independent 16-byte
+ * non-temporal loads per lane, 8 KB per wave, nothing else to do.  hop != 0: every wave first reads its
+ * position from a 64-byte record through a scalar load (the one dependent round trip a product wave
+ * starts with: its descriptor).  scratch: device memory, 8 KB + (hop ? 64 bytes per 8 KB of `bytes` : 0).
+ * Enqueued on `stream`; the first call with a given scratch buffer and hop != 0 uploads the record
+ * table synchronously. */
+int bsm_bench_stream(const void *buf, int64_t bytes, void *scratch, int64_t scratch_bytes, int hop, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol(bsm):
     assert sorted(L.EXPORTS) == declared
     # ... and the bench / test utility header
     syn = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "bsm_synth.h")).read(), flags=re.S)
-    syn_declared = sorted(set(re.findall(r"\b(bsm_synth_[a-z_]+)\s*\(", syn)))
+    syn_declared = sorted(set(re.findall(r"\b(bsm_(?:synth|bench)_[a-z_]+)\s*\(", syn)))
     assert syn_declared == sorted(L.SYNTH_EXPORTS)
     for name in syn_declared:
         assert hasattr(lib, name), f"{name} declared in include/bsm_synth.h but not exported"

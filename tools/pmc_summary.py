@@ -52,6 +52,10 @@ def main():
                "note": "MFMA instruction / busy counters of the C4 product (128x128 fp32 blocks): expected 0 -- a single "
                        "right-hand side fills 1/16 of an MFMA tile and v_mfma_f32_*_f32 runs at the VALU FMA rate on "
                        "gfx950 (MI355X_MICROARCH.md, matrix cores), so the HBM-bound panel kernel uses v_fma only"}
+    # the build of the kernels the counters were taken with (bench.py refuses a file of another build)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bsm_amd import _lib
+    res["build"] = _lib.lib().bsm_version().decode().split("build ")[-1]
     with open(out_path, "w") as fh:
         json.dump(res, fh, indent=1)
         fh.write("\n")
