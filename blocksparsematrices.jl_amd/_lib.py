@@ -30,7 +30,7 @@ class BsmOptions(C.Structure):
 class BsmPartInfo(C.Structure):
     _fields_ = [("device", C.c_int32), ("reserved32", C.c_int32), ("own_lo", C.c_int64), ("own_hi", C.c_int64),
                 ("touched_lo", C.c_int64), ("touched_hi", C.c_int64), ("device_bytes", C.c_int64),
-                ("nblocks", C.c_int64), ("reserved", C.c_int64 * 4)]
+                ("nblocks", C.c_int64), ("col_lo", C.c_int64), ("col_hi", C.c_int64), ("reserved", C.c_int64 * 2)]
 
 
 class BsmStats(C.Structure):
@@ -53,7 +53,7 @@ EXPORTS = ["bsm_options_default", "bsm_vbcrs_create", "bsm_vbcrs_create_from_sym
            "bsm_vbcrs_create_from_blocksparse", "bsm_ctx_create", "bsm_ctx_destroy", "bsm_ctx_devices",
            "bsm_partition_rows", "bsm_part_info", "bsm_host_register", "bsm_host_unregister", "bsm_rowcolvals",
            "bsm_blocksparse_create",
-           "bsm_symmetric_create", "bsm_mul", "bsm_mul_multi", "bsm_get_bookkeeping", "bsm_get_image", "bsm_stats",
+           "bsm_symmetric_create", "bsm_mul", "bsm_mul_multi", "bsm_mul_parts", "bsm_get_bookkeeping", "bsm_get_image", "bsm_stats",
            "bsm_color", "bsm_destroy", "bsm_last_error", "bsm_version"]
 
 
@@ -125,6 +125,8 @@ def lib():
     L.bsm_mul_multi.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,
                                 C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     L.bsm_mul_multi.restype = C.c_int
+    L.bsm_mul_parts.argtypes = [C.c_void_p, C.c_int, _PP, _PP, C.c_void_p, C.c_void_p, C.c_int, _PP]
+    L.bsm_mul_parts.restype = C.c_int
     L.bsm_get_bookkeeping.argtypes = [C.c_void_p, C.c_int, _I64P, _I64P]
     L.bsm_get_image.argtypes = [C.c_void_p, C.c_int, C.c_void_p, _I64P]
     L.bsm_color.argtypes = [C.c_int64, _PP, _I64P, C.c_int, _I64P, _I64P]

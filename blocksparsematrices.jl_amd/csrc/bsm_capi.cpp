@@ -952,6 +952,15 @@ extern "C" int bsm_mul(bsm_matrix_t A, int op, const void *x, void *y, const voi
     return BSM_OK;
 }
 
+extern "C" int bsm_mul_parts(bsm_matrix_t A, int op, const void *const *x_parts, void *const *y_parts,
+                             const void *alpha, const void *beta, int beta_strong_zero, void *const *streams) {
+    if (!A) return fail(BSM_ERR_INVALID, "null handle");
+    if (op < 0 || op > 2) return fail(BSM_ERR_INVALID, "bad op");
+    if (!x_parts || !y_parts) return fail(BSM_ERR_INVALID, "null vector parts");
+    if (!A->dist) return fail(BSM_ERR_INVALID, "bsm_mul_parts needs a multi-device handle (bsm_options.ctx)");
+    return dist_mul_parts(A, op, x_parts, y_parts, alpha, beta, beta_strong_zero, streams);
+}
+
 extern "C" int bsm_mul_multi(bsm_matrix_t A, int op, int64_t nrhs, const void *X, int64_t ldx, void *Y,
                              int64_t ldy, const void *alpha, const void *beta, int beta_strong_zero,
                              int memspace, void *stream) {
@@ -962,8 +971,9 @@ extern "C" int bsm_mul_multi(bsm_matrix_t A, int op, int64_t nrhs, const void *X
     if (!X || !Y) return fail(BSM_ERR_INVALID, "null matrix");
     if (!A->on_device)
         return fail(BSM_ERR_DEVICE, "handle has no device image (created with BSM_DEVICE_NONE)");
-    const long long xlen = (op == 0 ? A->img.ncols : A->img.nrows);
-    const long long ylen = (op == 0 ? A->img.nrows : A->img.ncols);
+    // (the whole operator's size: a multi-device handle has no image of its own)
+    const long long xlen = (op == 0 ? A->an.ncols : A->an.nrows);
+    const long long ylen = (op == 0 ? A->an.nrows : A->an.ncols);
     if (ldx < std::max<long long>(xlen, 1) || ldy < std::max<long long>(ylen, 1))
         return fail(BSM_ERR_INVALID, "leading dimension smaller than the vector length");
     if (A->dist)  // multi-device handles: every device streams its part once per batch of <= 8 columns

@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <complex>
 #include <condition_variable>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <map>
@@ -43,6 +44,7 @@ struct Transfer {  // part `from` produced y[range] for rows part `to` owns
 // everything that depends on the direction of the product relative to the partition
 struct Plan {
     std::vector<Range> xr;    // x entries part p reads
+    std::vector<Range> in;    // x entries part p HOLDS when the vectors are partitioned (bsm_mul_parts): a tiling of [0, xlen)
     std::vector<Range> out;   // y entries part p delivers (a tiling of [0, ylen))
     std::vector<Range> zr;    // y entries part p must define in its work vector (touched + out)
     std::vector<Transfer> transfers;
@@ -60,8 +62,9 @@ struct Part {
     Range own;         // rows it owns
     Range rows, cols;  // hull of the row / column indices of its blocks
     hipStream_t stream = nullptr;
-    hipEvent_t ev_prod = nullptr, ev_done = nullptr;
+    hipEvent_t ev_prod = nullptr, ev_done = nullptr, ev_in = nullptr;
     void *d_x = nullptr, *d_w = nullptr, *d_recv = nullptr;
+    Range colpart;  // the part's share of the COLUMN partition (vectors of length ncols held in parts)
 };
 
 // One persistent thread per part, bound to the part's device once.  run(f) executes f(p) on every
@@ -147,6 +150,12 @@ struct DistState {
     int res_dev = -1;
     size_t res_bytes = 0;
     std::vector<char> h_res;  // numeric beta, y on the host
+    // every pair of the context's devices can address each other's memory: the vector traffic of a product
+    // with device-resident vectors runs as two fused kernels per device (fetch / finish) instead of copies
+    bool all_peer = false;
+    bool produced = false;       // some product has been issued: ev_done / ev_tail carry a record
+    hipEvent_t ev_tail = nullptr;  // end of the last copy-path product on its caller's stream
+    int tail_dev = -1;
 };
 
 }  // namespace bsm
@@ -303,7 +312,13 @@ void dist_destroy(bsm_matrix_s *A) {
             if (q) (void)hipFree(q);
         if (p.ev_prod) (void)hipEventDestroy(p.ev_prod);
         if (p.ev_done) (void)hipEventDestroy(p.ev_done);
+        if (p.ev_in) (void)hipEventDestroy(p.ev_in);
         if (p.stream) (void)hipStreamDestroy(p.stream);
+    }
+    if (D.ev_tail) {
+        DeviceGuard g;
+        (void)g.enter(D.tail_dev);
+        (void)hipEventDestroy(D.ev_tail);
     }
     for (auto &kv : D.ev_x) {
         DeviceGuard g;
@@ -343,6 +358,12 @@ int dist_create(bsm_matrix_s *A, bsm_ctx_s *ctx, int mtype, int dtype, int64_t n
     D.plan_t.xr.resize(P);
     D.plan_t.out.resize(P);
     const long long chunk_t = (ncols + P - 1) / P;
+    // the COLUMN partition (what a part holds of a vector of length ncols when the vectors are partitioned,
+    // and what it delivers of a product across the row partition): the row partition itself for square
+    // operators -- y of one product is x of the next, part by part -- else equal chunks
+    const bool square = (nrows == ncols);
+    D.plan_n.in.resize(P);
+    D.plan_t.in.resize(P);
     std::vector<std::vector<BlockIn>> subs(P);
     for (size_t b = 0; b < in.size(); b++) subs[part_of[b]].push_back(in[b]);
     for (int p = 0; p < P; p++) {
@@ -360,9 +381,12 @@ int dist_create(bsm_matrix_s *A, bsm_ctx_s *ctx, int mtype, int dtype, int64_t n
         touched_n[p] = pt.rows;
         // products ACROSS it (transpose / adjoint of a row-partitioned VBCRS / BlockSparseMatrix): every
         // part holds a partial result over the columns of its blocks; reduce-scatter onto equal chunks
+        pt.colpart = square ? pt.own : Range{std::min<long long>(p * chunk_t, ncols), std::min<long long>((p + 1) * chunk_t, ncols)};
         D.plan_t.xr[p] = pt.rows;
-        D.plan_t.out[p] = Range{std::min<long long>(p * chunk_t, ncols), std::min<long long>((p + 1) * chunk_t, ncols)};
+        D.plan_t.out[p] = pt.colpart;
         touched_t[p] = pt.cols;
+        D.plan_n.in[p] = pt.colpart;
+        D.plan_t.in[p] = pt.own;
     }
     finish_plan(D.plan_n, touched_n, D.es);
     finish_plan(D.plan_t, touched_t, D.es);
@@ -400,22 +424,257 @@ int dist_create(bsm_matrix_s *A, bsm_ctx_s *ctx, int mtype, int dtype, int64_t n
         e = hipStreamCreateWithFlags(&pt.stream, hipStreamNonBlocking);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&pt.ev_prod, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&pt.ev_done, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&pt.ev_in, hipEventDisableTiming);
         if (e == hipSuccess) e = hipMalloc(&pt.d_x, vec_bytes);
         if (e == hipSuccess) e = hipMalloc(&pt.d_w, vec_bytes);
         const size_t rb = std::max(D.plan_n.recv_bytes[p], D.plan_t.recv_bytes[p]);
         if (e == hipSuccess && rb) e = hipMalloc(&pt.d_recv, rb);
         if (e != hipSuccess) return hip_fail(e, "multi-device buffers");
     }
-    if (P > 2) D.workers.reset(new Workers(ctx->devices));
+    D.all_peer = true;
+    for (int a : ctx->devices)
+        for (int b : ctx->devices) {
+            if (a == b) continue;
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, a, b) != hipSuccess) {
+                (void)hipGetLastError();
+                can = 0;
+            }
+            D.all_peer = D.all_peer && can != 0;
+        }
+    if (const char *v = std::getenv("BSM_DIST_COPIES")) D.all_peer = D.all_peer && std::atoi(v) == 0;  // tests: force the copy path
+    // one persistent issuing thread per device from five parts on (BSM_DIST_WORKERS = smallest part count that
+    // gets them): below, the calling thread issues everything faster than the threads can be woken twice
+    int wmin = 5;
+    if (const char *v = std::getenv("BSM_DIST_WORKERS")) wmin = std::atoi(v);
+    if (P >= wmin) D.workers.reset(new Workers(ctx->devices));
+    return BSM_OK;
+}
+
+// part buffers for K columns (grow-only).  EVERY part's stream is drained before ANY buffer goes: a peer may
+// still be reading this part's work vector.
+static hipError_t grow_buffers(DistState &D, int K) {
+    if (K <= D.kcap) return hipSuccess;
+    const int P = (int)D.parts.size();
+    const size_t es = (size_t)D.es;
+    hipError_t e = hipSuccess;
+    for (int p = 0; p < P && e == hipSuccess; p++) {
+        DeviceGuard g;
+        e = g.enter(D.parts[p]->device);
+        if (e == hipSuccess) e = hipStreamSynchronize(D.parts[p]->stream);
+    }
+    if (e == hipSuccess && D.ev_tail) e = hipEventSynchronize(D.ev_tail);
+    for (int p = 0; p < P && e == hipSuccess; p++) {
+        Part &pt = *D.parts[p];
+        DeviceGuard g;
+        e = g.enter(pt.device);
+        if (e != hipSuccess) break;
+        for (void **q : {&pt.d_x, &pt.d_w, &pt.d_recv}) {
+            if (*q) (void)hipFree(*q);
+            *q = nullptr;
+        }
+        e = hipMalloc(&pt.d_x, D.vlen * es * K);
+        if (e == hipSuccess) e = hipMalloc(&pt.d_w, D.vlen * es * K);
+        const size_t rb = std::max(D.plan_n.recv_bytes[p], D.plan_t.recv_bytes[p]);
+        if (e == hipSuccess && rb) e = hipMalloc(&pt.d_recv, rb * K);
+    }
+    if (e == hipSuccess) D.kcap = K;
+    return e;
+}
+
+// ---- the fused path: device-resident vectors, every device of the context peer-accessible ----------------
+// Where a part finds the x entries it reads, and where it delivers its y entries.  bsm_mul: ONE source (the
+// caller's x) and one destination (the caller's y), on the caller's stream.  bsm_mul_parts: part q HOLDS the
+// x entries plan.in[q] and receives the y entries plan.out[q], on its own stream.
+struct VecSource {
+    const char *base;   // virtual base: entry i of the global vector at base + i * es
+    Range valid;        // entries this source holds
+    int device;
+    hipStream_t stream; // where the entries are produced
+    hipEvent_t ready;   // recorded on `stream` at the start of the call
+    int strided;        // column k of a multi-RHS batch at + k * ldx (else the source holds one column)
+};
+struct VecDest {
+    char *base;  // virtual base of the y entries
+    int device;
+    hipStream_t stream;
+    hipEvent_t ready;
+};
+
+static int dist_mul_fused(DistState &D, int op, int K, const std::vector<VecSource> &src, long long ldx,
+                          const std::vector<VecDest> &dst, long long ldy, const void *alpha, const void *beta,
+                          int beta_strong_zero) {
+    const int P = (int)D.parts.size();
+    const bool along = (op == BSM_OP_N) || D.symmetric;
+    const Plan &pl = along ? D.plan_n : D.plan_t;
+    const bool opT = (op != BSM_OP_N);
+    const bool conj = (op == BSM_OP_C);
+    const size_t es = (size_t)D.es;
+    const size_t vlen = D.vlen;
+    hipError_t e = hipSuccess;
+#define DCHECK(call, what)                             \
+    do {                                               \
+        e = (call);                                    \
+        if (e != hipSuccess) return hip_fail(e, what); \
+    } while (0)
+    DCHECK(grow_buffers(D, K), "multi-device buffers");
+    // "x (and the incoming y) are ready" on every stream that produces them
+    {
+        std::vector<hipEvent_t> done;
+        auto record = [&](hipEvent_t ev, hipStream_t st, int dev) -> hipError_t {
+            for (hipEvent_t d : done)
+                if (d == ev) return hipSuccess;
+            done.push_back(ev);
+            DeviceGuard g;
+            hipError_t e2 = g.enter(dev);
+            return e2 == hipSuccess ? hipEventRecord(ev, st) : e2;
+        };
+        for (const VecSource &s : src) DCHECK(record(s.ready, s.stream, s.device), "hipEventRecord");
+        for (const VecDest &d : dst) DCHECK(record(d.ready, d.stream, d.device), "hipEventRecord");
+    }
+    const bool was_produced = D.produced;
+    // The stream a part's work is issued on.  bsm_mul_parts: the caller's stream of that part -- local work needs
+    // no cross-stream hop at all, only what depends on a PEER waits for an event.  bsm_mul: the first part that
+    // lives on the caller's device works on the caller's stream for the same reason (the hops of the other
+    // parts then overlap with it); the others use their own streams.
+    std::vector<hipStream_t> run((size_t)P);
+    {
+        bool taken = false;
+        for (int p = 0; p < P; p++) {
+            const VecDest &yd = dst[dst.size() == 1 ? 0 : (size_t)p];
+            const bool mine = yd.device == D.parts[p]->device && (dst.size() > 1 || !taken);
+            run[p] = mine ? yd.stream : D.parts[p]->stream;
+            if (mine) taken = true;
+        }
+    }
+    // A part that neither sends nor receives a y segment (VBCRS forward: block rows own disjoint y ranges,
+    // reference src/vbcrs.jl:275-283) multiplies straight into the caller's y -- beta fused, no work vector,
+    // no delivery launch.
+    std::vector<char> direct((size_t)P, 0);
+    for (int p = 0; p < P; p++) {
+        bool alone = D.parts[p]->has_image && pl.zr[p].lo == pl.out[p].lo && pl.zr[p].hi == pl.out[p].hi;
+        for (const Transfer &t : pl.transfers) alone = alone && t.from != p && t.to != p;
+        direct[p] = alone;
+    }
+    auto wait_for = [&](int p, hipEvent_t ev, hipStream_t recorded_on) -> hipError_t {
+        if (recorded_on == run[p]) return hipSuccess;  // same stream: already ordered
+        return hipStreamWaitEvent(run[p], ev, 0);
+    };
+    // phase 0 (part p): wait for its inputs, gather the x pieces it reads (one launch), local product
+    // phase 1 (part q): add the y segments its peers produced for its rows, deliver (one launch)
+    auto phase = [&](int ph, int p, bool bind) -> int {
+        hipError_t e = hipSuccess;
+        Part &pt = *D.parts[p];
+        DeviceGuard g;
+        if (bind) DCHECK(g.enter(pt.device), "hipSetDevice");
+        const VecDest &yd = dst[dst.size() == 1 ? 0 : (size_t)p];
+        hipStream_t st = run[(size_t)p];
+        if (ph == 0) {
+            // peers that read this part's work vector in the previous product have finished (their ev_done
+            // carries that product's record until phase 1 of THIS product re-records it, after a host barrier)
+            if (was_produced) {
+                for (const Transfer &t : D.plan_n.transfers)
+                    if (t.from == p) DCHECK(hipStreamWaitEvent(st, D.parts[t.to]->ev_done, 0), "hipStreamWaitEvent");
+                for (const Transfer &t : D.plan_t.transfers)
+                    if (t.from == p) DCHECK(hipStreamWaitEvent(st, D.parts[t.to]->ev_done, 0), "hipStreamWaitEvent");
+                DCHECK(hipStreamWaitEvent(st, pt.ev_done, 0), "hipStreamWaitEvent");  // its own previous delivery (another stream, perhaps)
+                if (D.ev_tail) DCHECK(hipStreamWaitEvent(st, D.ev_tail, 0), "hipStreamWaitEvent");
+            }
+            DCHECK(wait_for(p, yd.ready, yd.stream), "hipStreamWaitEvent");  // the incoming y (numeric beta) / its buffer
+            const Range zr = pl.zr[p];
+            if (pt.has_image) {
+                const Range xr = pl.xr[p];
+                const void *xp = pt.d_x;
+                long long xld = (long long)vlen;
+                VecPieces pc;
+                int np = 0;
+                bool in_place = false;
+                for (const VecSource &s : src) {
+                    const Range o = isect(s.valid, xr);
+                    if (o.empty()) continue;
+                    DCHECK(wait_for(p, s.ready, s.stream), "hipStreamWaitEvent");
+                    if (o.lo == xr.lo && o.hi == xr.hi && s.device == pt.device) {  // everything it reads lies on its own device
+                        xp = s.base;
+                        xld = s.strided ? ldx : 0;
+                        in_place = true;
+                        break;
+                    }
+                    if (np == kMaxVecPieces) {
+                        DCHECK(launch_vec_fetch(D.dtype, pt.d_x, (long long)vlen, pc, np, ldx, K, st), "x fetch");
+                        np = 0;
+                    }
+                    pc.base[np] = s.base;
+                    pc.lo[np] = o.lo;
+                    pc.hi[np] = o.hi;
+                    pc.strided[np] = s.strided;
+                    np++;
+                }
+                if (!in_place && np) DCHECK(launch_vec_fetch(D.dtype, pt.d_x, (long long)vlen, pc, np, ldx, K, st), "x fetch");
+                const long long z[2] = {zr.lo, zr.hi};
+                void *target = direct[p] ? (void *)yd.base : pt.d_w;
+                const long long tld = direct[p] ? ldy : (long long)vlen;
+                const void *b = direct[p] ? beta : nullptr;
+                const int sz = direct[p] ? beta_strong_zero : 1;
+                if (K == 1)
+                    DCHECK(launch_mul(pt.img, opT, conj, xp, target, alpha, b, sz, st, false, z), "kernel launch");
+                else
+                    DCHECK(launch_mul_multi(pt.img, opT, conj, K, xp, xld, target, tld, alpha, b, sz, st, z), "kernel launch");
+            } else if (!zr.empty()) {
+                for (int k = 0; k < K; k++)
+                    DCHECK(hipMemsetAsync((char *)pt.d_w + ((size_t)k * vlen + zr.lo) * es, 0, (size_t)zr.len() * es, st), "memset");
+            }
+            DCHECK(hipEventRecord(pt.ev_prod, st), "hipEventRecord");
+            return BSM_OK;
+        }
+        const Range o = pl.out[p];
+        VecPieces pc;
+        int np = 0;
+        for (const Transfer &t : pl.transfers) {
+            if (t.to != p) continue;
+            Part &from = *D.parts[t.from];
+            DCHECK(wait_for(p, from.ev_prod, run[(size_t)t.from]), "hipStreamWaitEvent");
+            if (np == kMaxVecPieces) {  // more peers than one launch takes: fold these into the work vector first
+                DCHECK(launch_vec_finish(D.dtype, nullptr, 0, pt.d_w, (long long)vlen, pc, np, o.lo, o.hi, nullptr, 1, 1, K, st), "halo add");
+                np = 0;
+            }
+            pc.base[np] = from.d_w;
+            pc.lo[np] = t.range.lo;
+            pc.hi[np] = t.range.hi;
+            pc.strided[np] = 1;
+            np++;
+        }
+        if (!o.empty() && !direct[p])
+            DCHECK(launch_vec_finish(D.dtype, yd.base, ldy, pt.d_w, (long long)vlen, pc, np, o.lo, o.hi, beta, beta_strong_zero, 0, K,
+                                     st), "y delivery");
+        DCHECK(hipEventRecord(pt.ev_done, st), "hipEventRecord");
+        return BSM_OK;
+    };
+    for (int ph = 0; ph < 2; ph++) {
+        int rc = BSM_OK;
+        if (D.workers)
+            rc = D.workers->run([&](int p) { return phase(ph, p, false); });
+        else
+            for (int p = 0; p < P && rc == BSM_OK; p++) rc = phase(ph, p, true);
+        if (rc != BSM_OK) return rc;
+    }
+    D.produced = true;
+    // the consumers of y continue when the parts that deliver to them are done
+    for (int q = 0; q < P; q++) {
+        const VecDest &yd = dst[dst.size() == 1 ? 0 : (size_t)q];
+        if (yd.stream == run[(size_t)q]) continue;  // delivered on the consumer's own stream
+        DeviceGuard g;
+        DCHECK(g.enter(yd.device), "hipSetDevice");
+        DCHECK(hipStreamWaitEvent(yd.stream, D.parts[q]->ev_done, 0), "hipStreamWaitEvent");
+    }
+#undef DCHECK
     return BSM_OK;
 }
 
 // K <= 8 right-hand sides in one fan-out (K = 1: bsm_mul).  X / Y: column k at x + k * ldx / y + k * ldy
 // elements.  The part buffers hold column k at k * vlen elements.
-static int dist_mul_k(bsm_matrix_s *A, int op, int K, const void *x, long long ldx, void *y, long long ldy,
-                      const void *alpha, const void *beta, int beta_strong_zero, int memspace, hipStream_t stream) {
+static int dist_mul_copies(bsm_matrix_s *A, int op, int K, const void *x, long long ldx, void *y, long long ldy,
+                           const void *alpha, const void *beta, int beta_strong_zero, int memspace, hipStream_t stream) {
     DistState &D = *A->dist;
-    std::lock_guard<std::mutex> lock(D.mu);
     const int P = (int)D.parts.size();
     const bool along = (op == BSM_OP_N) || D.symmetric;
     const Plan &pl = along ? D.plan_n : D.plan_t;
@@ -423,6 +682,8 @@ static int dist_mul_k(bsm_matrix_s *A, int op, int K, const void *x, long long l
     const bool conj = (op == BSM_OP_C);
     const size_t es = (size_t)D.es;
     const long long ylen = (op == BSM_OP_N) ? D.nrows : D.ncols;
+    static const double kZero[2] = {0.0, 0.0};
+    if (!beta) beta = kZero;  // "NULL = 0" of include/bsm_rocm.h, also where this file reads beta itself
     const size_t vlen = D.vlen;  // elements per column of the part buffers
     const char *xb = (const char *)x;
     char *yb = (char *)y;
@@ -435,25 +696,7 @@ static int dist_mul_k(bsm_matrix_s *A, int op, int K, const void *x, long long l
         if (e != hipSuccess) return hip_fail(e, what); \
     } while (0)
 
-    // part buffers for K columns (grow-only; the parts are idle: products on one handle are serialised)
-    if (K > D.kcap) {
-        for (int p = 0; p < P; p++) {
-            Part &pt = *D.parts[p];
-            DeviceGuard g;
-            DCHECK(g.enter(pt.device), "hipSetDevice");
-            DCHECK(hipStreamSynchronize(pt.stream), "hipStreamSynchronize");
-            for (void **q : {&pt.d_x, &pt.d_w, &pt.d_recv}) {
-                if (*q) (void)hipFree(*q);
-                *q = nullptr;
-            }
-            DCHECK(hipMalloc(&pt.d_x, vlen * es * K), "multi-device buffers");
-            DCHECK(hipMalloc(&pt.d_w, vlen * es * K), "multi-device buffers");
-            const size_t rb = std::max(D.plan_n.recv_bytes[p], D.plan_t.recv_bytes[p]);
-            if (rb) DCHECK(hipMalloc(&pt.d_recv, rb * K), "multi-device buffers");
-        }
-        D.kcap = K;
-    }
-
+    DCHECK(grow_buffers(D, K), "multi-device buffers");
     int cur = 0;
     DCHECK(hipGetDevice(&cur), "hipGetDevice");
     int xdev = -1, ydev = -1, sdev = cur;
@@ -515,6 +758,12 @@ static int dist_mul_k(bsm_matrix_s *A, int op, int K, const void *x, long long l
         DeviceGuard g;
         if (bind) DCHECK(g.enter(pt.device), "hipSetDevice");
         if (ph == 0) {
+            // the previous product of this handle -- peers still reading this part's work vector, the late
+            // combine on the caller's stream reading the result staging -- is complete before this one starts
+            if (D.produced) {
+                for (int q = 0; q < P; q++) DCHECK(hipStreamWaitEvent(pt.stream, D.parts[q]->ev_done, 0), "hipStreamWaitEvent");
+                if (D.ev_tail) DCHECK(hipStreamWaitEvent(pt.stream, D.ev_tail, 0), "hipStreamWaitEvent");
+            }
             if (ev_ready) DCHECK(hipStreamWaitEvent(pt.stream, ev_ready, 0), "hipStreamWaitEvent");
             const Range zr = pl.zr[p];
             if (pt.has_image) {
@@ -595,6 +844,7 @@ static int dist_mul_k(bsm_matrix_s *A, int op, int K, const void *x, long long l
             for (int p = 0; p < P && rc == BSM_OK; p++) rc = phase(ph, p, true);
         if (rc != BSM_OK) return rc;
     }
+    D.produced = true;
     if (host) {
         for (int q = 0; q < P; q++) {
             Part &pt = *D.parts[q];
@@ -639,8 +889,85 @@ static int dist_mul_k(bsm_matrix_s *A, int op, int K, const void *x, long long l
                                         (char *)D.d_res + ((size_t)k * ylen + o.lo) * es, o.len(), beta, stream), "y combine");
         }
     }
+    {  // the end of this product on the caller's stream: what the next product of the handle waits for
+        DeviceGuard g;
+        DCHECK(g.enter(sdev), "hipSetDevice");
+        if (D.ev_tail && D.tail_dev != sdev) {
+            (void)hipEventDestroy(D.ev_tail);
+            D.ev_tail = nullptr;
+        }
+        if (!D.ev_tail) {
+            DCHECK(hipEventCreateWithFlags(&D.ev_tail, hipEventDisableTiming), "hipEventCreate");
+            D.tail_dev = sdev;
+        }
+        DCHECK(hipEventRecord(D.ev_tail, stream), "hipEventRecord");
+    }
 #undef DCHECK
     return BSM_OK;
+}
+
+static int dist_mul_k(bsm_matrix_s *A, int op, int K, const void *x, long long ldx, void *y, long long ldy,
+                      const void *alpha, const void *beta, int beta_strong_zero, int memspace, hipStream_t stream) {
+    DistState &D = *A->dist;
+    std::lock_guard<std::mutex> lock(D.mu);  // one product of a handle is ISSUED at a time (the work vectors are the handle's)
+    if (memspace == BSM_MEM_DEVICE && D.all_peer) {
+        int cur = 0;
+        hipError_t e = hipGetDevice(&cur);
+        if (e != hipSuccess) return hip_fail(e, "hipGetDevice");
+        const int xdev = pointer_device(x, cur), ydev = pointer_device(y, cur);
+        int sdev = cur;
+        if (stream && hipStreamGetDevice(stream, &sdev) != hipSuccess) {
+            (void)hipGetLastError();
+            sdev = cur;
+        }
+        bool inside = false, xin = false, yin = false;
+        for (const auto &pp : D.parts) {
+            inside |= pp->device == sdev;
+            xin |= pp->device == xdev;
+            yin |= pp->device == ydev;
+        }
+        if (inside && xin && yin) {  // x, y and the stream live on devices of the context: everybody can address them
+            auto it = D.ev_x.find(sdev);
+            if (it == D.ev_x.end()) {
+                DeviceGuard g;
+                e = g.enter(sdev);
+                hipEvent_t ev = nullptr;
+                if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+                if (e != hipSuccess) return hip_fail(e, "hipEventCreate");
+                it = D.ev_x.emplace(sdev, ev).first;
+            }
+            const long long xlen = (op == BSM_OP_N) ? D.ncols : D.nrows;
+            std::vector<VecSource> src{VecSource{(const char *)x, Range{0, xlen}, xdev, stream, it->second, 1}};
+            std::vector<VecDest> dst{VecDest{(char *)y, ydev, stream, it->second}};
+            return dist_mul_fused(D, op, K, src, ldx, dst, ldy, alpha, beta, beta_strong_zero);
+        }
+    }
+    return dist_mul_copies(A, op, K, x, ldx, y, ldy, alpha, beta, beta_strong_zero, memspace, stream);
+}
+
+// bsm_mul_parts: x and y PARTITIONED over the devices of the handle (include/bsm_rocm.h)
+int dist_mul_parts(bsm_matrix_s *A, int op, const void *const *x_parts, void *const *y_parts, const void *alpha,
+                   const void *beta, int beta_strong_zero, void *const *streams) {
+    DistState &D = *A->dist;
+    std::lock_guard<std::mutex> lock(D.mu);
+    if (!D.all_peer)
+        return fail(BSM_ERR_UNSUPPORTED, "bsm_mul_parts needs peer access between all devices of the context");
+    const int P = (int)D.parts.size();
+    const bool along = (op == BSM_OP_N) || D.symmetric;
+    const Plan &pl = along ? D.plan_n : D.plan_t;
+    const size_t es = (size_t)D.es;
+    std::vector<VecSource> src;
+    std::vector<VecDest> dst;
+    for (int p = 0; p < P; p++) {
+        const Part &pt = *D.parts[p];
+        const Range in = pl.in[p], out = pl.out[p];
+        if ((!in.empty() && !x_parts[p]) || (!out.empty() && !y_parts[p]))
+            return fail(BSM_ERR_INVALID, "part " + std::to_string(p) + ": null vector part");
+        hipStream_t st = streams ? (hipStream_t)streams[p] : nullptr;
+        src.push_back(VecSource{(const char *)x_parts[p] - (size_t)in.lo * es, in, pt.device, st, pt.ev_in, 0});
+        dst.push_back(VecDest{(char *)y_parts[p] - (size_t)out.lo * es, pt.device, st, pt.ev_in});
+    }
+    return dist_mul_fused(D, op, 1, src, 0, dst, 0, alpha, beta, beta_strong_zero);
 }
 
 int dist_mul(bsm_matrix_s *A, int op, const void *x, void *y, const void *alpha, const void *beta,
@@ -675,6 +1002,8 @@ int dist_part_info(bsm_matrix_s *A, int32_t part, bsm_part_info_t *out) {
     out->touched_hi = z.hi;
     out->device_bytes = p.img.device_bytes;
     out->nblocks = p.nblocks;
+    out->col_lo = p.colpart.lo + 1;
+    out->col_hi = p.colpart.hi;
     return BSM_OK;
 }
 

@@ -73,6 +73,8 @@ int dist_mul(bsm_matrix_s *A, int op, const void *x, void *y, const void *alpha,
              int beta_strong_zero, int memspace, hipStream_t stream);
 int dist_mul_multi(bsm_matrix_s *A, int op, long long nrhs, const void *X, long long ldx, void *Y, long long ldy,
                    const void *alpha, const void *beta, int beta_strong_zero, int memspace, hipStream_t stream);
+int dist_mul_parts(bsm_matrix_s *A, int op, const void *const *x_parts, void *const *y_parts, const void *alpha,
+                   const void *beta, int beta_strong_zero, void *const *streams);
 void dist_destroy(bsm_matrix_s *A);
 int dist_part_info(bsm_matrix_s *A, int32_t part, bsm_part_info_t *out);
 int64_t dist_device_bytes(const bsm_matrix_s *A);

@@ -42,6 +42,24 @@ hipError_t launch_mul(const DeviceImage &img, bool opT, bool conj, const void *x
 hipError_t launch_vec_add(int dtype, void *dst, const void *src, long long n, hipStream_t stream);
 hipError_t launch_vec_axpby(int dtype, void *y, const void *r, long long n, const void *beta, hipStream_t stream);
 
+// Fused vector traffic of multi-device handles (peer-accessible devices): up to kMaxVecPieces sources per launch,
+// each a virtual base pointer (element i of the global vector at base + i; column k of a multi-RHS batch
+// `ld` elements further when strided) valid for indices [lo, hi).
+constexpr int kMaxVecPieces = 8;
+struct VecPieces {
+    const void *base[kMaxVecPieces];
+    long long lo[kMaxVecPieces], hi[kMaxVecPieces];
+    int strided[kMaxVecPieces];
+};
+// dst[i + k * ld_dst] = piece(i)[k * ld_src] for every piece's range, K columns
+hipError_t launch_vec_fetch(int dtype, void *dst, long long ld_dst, const VecPieces &pc, int npieces, long long ld_src, int K,
+                            hipStream_t stream);
+// y[i] = beta * y[i] + w[i] + sum of the pieces covering i, i in [lo, hi), K columns (w and the pieces: column stride
+// ldw); accumulate_only: the sum goes back to w instead (more than kMaxVecPieces contributions)
+hipError_t launch_vec_finish(int dtype, void *y, long long ldy, void *w, long long ldw, const VecPieces &pc, int npieces,
+                             long long lo, long long hi, const void *beta, int strong_zero, int accumulate_only, int K,
+                             hipStream_t stream);
+
 // nrhs right-hand sides: X (ldx) and Y (ldy) column-major; A is streamed once per batch of <= 8.
 hipError_t launch_mul_multi(const DeviceImage &img, bool opT, bool conj, long long nrhs, const void *x,
                             long long ldx, void *y, long long ldy, const void *alpha, const void *beta,

@@ -1194,6 +1194,86 @@ __global__ void __launch_bounds__(256) vec_axpby_kernel(T *__restrict__ y, const
     const long long stride = (long long)gridDim.x * blockDim.x;
     for (; i < n; i += stride) y[i] = madd(r[i], beta, y[i]);
 }
+// ---- fused fan-out kernels of multi-device handles (bsm_dist.cpp) ------------------------------------
+// The devices of a context can read each other's memory over xGMI (peer access), so the vector traffic of
+// a product needs no copy engine and no staging buffer: ONE launch per device gathers the x pieces the
+// device's blocks read (from the caller's x or from the x parts of its peers), ONE launch adds the y
+// segments the peers produced for its rows to its own and writes the result to the caller's y (beta fused).
+// Every pointer is a "virtual base": element i of the global vector lives at base + i.
+template <typename T>
+__global__ void __launch_bounds__(256) vec_fetch_kernel(T *__restrict__ dst, long long ld_dst, VecPieces pc, long long ld_src) {
+    const int c = blockIdx.y;
+    const T *__restrict__ src = reinterpret_cast<const T *>(pc.base[c]) + (long long)blockIdx.z * (pc.strided[c] ? ld_src : 0);
+    T *__restrict__ d = dst + (long long)blockIdx.z * ld_dst;
+    const long long lo = pc.lo[c], hi = pc.hi[c];
+    for (long long i = lo + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < hi; i += (long long)gridDim.x * blockDim.x)
+        d[i] = src[i];
+}
+
+// y[i] = (strong ? 0 : beta * y[i]) + w[i] + sum over the pieces that cover i;  accumulate_only: w[i] += ... (no y)
+template <typename T>
+__global__ void __launch_bounds__(256) vec_finish_kernel(T *__restrict__ y, long long ldy, T *__restrict__ w, long long ldw,
+                                                         VecPieces pc, int npieces, long long lo, long long hi, T beta,
+                                                         int strong_zero, int accumulate_only) {
+    const long long k = blockIdx.y;
+    T *__restrict__ wk = w + k * ldw;
+    for (long long i = lo + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < hi; i += (long long)gridDim.x * blockDim.x) {
+        T v = wk[i];
+        for (int c = 0; c < npieces; ++c)
+            if (i >= pc.lo[c] && i < pc.hi[c]) v = add(v, (reinterpret_cast<const T *>(pc.base[c]) + k * ldw)[i]);
+        if (accumulate_only) {
+            wk[i] = v;
+        } else {
+            T *__restrict__ yk = y + k * ldy;
+            yk[i] = strong_zero ? v : madd(v, beta, yk[i]);
+        }
+    }
+}
+
+template <typename T>
+static hipError_t fetch_typed(void *dst, long long ld_dst, const VecPieces &pc, int npieces, long long ld_src, int K,
+                              hipStream_t stream) {
+    long long longest = 0;
+    for (int c = 0; c < npieces; ++c) longest = longest > pc.hi[c] - pc.lo[c] ? longest : pc.hi[c] - pc.lo[c];
+    if (npieces <= 0 || longest <= 0) return hipSuccess;
+    long long nblk = (longest + 255) / 256;
+    if (nblk > 1024) nblk = 1024;
+    hipLaunchKernelGGL((vec_fetch_kernel<T>), dim3((unsigned)nblk, (unsigned)npieces, (unsigned)K), dim3(256), 0, stream, (T *)dst,
+                       ld_dst, pc, ld_src);
+    return hipGetLastError();
+}
+hipError_t launch_vec_fetch(int dtype, void *dst, long long ld_dst, const VecPieces &pc, int npieces, long long ld_src, int K,
+                            hipStream_t stream) {
+    switch (dtype) {
+        case 0: return fetch_typed<float>(dst, ld_dst, pc, npieces, ld_src, K, stream);
+        case 1: return fetch_typed<double>(dst, ld_dst, pc, npieces, ld_src, K, stream);
+        case 2: return fetch_typed<c64>(dst, ld_dst, pc, npieces, ld_src, K, stream);
+        case 3: return fetch_typed<c128>(dst, ld_dst, pc, npieces, ld_src, K, stream);
+    }
+    return hipErrorInvalidValue;
+}
+template <typename T>
+static hipError_t finish_typed(void *y, long long ldy, void *w, long long ldw, const VecPieces &pc, int npieces, long long lo,
+                               long long hi, const void *beta_p, int strong_zero, int accumulate_only, int K, hipStream_t stream) {
+    if (hi <= lo) return hipSuccess;
+    long long nblk = (hi - lo + 255) / 256;
+    if (nblk > 2048) nblk = 2048;
+    hipLaunchKernelGGL((vec_finish_kernel<T>), dim3((unsigned)nblk, (unsigned)K), dim3(256), 0, stream, (T *)y, ldy, (T *)w, ldw, pc,
+                       npieces, lo, hi, load_scalar<T>(beta_p, 0.0), strong_zero, accumulate_only);
+    return hipGetLastError();
+}
+hipError_t launch_vec_finish(int dtype, void *y, long long ldy, void *w, long long ldw, const VecPieces &pc, int npieces,
+                             long long lo, long long hi, const void *beta, int strong_zero, int accumulate_only, int K,
+                             hipStream_t stream) {
+    switch (dtype) {
+        case 0: return finish_typed<float>(y, ldy, w, ldw, pc, npieces, lo, hi, beta, strong_zero, accumulate_only, K, stream);
+        case 1: return finish_typed<double>(y, ldy, w, ldw, pc, npieces, lo, hi, beta, strong_zero, accumulate_only, K, stream);
+        case 2: return finish_typed<c64>(y, ldy, w, ldw, pc, npieces, lo, hi, beta, strong_zero, accumulate_only, K, stream);
+        case 3: return finish_typed<c128>(y, ldy, w, ldw, pc, npieces, lo, hi, beta, strong_zero, accumulate_only, K, stream);
+    }
+    return hipErrorInvalidValue;
+}
+
 template <typename T>
 static hipError_t vec_launch(int which, void *dst, const void *src, long long n, const void *beta_p, hipStream_t stream) {
     if (n <= 0) return hipSuccess;

@@ -32,7 +32,7 @@ except Exception:  # pragma: no cover
 __all__ = [
     "SerialScheduler", "DynamicScheduler", "isserial", "AbstractBlockMatrix", "BlockSparseMatrix",
     "SymmetricBlockMatrix", "VariableBlockCompressedRowStorage", "TransposeMap", "AdjointMap",
-    "transpose", "adjoint", "mul", "MulPlan", "nnz", "size", "eltype", "scheduler", "block", "eachblockindex",
+    "transpose", "adjoint", "mul", "mul_parts", "MulPlan", "nnz", "size", "eltype", "scheduler", "block", "eachblockindex",
     "rowindices", "colindices", "colors", "transposecolors", "diagonal", "offdiagonal",
     "eachdiagonalindex", "eachoffdiagonalindex", "diagonalindices", "diagonalcolors",
     "offdiagonalcolors", "transposeoffdiagonalcolors", "rowcolvals", "sparse", "ColorInfo", "conflicts",
@@ -303,7 +303,7 @@ class AbstractBlockMatrix(_LinearMap):
             pi = L.BsmPartInfo()
             L.check(L.lib().bsm_part_info(self._h.ptr, p, C.byref(pi)))
             out.append(dict(device=pi.device, own=(pi.own_lo, pi.own_hi), touched=(pi.touched_lo, pi.touched_hi),
-                            device_bytes=pi.device_bytes, nblocks=pi.nblocks))
+                            cols=(pi.col_lo, pi.col_hi), device_bytes=pi.device_bytes, nblocks=pi.nblocks))
         return out
 
     def stats(self):
@@ -691,6 +691,43 @@ def mul(y, A, x, alpha=True, beta=False):
     L.check(L.lib().bsm_mul(base._h.ptr, op, xp, yp, a.ctypes.data, b.ctypes.data,
                             1 if strong else 0, xms, yst if yst is not None else None))
     return y
+
+
+def mul_parts(y_parts, A, x_parts, alpha=True, beta=False):
+    """bsm_mul_parts: mul!(y, A, x, alpha, beta) on a multi-device handle with x and y PARTITIONED over its
+    devices.  x_parts[p] / y_parts[p]: torch CUDA tensors on the device of part p holding, for A (op N), the
+    x entries of the part's column range (`A.parts()[p]["cols"]`) and the y entries of its row range
+    (`["own"]`); for transpose(A) / adjoint(A) the other way round.  Enqueued on the current torch stream
+    of every part's device; nothing is synchronised."""
+    base, op = _unwrap(A)
+    if base.devices is None:
+        raise ValueError("mul_parts needs a multi-device handle (devices=[...])")
+    dt = base.dtype
+    parts = base.parts()
+    if len(x_parts) != len(parts) or len(y_parts) != len(parts):
+        raise ValueError("one x part and one y part per device of the handle")
+    P = len(parts)
+    xp, yp, st = (C.c_void_p * P)(), (C.c_void_p * P)(), (C.c_void_p * P)()
+    for p, info in enumerate(parts):
+        xr, yr = (info["cols"], info["own"]) if op == L.BSM_OP_N else (info["own"], info["cols"])
+        for v, (lo, hi), name, arr in ((x_parts[p], xr, "x", xp), (y_parts[p], yr, "y", yp)):
+            n = max(hi - lo + 1, 0)
+            if v is None and n == 0:
+                arr[p] = None
+                continue
+            if not (isinstance(v, torch.Tensor) and v.is_cuda and v.dim() == 1 and v.is_contiguous()):
+                raise TypeError(f"{name}_parts[{p}] must be a contiguous 1-D CUDA tensor")
+            if v.numel() != n or _TORCH_DT.get(v.dtype) != dt:
+                raise ValueError(f"DimensionMismatch: {name}_parts[{p}] has {v.numel()} entries of {v.dtype}, expected {n} of {dt}")
+            if v.device.index != info["device"]:
+                raise ValueError(f"{name}_parts[{p}] lives on cuda:{v.device.index}, part {p} on cuda:{info['device']}")
+            arr[p] = v.data_ptr()
+        st[p] = torch.cuda.current_stream(torch.device("cuda", info["device"])).cuda_stream
+    strong = beta is False
+    a = _scalar_buf(1 if alpha is True else alpha, dt)
+    b = _scalar_buf(0 if strong else (1 if beta is True else beta), dt)
+    L.check(L.lib().bsm_mul_parts(base._h.ptr, op, xp, yp, a.ctypes.data, b.ctypes.data, 1 if strong else 0, st))
+    return y_parts
 
 
 class MulPlan:

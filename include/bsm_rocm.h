@@ -153,7 +153,11 @@ int bsm_partition_rows(int64_t nrows, int64_t nblocks, const int64_t *rowkey, co
 typedef struct {
     int32_t device, reserved32;
     int64_t own_lo, own_hi, touched_lo, touched_hi, device_bytes, nblocks;
-    int64_t reserved[4];
+    /* the part's share of the COLUMN partition (1-based inclusive): what it holds of a vector of length
+     * size(A,2) in bsm_mul_parts.  Square operators: the row partition itself (own_lo..own_hi), so that the
+     * y parts of one product are the x parts of the next; otherwise equal chunks of the columns. */
+    int64_t col_lo, col_hi;
+    int64_t reserved[2];
 } bsm_part_info_t;
 int bsm_part_info(bsm_matrix_t A, int32_t part, bsm_part_info_t *out);
 
@@ -229,6 +233,24 @@ int bsm_symmetric_create(int dtype, int64_t nrows, int64_t ncols, int64_t ndiag,
  * x has size(op(A),2) entries, y size(op(A),1); they must not alias. */
 int bsm_mul(bsm_matrix_t A, int op, const void *x, void *y, const void *alpha,
             const void *beta, int beta_strong_zero, int memspace, void *stream);
+
+/* bsm_mul for a multi-device handle (bsm_options.ctx) with x and y PARTITIONED over its devices -- what an
+ * iterative solver on N GPUs holds: block rows own disjoint y ranges (reference src/vbcrs.jl:275-283), so
+ * nobody ever needs the whole of x or y in one place.  Part p (bsm_part_info) passes
+ *   x_parts[p]: device pointer ON ITS DEVICE to the x entries it holds -- op N: columns col_lo..col_hi,
+ *               op T / C: rows own_lo..own_hi (first entry of the range at x_parts[p][0]);
+ *   y_parts[p]: device pointer on its device to the y entries it receives -- op N: rows own_lo..own_hi,
+ *               op T / C: columns col_lo..col_hi.  Empty ranges may pass NULL.
+ * Only what a device's blocks read beyond its own part travels (the x halo), and only the y segments it
+ * produced for rows of another device (symmetric / index-list operators; a reduce-scatter for products across
+ * the partition): both as ONE fused kernel per device that reads its peers' memory over xGMI -- no copy of the
+ * full x to anybody, no staging.  streams[p] (may be NULL = the device's default stream; the array itself may be
+ * NULL): the stream of part p's device on which x_parts[p] / y_parts[p] are produced and consumed; the call
+ * orders its work behind them and them behind its result, and returns without synchronising.
+ * Needs peer access between all devices of the context (BSM_ERR_UNSUPPORTED otherwise).  alpha, beta,
+ * beta_strong_zero as in bsm_mul. */
+int bsm_mul_parts(bsm_matrix_t A, int op, const void *const *x_parts, void *const *y_parts, const void *alpha,
+                  const void *beta, int beta_strong_zero, void *const *streams);
 
 /* Page-locks a HOST vector the caller keeps using as x or y of BSM_MEM_HOST products (a Julia
  * Vector{T} that lives through a solver loop): bsm_mul then moves it by DMA straight from / to the

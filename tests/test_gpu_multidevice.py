@@ -250,3 +250,163 @@ def test_multi_rhs_through_the_multi_device_handle(torch_cuda, bsm, oracle, kind
             bsm.mul(Yh, Aop, np.asfortranarray(Xp[:n]), alpha, beta)
             for k in range(K):
                 assert relerr(Yh[:, k], refs[k]) < 1e-12, ("host", op, alpha, k)
+
+
+# ---- partitioned vectors behind the C ABI: bsm_mul_parts ------------------------------------------------------------
+def _scatter(torch, v, ranges):
+    """the parts of a full host vector (1-based inclusive ranges) as CUDA tensors"""
+    return [torch.from_numpy(np.ascontiguousarray(v[lo - 1:hi])).cuda() if hi >= lo else None for lo, hi in ranges]
+
+
+@pytest.mark.parametrize("kind,ndev", [("vbcrs", 3), ("vbcrs_rect", 2), ("symmetric", 2), ("symmetric", 4), ("fixture", 3),
+                                       ("blocksparse", 3)])
+def test_partitioned_vectors_through_the_multi_device_handle(torch_cuda, bsm, oracle, kind, ndev):
+    """bsm_mul_parts: every part holds only ITS x entries and receives only ITS y entries (reference: block rows own
+    disjoint y ranges, src/vbcrs.jl:275-283); halos and partial-y segments move as fused peer-reading kernels.
+    Against the oracle on the whole operator, every op, strong zero and numeric alpha / beta, twice (reused buffers)."""
+    torch = torch_cuda
+    if kind == "vbcrs":
+        prob = bsm.synthetic.config2(n=9000, nblocks=420)
+    elif kind == "vbcrs_rect":  # non-square: the column partition is its own (equal chunks)
+        rng = np.random.default_rng(4)
+        blocks, rs, cs = [], [], []
+        for r0 in range(1, 600, 40):
+            for c0 in rng.choice(np.arange(1, 900, 30), size=3, replace=False):
+                blocks.append(np.asfortranarray(rng.standard_normal((int(rng.integers(8, 40)), int(rng.integers(5, 30))))))
+                rs.append(r0)
+                cs.append(int(c0))
+        prob = dict(kind="vbcrs", blocks=blocks, rowstart=np.array(rs), colstart=np.array(cs), size=(640, 930))
+    elif kind == "symmetric":
+        prob = bsm.synthetic.config5(n=40_000, lo=16, hi=96, halfband=3)
+    elif kind == "fixture":
+        prob = fixture_problem("cuboid")
+    else:
+        prob = bsm.synthetic.config1(n=3000, nblocks=120, bs=24)
+    A = bsm.synthetic.build(prob, devices=[0] * ndev)
+    dt = np.dtype(A.dtype)
+    nr, nc = prob["size"]
+    parts = A.parts()
+    rows, cols = [p["own"] for p in parts], [p["cols"] for p in parts]
+    for rng_ in (rows, cols):  # both partitions tile their axis
+        cov = np.zeros(max(nr, nc) + 1, dtype=int)
+        for lo, hi in rng_:
+            if hi >= lo:
+                cov[lo:hi + 1] += 1
+        assert set(cov[1:(nr if rng_ is rows else nc) + 1]) == {1}
+    if nr == nc:
+        assert rows == cols  # square: y parts of one product are x parts of the next
+    rng = np.random.default_rng(5)
+    ops = (N, T, Cc) if dt.kind == "c" else (N, T)
+    for op in ops:
+        xl, yl = (nc, nr) if op == N else (nr, nc)
+        xr, yr = (cols, rows) if op == N else (rows, cols)
+        x, y0 = rand_vec(rng, xl, dt), rand_vec(rng, yl, dt)
+        y0[::7] = np.nan
+        combos = [(1, 0, True), (0.75, -1.5, False)] + ([(1j, 2j, False)] if dt.kind == "c" else [])
+        for alpha, beta, strong in combos:
+            yin = y0 if strong else np.nan_to_num(y0, nan=0.25)
+            ref = oracle_mul(oracle, prob, op, x, yin, alpha, beta, strong)
+            for _ in range(2):
+                xp, yp = _scatter(torch, x, xr), _scatter(torch, yin, yr)
+                bsm.mul_parts(yp, wrap(bsm, A, op), xp, alpha, False if strong else beta)
+                torch.cuda.synchronize()
+                got = np.full(yl, np.nan, dtype=dt)
+                for (lo, hi), t in zip(yr, yp):
+                    if hi >= lo:
+                        got[lo - 1:hi] = t.cpu().numpy()
+                assert relerr(got, ref) < TOL[dt], (kind, op, alpha, beta)
+    # chained: y parts of one product are the x parts of the next (square operators), no host round trip
+    if nr == nc and dt.kind != "c":
+        x = rand_vec(rng, nc, dt)
+        xp = _scatter(torch, x, cols)
+        y1 = [torch.empty_like(t) if t is not None else None for t in xp]
+        y2 = [torch.empty_like(t) if t is not None else None for t in xp]
+        bsm.mul_parts(y1, A, xp)
+        bsm.mul_parts(y2, A, y1)
+        torch.cuda.synchronize()
+        ref = oracle_mul(oracle, prob, N, oracle_mul(oracle, prob, N, x, np.zeros(nr)), np.zeros(nr))
+        got = np.concatenate([t.cpu().numpy() for t in y2 if t is not None])
+        assert relerr(got, ref) < 1e-11
+
+
+def test_copy_path_of_the_multi_device_handle_still_works(torch_cuda, bsm, oracle, monkeypatch):
+    """Devices without peer access take the copy path (hipMemcpyPeerAsync + adds): forced here with BSM_DIST_COPIES,
+    every op, host and device vectors, numeric beta (the late combine), products back to back on two streams."""
+    monkeypatch.setenv("BSM_DIST_COPIES", "1")
+    prob = bsm.synthetic.config5(n=30_000, lo=16, hi=96, halfband=3)
+    A = bsm.synthetic.build(prob, devices=[0, 0, 0])
+    check(torch_cuda, bsm, oracle, prob, A, ops=(N, T))
+    xp = _scatter(torch_cuda, prob["x"], [p["cols"] for p in A.parts()])
+    with pytest.raises(RuntimeError, match="peer access"):  # the partitioned-vector entry has no copy path
+        bsm.mul_parts([torch_cuda.empty_like(t) for t in xp], A, xp)
+
+
+def test_c_abi_null_scalars_and_leading_dimensions_on_a_multi_device_handle(torch_cuda, bsm, oracle, monkeypatch):
+    """alpha = NULL means 1 and beta = NULL means 0 on EVERY path of a multi-device handle (the host
+    numeric-beta path dereferenced beta); bsm_mul_multi rejects a leading dimension below the vector length."""
+    import ctypes as C
+    from bsm_amd import _lib as L
+    torch = torch_cuda
+    prob = bsm.synthetic.config5(n=20_000, lo=16, hi=96, halfband=3)
+    n = prob["size"][0]
+    x = prob["x"].copy()
+    ref = oracle_mul(oracle, prob, N, x, np.zeros(n), 1, 0, False)
+    for copies in ("0", "1"):
+        monkeypatch.setenv("BSM_DIST_COPIES", copies)
+        A = bsm.synthetic.build(prob, devices=[0, 0, 0])
+        lib = L.lib()
+        # host vectors, numeric beta (beta_strong_zero = 0) with beta = NULL: y = A x + 0 * y
+        y = np.full(n, 3.0)
+        L.check(lib.bsm_mul(A._h.ptr, N, x.ctypes.data, y.ctypes.data, None, None, 0, L.BSM_MEM_HOST, None))
+        assert relerr(y, ref) < 1e-12
+        xd, yd = torch.from_numpy(x).cuda(), torch.full((n,), 3.0, dtype=torch.float64, device="cuda")
+        L.check(lib.bsm_mul(A._h.ptr, N, xd.data_ptr(), yd.data_ptr(), None, None, 0, L.BSM_MEM_DEVICE, None))
+        torch.cuda.synchronize()
+        assert relerr(yd.cpu().numpy(), ref) < 1e-12
+        X = np.asfortranarray(np.stack([x, 2 * x], axis=1))
+        Y = np.zeros((n, 2), order="F")
+        rc = lib.bsm_mul_multi(A._h.ptr, N, 2, X.ctypes.data, n - 1, Y.ctypes.data, n, None, None, 1, L.BSM_MEM_HOST, None)
+        assert rc == -1 and b"leading dimension" in lib.bsm_last_error()
+        del A
+
+
+def test_unequal_parts_driven_from_two_streams(torch_cuda, bsm, oracle):
+    """products of one handle issued on two streams in turn, device vectors, parts of deliberately
+    unequal work (one part holds almost everything): a product must not overwrite a work vector a peer is still
+    reading.  Every result against the oracle."""
+    torch = torch_cuda
+    rng = np.random.default_rng(12)
+    # a symmetric operator whose first rows carry nearly all the bytes: partition by stored entries puts a few
+    # wide blocks in part 0 and hundreds of small ones in the others
+    n = 24_000
+    sz = np.concatenate([np.full(12, 250), np.full(300, 70)])
+    start = np.concatenate([[0], np.cumsum(sz)[:-1]])
+    diag, didx, off, ridx, cidx = [], [], [], [], []
+    for s0, m in zip(start, sz):
+        d = rng.standard_normal((m, m))
+        diag.append(np.asfortranarray((d + d.T) / 2))
+        didx.append(np.arange(s0 + 1, s0 + m + 1))
+    for i in range(1, len(sz)):
+        for k in (1, 2):
+            if i - k >= 0:
+                off.append(np.asfortranarray(rng.standard_normal((sz[i], sz[i - k]))))
+                ridx.append(didx[i])
+                cidx.append(didx[i - k])
+    prob = dict(kind="symmetric", diagonals=diag, diagonalindices=didx, offdiagonals=off, rowindices=ridx,
+                colindices=cidx, size=(n, n))
+    A = bsm.synthetic.build(prob, devices=[0, 0, 0, 0])
+    xs = [rng.standard_normal(n) for _ in range(2)]
+    refs = [oracle_mul(oracle, prob, N, x, np.zeros(n), 0.5, 0, True) for x in xs]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    xd = [torch.from_numpy(x).cuda() for x in xs]
+    outs = [[], []]
+    for it in range(40):
+        k = it % 2
+        with torch.cuda.stream(streams[k]):
+            yd = torch.full((n,), float("nan"), dtype=torch.float64, device="cuda")
+            bsm.mul(yd, A, xd[k], 0.5, False)
+            outs[k].append(yd)
+    torch.cuda.synchronize()
+    for k in range(2):
+        for yd in outs[k]:
+            assert relerr(yd.cpu().numpy(), refs[k]) < 1e-12

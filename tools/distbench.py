@@ -32,6 +32,19 @@ for devs in (None, [0], [0, 0], [0, 0, 0, 0]):
     for _ in range(30):
         bsm.mul(yh, A, xh)
     th = (time.perf_counter() - t0) / 30
+    tp = float("nan")
+    if devs:  # partitioned vectors (bsm_mul_parts): every part holds its x / y slice only
+        parts = A.parts()
+        xp = [x[p["cols"][0] - 1:p["cols"][1]].clone() for p in parts]
+        yp = [torch.zeros(max(p["own"][1] - p["own"][0] + 1, 0), dtype=x.dtype, device="cuda") for p in parts]
+        for _ in range(5):
+            bsm.mul_parts(yp, A, xp)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            bsm.mul_parts(yp, A, xp)
+        torch.cuda.synchronize()
+        tp = (time.perf_counter() - t0) / reps
     print(f"{which} devices={devs}: device vectors {td*1e6:8.1f} us ({st['alg_bytes']/td/1e9:6.0f} GB/s)   "
-          f"host vectors {th*1e6:8.1f} us", flush=True)
+          f"partitioned vectors {tp*1e6:8.1f} us   host vectors {th*1e6:8.1f} us", flush=True)
     del A
