@@ -206,6 +206,17 @@ template <typename T, int V, int P> struct Butterfly {
     }
 };
 
+// halving reduction over the lane bits D, 2D, ... 32 (the lanes that differ only in those bits hold partial
+// sums of the same CUR values); afterwards as for Butterfly: lane keeps max(1, CUR * D / 64) values from `pos`
+template <typename T, int CUR, int D> struct ReduceAbove {
+    static __device__ __forceinline__ void run(T *v, int lane, int &pos, int &dup) {
+        if constexpr (D < 64) {
+            bfly_step<T, CUR, D>(v, lane, pos, dup, [](T a) { return shx(a, D); });
+            ReduceAbove<T, (CUR >= 2 ? CUR / 2 : 1), D * 2>::run(v, lane, pos, dup);
+        }
+    }
+};
+
 #ifdef BSM_TRACE
 // developer build (make trace): per-wave phase timestamps for tools/wavetrace.py.  The stamps
 // (s_memtime) are parked in LDS and leave the wave once, at its end: a global store per stamp would
@@ -667,7 +678,7 @@ __device__ __forceinline__ void run_panel_multi(const WaveD &wd, const uint4 *__
                                                 const int *__restrict__ rows,
                                                 const int *__restrict__ cols, const T *__restrict__ x,
                                                 long long ldx, T *__restrict__ y, long long ldy, T alpha,
-                                                int flags, int lane, T *xs, T *vs, T (&out)[K]) {
+                                                int flags, int lane, T *xs, Vec16<T> *tile, T (&out)[K]) {
     constexpr int E = TT<T>::E;
     constexpr int G = 64 / P;
     constexpr int V = L * E;
@@ -684,14 +695,30 @@ __device__ __forceinline__ void run_panel_multi(const WaveD &wd, const uint4 *__
     T acc[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) acc[k] = zero_of(T{});
-    T xr[TRN ? K : 1];
+    // Transposed half, V[w][k] = sum_i B[i][w] * X[row(i)][k].  With the lane on the row (the layout the
+    // matrix arrives in) every one of the K right-hand sides would need its own cross-lane reduction per
+    // iteration (K halving butterflies: the multi-RHS fused products were bound by exactly that: C3 x 8 at
+    // 2.6 products, the BEM fixture at 6.4).  Instead the loaded tile (L * G strips of P rows, 16 bytes per
+    // lane and load) goes through LDS once and comes back in a COLUMN-role layout: lane (sp = lane % NS,
+    // rg = lane / NS) holds strip sp (E columns) for the L rows rg * L .. rg * L + L - 1 -- the same 16
+    // bytes per lane and load, transposed.  The x entries of those L rows stay in registers for the whole
+    // piece, the transposed product becomes L * E * K in-lane FMAs like the forward one, and only E * K
+    // partial sums per lane are reduced over the RG = 64 / NS lanes of a strip.
+    constexpr int NS = G * L;
+    constexpr int RG = 64 / NS;
+    constexpr int PM = P + 1;  // strip stride in the LDS tile (16-byte units): conflict-free for both layouts
+    static_assert(NS <= 64, "an iteration's strips must fit the wave");
+    const int sp = lane % NS, rg = lane / NS;
+    T xrr[TRN ? L : 1][K];
     if (TRN) {
 #pragma unroll
-        for (int k = 0; k < K; ++k) xr[k] = zero_of(T{});
-        if (row_ok) {
-            const int ri = (wd.rbase >= 0) ? wd.rbase + i : rows[wd.row_off + i];
+        for (int j = 0; j < L; ++j) {
+            const int r = rg * L + j;
+            const bool ok = r < m;
+            int ri = 0;
+            if (ok) ri = (wd.rbase >= 0) ? wd.rbase + r : rows[wd.row_off + r];
 #pragma unroll
-            for (int k = 0; k < K; ++k) xr[k] = x[ri + k * ldx];
+            for (int k = 0; k < K; ++k) xrr[j][k] = ok ? x[ri + k * ldx] : zero_of(T{});
         }
     }
 
@@ -741,6 +768,8 @@ __device__ __forceinline__ void run_panel_multi(const WaveD &wd, const uint4 *__
             }
             const int s_end = min(nstrips, (c0 + XCH) / E);
             for (int s0 = c0 / E; s0 < s_end; s0 += G * L) {
+                // (issuing the next iteration's matrix loads before this iteration's arithmetic -- two register
+                // buffers -- was measured here too: C3 x 8 379 -> 462 us, C4 slice x 8 406 -> 570 us)
                 Vec16<T> b[L];
 #pragma unroll
                 for (int l = 0; l < L; ++l) {
@@ -766,37 +795,43 @@ __device__ __forceinline__ void run_panel_multi(const WaveD &wd, const uint4 *__
                     }
                 }
                 if (trn_en) {
+                    // registers (row role) -> LDS -> registers (column role); one wave, LDS runs in order
 #pragma unroll
-                    for (int k = 0; k < K; ++k) {
-                        T vals[V];
+                    for (int l = 0; l < L; ++l) tile[(l * G + g) * PM + i] = b[l];
+                    T tv[E * K];
 #pragma unroll
-                        for (int l = 0; l < L; ++l)
+                    for (int q = 0; q < E * K; ++q) tv[q] = zero_of(T{});
 #pragma unroll
-                            for (int e = 0; e < E; ++e) vals[l * E + e] = mul(cj(b[l].v[e], cjf), xr[k]);
-                        int pos = 0, dup = 0;
-                        Butterfly<T, V, P>::run(vals, i, pos, dup);
-                        constexpr int CF = (V / P) > 1 ? (V / P) : 1;
-                        if ((i & dup) == 0) {
+                    for (int j = 0; j < L; ++j) {
+                        const Vec16<T> u = tile[sp * PM + rg * L + j];
 #pragma unroll
-                            for (int j = 0; j < CF; ++j) {
-                                const int q = pos + j;
-                                const int l = q / E, e = q % E;
-                                vs[(l * G + g) * E + e] = vals[j];
-                            }
+                        for (int e = 0; e < E; ++e) {
+                            const T bv = cj(u.v[e], cjf);
+#pragma unroll
+                            for (int k = 0; k < K; ++k) tv[e * K + k] = madd(tv[e * K + k], bv, xrr[j][k]);
                         }
+                    }
+                    int pos = 0, dup = 0;
+                    ReduceAbove<T, E * K, NS>::run(tv, lane, pos, dup);
+                    constexpr int CF = (E * K / RG) > 1 ? (E * K / RG) : 1;
+                    const int s = s0 + sp;  // the lane's strip of the piece
+                    if ((lane & dup) == 0 && s < nstrips) {
 #pragma unroll
-                        for (int q = 0; q < (NC + 63) / 64; ++q) {
-                            const int c = q * 64 + lane;
-                            const int w = s0 * E + c;
-                            bool off = false;
-                            const int yi = (c < NC && w < ncols) ? col_lookup(w, off) : 0;
-                            if (c < NC && w < ncols && (opT || off)) {
-                                T *yp = &y[yi + k * ldy];
-                                const T val = mul(alpha, vs[c]);
-                                if (flags & FLAG_RMW)
-                                    *yp = add(*yp, val);
-                                else
-                                    atomic_acc(yp, val);
+                        for (int jj = 0; jj < CF; ++jj) {
+                            const int q = pos + jj;
+                            const int e = q / K, k = q % K;
+                            const int w = s * E + e;
+                            if (w < ncols) {
+                                bool off = false;
+                                const int yi = col_lookup(w, off);
+                                if (opT || off) {
+                                    T *yp = &y[yi + k * ldy];
+                                    const T val = mul(alpha, tv[jj]);
+                                    if (flags & FLAG_RMW)
+                                        *yp = add(*yp, val);
+                                    else if (!BSM_DBG(DBG_NO_GLOBAL_ATOMICS))
+                                        atomic_acc(yp, val);
+                                }
                             }
                         }
                     }
@@ -823,9 +858,9 @@ __global__ void __launch_bounds__(64 * kWavesPerWg) __attribute__((amdgpu_waves_
                        T beta, int flags, unsigned wg_base) {
     constexpr int E = TT<T>::E;
     constexpr int XS = x_chunk_cols_multi<T, K>() * K;  // >= 64*K: also holds the combine slab
-    constexpr int VS = 8 * L * E;
+    constexpr int TILE = L * 72;  // 16-byte units: max over P of (64 / P) * L strips of P + 1 units
     __shared__ __attribute__((aligned(16))) T xs[kWavesPerWg][FWD ? XS : 1];
-    __shared__ __attribute__((aligned(16))) T vs[kWavesPerWg][TRN ? VS : 1];
+    __shared__ Vec16<T> tl[kWavesPerWg][TRN ? TILE : 1];
 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -838,13 +873,13 @@ __global__ void __launch_bounds__(64 * kWavesPerWg) __attribute__((amdgpu_waves_
     for (int k = 0; k < K; ++k) u[k] = zero_of(T{});
     if (work == WORK_PANEL) {
         if (m <= 8)
-            run_panel_multi<T, L, 8, FWD, TRN, K>(wd, values, rows, cols, x, ldx, y, ldy, alpha, flags, lane, xs[wave], vs[wave], u);
+            run_panel_multi<T, L, 8, FWD, TRN, K>(wd, values, rows, cols, x, ldx, y, ldy, alpha, flags, lane, xs[wave], tl[wave], u);
         else if (m <= 16)
-            run_panel_multi<T, L, 16, FWD, TRN, K>(wd, values, rows, cols, x, ldx, y, ldy, alpha, flags, lane, xs[wave], vs[wave], u);
+            run_panel_multi<T, L, 16, FWD, TRN, K>(wd, values, rows, cols, x, ldx, y, ldy, alpha, flags, lane, xs[wave], tl[wave], u);
         else if (m <= 32)
-            run_panel_multi<T, L, 32, FWD, TRN, K>(wd, values, rows, cols, x, ldx, y, ldy, alpha, flags, lane, xs[wave], vs[wave], u);
+            run_panel_multi<T, L, 32, FWD, TRN, K>(wd, values, rows, cols, x, ldx, y, ldy, alpha, flags, lane, xs[wave], tl[wave], u);
         else
-            run_panel_multi<T, L, 64, FWD, TRN, K>(wd, values, rows, cols, x, ldx, y, ldy, alpha, flags, lane, xs[wave], vs[wave], u);
+            run_panel_multi<T, L, 64, FWD, TRN, K>(wd, values, rows, cols, x, ldx, y, ldy, alpha, flags, lane, xs[wave], tl[wave], u);
     }
     const bool direct = (flags & FLAG_DIRECT) != 0;
     const bool sz = (flags & FLAG_STRONG_ZERO) != 0;
@@ -1075,6 +1110,9 @@ static hipError_t launch_typed_multi(const DeviceImage &img, bool opT, bool conj
     if (strong_zero) flags |= FLAG_STRONG_ZERO;
     if (conj) flags |= FLAG_CONJ;
     if (opT) flags |= FLAG_OPT;
+#ifdef BSM_EXPERIMENT
+    if (const char *v = std::getenv("BSM_DEBUG_FLAGS")) flags |= std::atoi(v) << 16;
+#endif
     const WaveWork *waves = (const WaveWork *)img.d_waves;
     const uint4 *values = (const uint4 *)img.d_values;
     const int *rows = (const int *)img.d_rows;

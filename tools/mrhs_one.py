@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""Developer probe for profilers: N launches of the K-right-hand-side product of one operator.
+usage: mrhs_one.py <case> <K> [launches]"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import numpy as np, torch, bsm_amd as bsm
+S = bsm.synthetic
+name, K = sys.argv[1], int(sys.argv[2])
+reps = int(sys.argv[3]) if len(sys.argv) > 3 else 10
+prob = {"c2": lambda: S.config2(on_device=True), "c3": lambda: S.config3(on_device=True),
+        "c2x20": lambda: S.config2(n=2_000_000, nblocks=100_000, on_device=True),
+        "c4s": lambda: S.config4(on_device=True, row_lo=0, row_hi=1953),
+        "c5s": lambda: S.config5(n=625_000, on_device=True)}[name]()
+A = S.build(prob)
+x = prob["x"]
+n = x.shape[0]
+if K == 1:
+    y = torch.zeros_like(x)
+    f = bsm.MulPlan(y, A, x)
+else:
+    X = torch.empty((K, n), dtype=x.dtype, device="cuda").t()
+    for k in range(K):
+        X[:, k] = x * (k + 1)
+    Y = torch.zeros((K, n), dtype=x.dtype, device="cuda").t()
+    f = lambda: bsm.mul(Y, A, X)
+for _ in range(reps):
+    f()
+torch.cuda.synchronize()
+print("done", name, K, A.stats()["alg_bytes"])
