@@ -864,8 +864,8 @@ extern "C" int bsm_part_info(bsm_matrix_t A, int32_t part, bsm_part_info_t *out)
 // another thread, or whose predecessor may still be running on ANOTHER stream (same stream: stream
 // order protects it), does not get the claim and its product takes the atomic path.  Nothing is
 // enqueued for the bookkeeping (an event recorded per product costs 3 us between two 9 us launches):
-// the previous stream is queried only when the stream changes.  Not tracked while the stream is
-// being captured into a graph: replays of one graph are ordered by the caller.
+// the previous stream is queried only when the stream changes.  A product enqueued while the stream is
+// being captured into a graph never gets the claim (atomic path): a replay could meet an eager product.
 struct WorkspaceClaim {
     bsm_matrix_s *A;
     hipStream_t st;
@@ -875,17 +875,20 @@ struct WorkspaceClaim {
         : A(A_), st(st_), lock(A_->gather_mu, std::defer_lock) {
         held = img.d_ws != nullptr && lock.try_lock();
         if (!held) return;
-        if (A->ws_pending && A->ws_stream == st) {  // the common case: one stream, nothing to ask
-            track = true;
-            return;
-        }
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
         if (hipStreamIsCapturing(st, &cs) != hipSuccess) {
             (void)hipGetLastError();
             cs = hipStreamCaptureStatusNone;
         }
-        track = (cs == hipStreamCaptureStatusNone);
-        if (track && A->ws_pending) {  // the stream changed: is the previous one idle?
+        if (cs != hipStreamCaptureStatusNone) {
+            // a captured product would use the workspace at every replay, on whatever stream, beside eager
+            // products nobody can order against: captured products take the atomic path
+            held = track = false;
+            return;
+        }
+        track = true;
+        if (A->ws_pending && A->ws_stream == st) return;  // the common case: one stream, nothing to ask
+        if (A->ws_pending) {  // the stream changed: is the previous one idle?
             const hipError_t q = hipStreamQuery(A->ws_stream);
             if (q != hipSuccess) {
                 (void)hipGetLastError();  // hipErrorNotReady is not a failure

@@ -681,7 +681,6 @@ __device__ __forceinline__ void run_panel_multi(const WaveD &wd, const uint4 *__
                                                 int flags, int lane, T *xs, Vec16<T> *tile, T (&out)[K]) {
     constexpr int E = TT<T>::E;
     constexpr int G = 64 / P;
-    constexpr int V = L * E;
     constexpr int NC = G * L * E;
     constexpr int XCH = x_chunk_cols_multi<T, K>();
     static_assert(XCH % NC == 0, "x chunk must hold whole iterations");
@@ -856,7 +855,6 @@ __global__ void __launch_bounds__(64 * kWavesPerWg) __attribute__((amdgpu_waves_
                        const int *__restrict__ rows, const int *__restrict__ cols,
                        const T *__restrict__ x, long long ldx, T *__restrict__ y, long long ldy, T alpha,
                        T beta, int flags, unsigned wg_base) {
-    constexpr int E = TT<T>::E;
     constexpr int XS = x_chunk_cols_multi<T, K>() * K;  // >= 64*K: also holds the combine slab
     constexpr int TILE = L * 72;  // 16-byte units: max over P of (64 / P) * L strips of P + 1 units
     __shared__ __attribute__((aligned(16))) T xs[kWavesPerWg][FWD ? XS : 1];

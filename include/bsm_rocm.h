@@ -227,7 +227,10 @@ int bsm_symmetric_create(int dtype, int64_t nrows, int64_t ncols, int64_t ndiag,
  *     not propagate.  With beta_strong_zero == 0 a numeric beta = 0 multiplies.
  *   memspace BSM_MEM_DEVICE: x, y are device pointers valid on the handle's device; the
  *     call only enqueues work on `stream` (a hipStream_t, NULL = default stream) and
- *     returns; no allocation or synchronisation happens, so it can be graph-captured.
+ *     returns; no allocation or synchronisation happens, so it can be graph-captured (single-device handles
+ *     only: a multi-device handle issues on several streams and devices and must not be captured; a
+ *     BSM_ACC_GATHER handle takes its atomic path while the stream is capturing -- the workspace of the
+ *     gather path admits one product in flight, which a replayed graph could not promise).
  *   memspace BSM_MEM_HOST: x, y are host arrays; the library stages them through device
  *     buffers and returns when y is complete.
  * x has size(op(A),2) entries, y size(op(A),1); they must not alias. */

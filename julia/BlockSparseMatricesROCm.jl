@@ -175,6 +175,13 @@ function LinearMaps._unsafe_mul!(y::Vector{T}, A::ROCmOp{Z}, x::Vector{T}, α::N
     return _fallback_mul!(y, A, x, α, β)
 end
 
+# The 3-argument form.  The reference defines its own for the VBCRS wrappers (src/vbcrs.jl:331-341:
+# `fill!(y, zero(T))`, then the 5-argument method with β = true) -- for a ROCmScheduler that would zero y on
+# the host, upload it and add: forward Julia's strong zero instead (y never travels to the device).
+function LinearMaps._unsafe_mul!(y::AbstractVector, A::ROCmOp{Z}, x::AbstractVector) where {Z<:ROCmMat}
+    return LinearMaps._unsafe_mul!(y, A, x, true, false)
+end
+
 # everything else LinearMaps may hand over -- SubArray columns of `A * X`, strided views, other
 # element types, complex α / β on a real matrix: by linearity through contiguous Vector{T} temporaries.
 # NEVER the reference's own loop: its `@tasks ... @set scheduler = ...` cannot run a ROCmScheduler.
@@ -185,6 +192,7 @@ end
 
 function _fallback_mul!(y, A, x, α, β)
     T = eltype(_base(A))
+    # (one result temporary per product; `convert` copies x only when it is not already a Vector{T})
     gpu(v) = _mul!(Vector{T}(undef, size(A, 1)), A, convert(Vector{T}, v), one(T), zero(T), true, 0, C_NULL, T)
     t = (T <: Real && eltype(x) <: Complex) ? complex.(gpu(real.(x)), gpu(imag.(x))) : gpu(x)
     if β === false
@@ -233,6 +241,26 @@ if Base.find_package("AMDGPU") !== nothing
                 throw(ArgumentError("device vectors must have the matrix' element type; α, β convertible to it"))
             st = Base.unsafe_convert(Ptr{Cvoid}, AMDGPU.stream().stream)
             return _mul!(y, A, x, T(α), T(β === false ? 0 : β), β === false, 1, st, T)
+        end
+
+        """
+            mul_parts!(yparts, A, xparts, α=true, β=false)
+
+        `mul!` for a matrix spread over several GPUs (`ROCmScheduler(devices=[...])`) with x and y PARTITIONED
+        like its block rows: `xparts[p]` / `yparts[p]` are `ROCVector`s on device `devices[p]` holding the
+        entries of part p's column / row range (`part_ranges(A)`).  Only the halo a part reads beyond its own
+        slice and the y segments it produced for rows of another device travel (bsm_mul_parts, xGMI).
+        """
+        function mul_parts!(yparts::Vector{<:AMDGPU.ROCVector{T}}, A::ROCmOp{Z}, xparts::Vector{<:AMDGPU.ROCVector{T}},
+                α::Number=true, β::Number=false) where {T<:ROCmEltype,Z<:ROCmMat}
+            h = handle(_base(A))
+            xp = Ptr{Cvoid}[Base.unsafe_convert(Ptr{Cvoid}, pointer(v)) for v in xparts]
+            yp = Ptr{Cvoid}[Base.unsafe_convert(Ptr{Cvoid}, pointer(v)) for v in yparts]
+            a = Ref(T(α)); b = Ref(T(β === false ? 0 : β))
+            GC.@preserve xparts yparts _check(ccall((:bsm_mul_parts, libbsm), Cint,
+                (Ptr{Cvoid}, Cint, Ptr{Ptr{Cvoid}}, Ptr{Ptr{Cvoid}}, Ref{T}, Ref{T}, Cint, Ptr{Ptr{Cvoid}}),
+                h.ptr, _op(A), xp, yp, a, b, β === false, C_NULL))   # NULL streams: every device's default stream
+            return yparts
         end
     end
 end

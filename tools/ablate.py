@@ -10,20 +10,28 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch, bsm_amd as bsm
 from _common import fixture_problem
-K = int(sys.argv[1]) if len(sys.argv) > 1 else 400
-real = len(sys.argv) > 2 and sys.argv[2] == "f64"
 rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 3
-p = fixture_problem("cuboid", np.float64 if real else np.complex128, "real" if real else "full")
-n0 = p["size"][0]
-tile = lambda lists: [l + k * n0 for k in range(K) for l in lists]
-prob = dict(kind="symmetric", diagonals=p["diagonals"] * K, diagonalindices=tile(p["diagonalindices"]),
-            offdiagonals=p["offdiagonals"] * K, rowindices=tile(p["rowindices"]), colindices=tile(p["colindices"]),
-            size=(n0 * K, n0 * K))
-dt = p["diagonals"][0].dtype
-xh = np.random.default_rng(0).standard_normal(n0 * K).astype(dt)
-A = bsm.synthetic.build(prob)
-st = A.stats()
-x = torch.from_numpy(xh).cuda()
+if len(sys.argv) > 1 and not sys.argv[1].isdigit():  # a synthetic configuration instead of the tiled fixture
+    S = bsm.synthetic
+    prob = {"c3": lambda: S.config3(on_device=True), "c5s": lambda: S.config5(n=625_000, on_device=True)}[sys.argv[1]]()
+    K, dt = sys.argv[1], np.dtype(np.float64)
+    A = S.build(prob)
+    st = A.stats()
+    x = prob["x"]
+else:
+    K = int(sys.argv[1]) if len(sys.argv) > 1 else 400
+    real = len(sys.argv) > 2 and sys.argv[2] == "f64"
+    p = fixture_problem("cuboid", np.float64 if real else np.complex128, "real" if real else "full")
+    n0 = p["size"][0]
+    tile = lambda lists: [l + k * n0 for k in range(K) for l in lists]
+    prob = dict(kind="symmetric", diagonals=p["diagonals"] * K, diagonalindices=tile(p["diagonalindices"]),
+                offdiagonals=p["offdiagonals"] * K, rowindices=tile(p["rowindices"]), colindices=tile(p["colindices"]),
+                size=(n0 * K, n0 * K))
+    dt = p["diagonals"][0].dtype
+    xh = np.random.default_rng(0).standard_normal(n0 * K).astype(dt)
+    A = bsm.synthetic.build(prob)
+    st = A.stats()
+    x = torch.from_numpy(xh).cuda()
 y = torch.zeros_like(x)
 plan = bsm.MulPlan(y, A, x)
 VARIANTS = [("full kernel", 0), ("no global atomics", 1), ("no window adds", 2), ("no atomics, no window adds", 3),
@@ -43,7 +51,7 @@ for r in range(rounds):
         b.record()
         torch.cuda.synchronize()
         res[name].append(a.elapsed_time(b) * 1e3 / 20)
-print(f"tiled BEM fixture x{K} ({dt}), {st['alg_bytes']/1e6:.0f} MB algorithmic, {st['nworkgroups']} workgroups; us per launch (median of {rounds} interleaved rounds, min)")
+print(f"operator {K} ({dt}), {st['alg_bytes']/1e6:.0f} MB algorithmic, {st['nworkgroups']} workgroups; us per launch (median of {rounds} interleaved rounds, min)")
 for name, _ in VARIANTS:
     v = sorted(res[name])
     print(f"  {name:55s} {v[len(v)//2]:7.1f}  {v[0]:7.1f}   {st['alg_bytes']/v[len(v)//2]/1e3:6.0f} GB/s")
