@@ -149,3 +149,29 @@ def test_row_partitioned_with_the_hip_local_product(kind, world):
     assert status == "ok", errs
     assert all(e < 1e-12 for e in errs), errs
     assert all(p.exitcode == 0 for p in procs)
+
+
+def test_bench_launches_its_own_ranks_and_reports_parity():
+    """`python bench.py --gpus 2` as the driver invokes it (no torch.distributed.run in front): the script starts
+    its own rank processes, runs the overlapped C5 step + C4 in `extra` (gloo rehearsal: both ranks on cuda:0,
+    operators shrunk) and prints ONE line with the parity number, the exchange time and the ranks it saw."""
+    import json
+    import subprocess
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--device", "0",
+                        "--scale", "0.02", "--steps", "4", "--warmup", "2"], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["dtype"] == "f64"
+    c = d["config"]
+    assert c["ranks"] == 2 and c["overlap"] is True and len(c["devices"]) == 2
+    assert c["parity_relerr"] <= 1e-12 and "exchange_us" in c and c["local_kernel_us_max"] > 0
+    assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1
+    c4 = d["extra"]["c4"]
+    assert c4["parity_relerr"] <= 2e-5 and c4["overlap"] is True
+    assert "value_invalid" not in d
