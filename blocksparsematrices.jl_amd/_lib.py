@@ -118,15 +118,17 @@ def lib():
     L.bsm_synth_blocks.argtypes = [C.c_int, C.c_uint64, C.c_int64, _I64P, _I64P, _I64P, _I32P, _PP, C.c_void_p]
     L.bsm_synth_vector.argtypes = [C.c_int, C.c_uint64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]
     L.bsm_synth_blocks.restype = L.bsm_synth_vector.restype = C.c_int
-    L.bsm_bench_stream.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
-    L.bsm_bench_stream.restype = C.c_int
+    if hasattr(L, "bsm_bench_stream") or "BSM_LIB" not in os.environ:  # (developer A/B builds may predate it)
+        L.bsm_bench_stream.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
+        L.bsm_bench_stream.restype = C.c_int
     L.bsm_mul.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                           C.c_int, C.c_int, C.c_void_p]
     L.bsm_mul_multi.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,
                                 C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     L.bsm_mul_multi.restype = C.c_int
-    L.bsm_mul_parts.argtypes = [C.c_void_p, C.c_int, _PP, _PP, C.c_void_p, C.c_void_p, C.c_int, _PP]
-    L.bsm_mul_parts.restype = C.c_int
+    if hasattr(L, "bsm_mul_parts") or "BSM_LIB" not in os.environ:
+        L.bsm_mul_parts.argtypes = [C.c_void_p, C.c_int, _PP, _PP, C.c_void_p, C.c_void_p, C.c_int, _PP]
+        L.bsm_mul_parts.restype = C.c_int
     L.bsm_get_bookkeeping.argtypes = [C.c_void_p, C.c_int, _I64P, _I64P]
     L.bsm_get_image.argtypes = [C.c_void_p, C.c_int, C.c_void_p, _I64P]
     L.bsm_color.argtypes = [C.c_int64, _PP, _I64P, C.c_int, _I64P, _I64P]

@@ -34,7 +34,11 @@ def bem(K, dtype, part):
     prob = dict(kind="symmetric", diagonals=p["diagonals"] * K, diagonalindices=tile(p["diagonalindices"]),
                 offdiagonals=p["offdiagonals"] * K, rowindices=tile(p["rowindices"]), colindices=tile(p["colindices"]),
                 size=(n0 * K, n0 * K))
-    prob["x"] = torch.from_numpy(np.random.default_rng(0).standard_normal(n0 * K).astype(dtype)).cuda()
+    rng = np.random.default_rng(0)
+    xh = rng.standard_normal(n0 * K)
+    if np.dtype(dtype).kind == "c":  # a FULL complex x: zero imaginary parts run 5-8 % faster (less switching, higher clock)
+        xh = xh + 1j * rng.standard_normal(n0 * K)
+    prob["x"] = torch.from_numpy(xh.astype(dtype)).cuda()
     return prob
 
 
