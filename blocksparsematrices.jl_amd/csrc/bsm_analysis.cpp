@@ -29,7 +29,6 @@ Tunables Tunables::from_env() {
     if (const char *f = std::getenv("BSM_FAT_FILL_BELOW")) t.fat_fill_below = std::atof(f);
     t.pack_threads = (int)geti("BSM_PACK_THREADS", t.pack_threads);
     t.wg_order = (int)geti("BSM_ORDER", t.wg_order);
-    t.balance_run = (int)geti("BSM_BALANCE_RUN", t.balance_run);
     t.deep_group_bytes = geti("BSM_DEEP_GROUP_BYTES", t.deep_group_bytes);
     t.deep_total_bytes = geti("BSM_DEEP_TOTAL_BYTES", t.deep_total_bytes);
     t.window_bytes = (size_t)geti("BSM_UPLOAD_WINDOW_BYTES", (int64_t)t.window_bytes);
@@ -771,7 +770,6 @@ void Analysis::stage_work_items(BuildState &st) {
                 W = std::min(tun.wave_bytes_max, (int64_t)val_units * 16 / tun.target_waves);
                 if (4 * W < 5 * tun.wave_bytes_min) W = tun.wave_bytes_min;  // not long enough to pay
             }
-            fat_waves = W > tun.wave_bytes_min;
             if (W > tun.wave_bytes_min) {
                 // fat waves: a row group gets a second wave only from 2 W on and never four -- every
                 // extra wave of a group is another fixed chain plus a workgroup barrier (tiled BEM
@@ -818,23 +816,6 @@ void Analysis::stage_work_items(BuildState &st) {
         if (use_window && a.nw < 4) return locality(a) < locality(b);
         return a.bytes > b.bytes;
     });
-    // A workgroup keeps its slot until its SLOWEST wave is done.  Locality order puts waves of very
-    // different sizes side by side (BEM leaves: 3-28 rows, 10-140 columns); inside every run of
-    // `balance_run` neighbouring one-wave items the items are therefore re-ordered by size, so that the
-    // four waves of a workgroup are neighbours AND of similar length.
-    if (use_window && tun.balance_run > 1) {
-        size_t a = 0;
-        while (a < items.size()) {
-            if (items[a].nw != 1) {
-                a++;
-                continue;
-            }
-            size_t b = a;
-            while (b < items.size() && items[b].nw == 1 && items[b].color == items[a].color && b - a < (size_t)tun.balance_run) b++;
-            std::stable_sort(items.begin() + a, items.begin() + b, [](const Item &x, const Item &y) { return x.bytes > y.bytes; });
-            a = b;
-        }
-    }
 }
 
 // ---- value stream layout: the panels lie in the order in which the launch reaches them --------------------

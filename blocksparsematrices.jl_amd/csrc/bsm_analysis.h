@@ -81,7 +81,6 @@ struct Tunables {
     int pack_threads = 8;
     size_t window_bytes = 64u << 20;  // staging window of a streamed upload (BSM_UPLOAD_WINDOW_BYTES)
     int lds_window = 1;  // LDS y window for locality-packed small symmetric row groups
-    int balance_run = 0;  // locality-ordered one-wave items: re-order runs of this many by size (BSM_BALANCE_RUN; 0: off)
     int wg_order = -1;  // workgroup dispatch order (BSM_ORDER): -1 auto (snake for exclusive images), 0 plain largest first
     static Tunables from_env();
 };
@@ -163,7 +162,6 @@ class Analysis {
     int64_t nwg_total = 0;  // + workgroups of scale work (exclusive forward launch only)
     int64_t ngroups = 0;
     bool exclusive_fwd = false;  // every y row is produced by at most one row group
-    bool fat_waves = false;      // the operator got more than wave_bytes_min per wave (see Tunables::wave_bytes)
     // coloured mode: workgroups [color_wg_ptr[c], color_wg_ptr[c+1]) form launch c; the row groups
     // of one launch touch pairwise disjoint y entries (rows and columns), for every op
     std::vector<int64_t> color_wg_ptr;

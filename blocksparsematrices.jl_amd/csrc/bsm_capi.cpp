@@ -234,7 +234,6 @@ void fill_image(const Analysis &an, const bsm_options &o, bool use_own, DeviceIm
     img.nwg_total = an.nwg_total;
     img.exclusive_fwd = an.exclusive_fwd && (o.accumulate == BSM_ACC_AUTO || o.accumulate == BSM_ACC_DIRECT);
     img.has_off = false;
-    img.fat_waves = an.fat_waves;
     for (const WaveWork &w : an.waves)
         if (w.work == WORK_PANEL && w.npieces > 0 && (w.first.kind & kKindHasOff)) img.has_off = true;
     if (!img.exclusive_fwd) img.nwg_total = img.nwg_main;

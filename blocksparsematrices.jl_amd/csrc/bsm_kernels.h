@@ -17,7 +17,6 @@ struct DeviceImage {
     long long nwg_main = 0, nwg_total = 0;
     bool exclusive_fwd = false;
     bool has_off = false;  // SymmetricBlockMatrix off-diagonal pieces present
-    bool fat_waves = false;  // long launch of row groups that do not fill their lanes (Tunables::wave_bytes)
     long long device_bytes = 0;
     long long value_bytes = 0;  // packed matrix bytes (decides the cache policy of the matrix loads)
     std::vector<long long> color_wg_ptr;  // non-empty: coloured launches, plain read-modify-write
