@@ -552,7 +552,11 @@ static int dist_mul_fused(DistState &D, int op, int K, const std::vector<VecSour
     // no delivery launch.
     std::vector<char> direct((size_t)P, 0);
     for (int p = 0; p < P; p++) {
-        bool alone = D.parts[p]->has_image && pl.zr[p].lo == pl.out[p].lo && pl.zr[p].hi == pl.out[p].hi;
+        // (only into y on the part's OWN device: accumulate-mode images add with hardware fp atomics, which are
+        // not relied upon across xGMI; a remote y receives plain stores from the finish kernel instead)
+        const VecDest &yd = dst[dst.size() == 1 ? 0 : (size_t)p];
+        bool alone = D.parts[p]->has_image && yd.device == D.parts[p]->device && pl.zr[p].lo == pl.out[p].lo &&
+                     pl.zr[p].hi == pl.out[p].hi;
         for (const Transfer &t : pl.transfers) alone = alone && t.from != p && t.to != p;
         direct[p] = alone;
     }
