@@ -914,6 +914,14 @@ static int dist_mul_k(bsm_matrix_s *A, int op, int K, const void *x, long long l
                       const void *alpha, const void *beta, int beta_strong_zero, int memspace, hipStream_t stream) {
     DistState &D = *A->dist;
     std::lock_guard<std::mutex> lock(D.mu);  // one product of a handle is ISSUED at a time (the work vectors are the handle's)
+    if (memspace == BSM_MEM_DEVICE && stream) {
+        // a multi-device product issues on several streams and devices and waits for events of earlier products:
+        // it cannot be recorded into the caller's graph (include/bsm_rocm.h) -- refuse instead of corrupting the capture
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(stream, &cs) != hipSuccess) (void)hipGetLastError();
+        if (cs != hipStreamCaptureStatusNone)
+            return fail(BSM_ERR_UNSUPPORTED, "a multi-device handle cannot be captured into a graph");
+    }
     if (memspace == BSM_MEM_DEVICE && D.all_peer) {
         int cur = 0;
         hipError_t e = hipGetDevice(&cur);

@@ -410,3 +410,33 @@ def test_unequal_parts_driven_from_two_streams(torch_cuda, bsm, oracle):
     for k in range(2):
         for yd in outs[k]:
             assert relerr(yd.cpu().numpy(), refs[k]) < 1e-12
+
+
+def test_multi_device_products_refuse_graph_capture(torch_cuda, bsm):
+    """a product of a multi-device handle issues on several streams and waits for events of earlier
+    products -- it must not be recorded into a graph; bsm_mul says so instead of corrupting the capture."""
+    torch = torch_cuda
+    prob = bsm.synthetic.config2(n=6000, nblocks=200)
+    A = bsm.synthetic.build(prob, devices=[0, 0])
+    x = torch.from_numpy(prob["x"]).cuda()
+    y = torch.zeros_like(x)
+    plan = bsm.MulPlan(y, A, x)
+    plan()
+    torch.cuda.synchronize()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    raised = False
+    with torch.cuda.stream(s):
+        g = torch.cuda.CUDAGraph()
+        try:
+            with torch.cuda.graph(g, stream=s):
+                try:
+                    plan()
+                except RuntimeError as e:
+                    raised = "cannot be captured" in str(e)
+        except Exception:
+            pass  # an empty capture may fail to instantiate on some runtimes: irrelevant here
+    torch.cuda.synchronize()
+    assert raised
+    plan()  # the handle is still usable
+    torch.cuda.synchronize()
