@@ -560,8 +560,9 @@ static int dist_mul_fused(DistState &D, int op, int K, const std::vector<VecSour
         for (const Transfer &t : pl.transfers) alone = alone && t.from != p && t.to != p;
         direct[p] = alone;
     }
-    auto wait_for = [&](int p, hipEvent_t ev, hipStream_t recorded_on) -> hipError_t {
-        if (recorded_on == run[p]) return hipSuccess;  // same stream: already ordered
+    // (a NULL stream is a different stream on every device: "same stream" needs the same device too)
+    auto wait_for = [&](int p, hipEvent_t ev, hipStream_t recorded_on, int recorded_dev) -> hipError_t {
+        if (recorded_on == run[p] && recorded_dev == D.parts[p]->device) return hipSuccess;  // same stream: already ordered
         return hipStreamWaitEvent(run[p], ev, 0);
     };
     // phase 0 (part p): wait for its inputs, gather the x pieces it reads (one launch), local product
@@ -584,7 +585,7 @@ static int dist_mul_fused(DistState &D, int op, int K, const std::vector<VecSour
                 DCHECK(hipStreamWaitEvent(st, pt.ev_done, 0), "hipStreamWaitEvent");  // its own previous delivery (another stream, perhaps)
                 if (D.ev_tail) DCHECK(hipStreamWaitEvent(st, D.ev_tail, 0), "hipStreamWaitEvent");
             }
-            DCHECK(wait_for(p, yd.ready, yd.stream), "hipStreamWaitEvent");  // the incoming y (numeric beta) / its buffer
+            DCHECK(wait_for(p, yd.ready, yd.stream, yd.device), "hipStreamWaitEvent");  // the incoming y (numeric beta) / its buffer
             const Range zr = pl.zr[p];
             if (pt.has_image) {
                 const Range xr = pl.xr[p];
@@ -596,7 +597,7 @@ static int dist_mul_fused(DistState &D, int op, int K, const std::vector<VecSour
                 for (const VecSource &s : src) {
                     const Range o = isect(s.valid, xr);
                     if (o.empty()) continue;
-                    DCHECK(wait_for(p, s.ready, s.stream), "hipStreamWaitEvent");
+                    DCHECK(wait_for(p, s.ready, s.stream, s.device), "hipStreamWaitEvent");
                     if (o.lo == xr.lo && o.hi == xr.hi && s.device == pt.device) {  // everything it reads lies on its own device
                         xp = s.base;
                         xld = s.strided ? ldx : 0;
@@ -636,7 +637,7 @@ static int dist_mul_fused(DistState &D, int op, int K, const std::vector<VecSour
         for (const Transfer &t : pl.transfers) {
             if (t.to != p) continue;
             Part &from = *D.parts[t.from];
-            DCHECK(wait_for(p, from.ev_prod, run[(size_t)t.from]), "hipStreamWaitEvent");
+            DCHECK(wait_for(p, from.ev_prod, run[(size_t)t.from], from.device), "hipStreamWaitEvent");
             if (np == kMaxVecPieces) {  // more peers than one launch takes: fold these into the work vector first
                 DCHECK(launch_vec_finish(D.dtype, nullptr, 0, pt.d_w, (long long)vlen, pc, np, o.lo, o.hi, nullptr, 1, 1, K, st), "halo add");
                 np = 0;
@@ -665,7 +666,7 @@ static int dist_mul_fused(DistState &D, int op, int K, const std::vector<VecSour
     // the consumers of y continue when the parts that deliver to them are done
     for (int q = 0; q < P; q++) {
         const VecDest &yd = dst[dst.size() == 1 ? 0 : (size_t)q];
-        if (yd.stream == run[(size_t)q]) continue;  // delivered on the consumer's own stream
+        if (yd.stream == run[(size_t)q] && yd.device == D.parts[q]->device) continue;  // delivered on the consumer's own stream
         DeviceGuard g;
         DCHECK(g.enter(yd.device), "hipSetDevice");
         DCHECK(hipStreamWaitEvent(yd.stream, D.parts[q]->ev_done, 0), "hipStreamWaitEvent");
