@@ -440,3 +440,26 @@ def test_multi_device_products_refuse_graph_capture(torch_cuda, bsm):
     assert raised
     plan()  # the handle is still usable
     torch.cuda.synchronize()
+
+
+def test_partitioned_vectors_fp32_and_device_resident_blocks(torch_cuda, bsm, oracle):
+    """bsm_mul_parts with fp32 elements and with blocks that already live in HBM (repacked by the pack kernel on every
+    part's device): C4-shaped VBCRS over three parts, op N and T, against the oracle."""
+    torch = torch_cuda
+    prob = bsm.synthetic.config4(ngrid=24, bs=64, per_row=5)
+    dev = dict(prob)
+    dev["blocks"] = [torch.from_numpy(np.ascontiguousarray(b.T)).cuda().t() for b in prob["blocks"]]
+    n = prob["size"][0]
+    x = prob["x"]
+    for p in (prob, dev):
+        A = bsm.synthetic.build(p, devices=[0, 0, 0])
+        parts = A.parts()
+        rows, cols = [q["own"] for q in parts], [q["cols"] for q in parts]
+        for op in (N, T):
+            ref = oracle_mul(oracle, prob, op, x, np.zeros(n, dtype=np.float32))
+            xp, yp = _scatter(torch, x, cols if op == N else rows), [torch.full((hi - lo + 1,), float("nan"), dtype=torch.float32, device="cuda")
+                                                                      for lo, hi in (rows if op == N else cols)]
+            bsm.mul_parts(yp, wrap(bsm, A, op), xp)
+            torch.cuda.synchronize()
+            got = np.concatenate([t.cpu().numpy() for t in yp])
+            assert relerr(got, ref) < 2e-5, op
