@@ -36,3 +36,20 @@ def test_c_demo_products_on_gpu(tmp_path, bsm):
     assert "SymmetricBlockMatrix KAT y = [11 14 1 2]" in out.stdout
     assert "two-device SymmetricBlockMatrix KAT y = [11 14 1 2]" in out.stdout
     assert "rowcolvals: 5 triples" in out.stdout
+
+
+@pytest.mark.gpu
+def test_partitioned_vectors_from_compiled_code(tmp_path, bsm):
+    """examples/parts_demo.cpp: bsm_mul_parts with raw hipMalloc'ed vector parts on a context of two (virtual) devices,
+    the y parts of one product as the x parts of the next -- compiled with hipcc against the C ABI only."""
+    from bsm_amd import _lib
+    _lib.lib()
+    exe = str(tmp_path / "parts_demo")
+    libdir = os.path.join(ROOT, "blocksparsematrices.jl_amd")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O1", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "parts_demo.cpp"), "-L", libdir, "-lbsmrocm",
+                           f"-Wl,-rpath,{libdir}", "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr + out.stdout
+    assert "partitioned SymmetricBlockMatrix KAT y = [11 14 1 2], A*y = [5 98 11 22]" in out.stdout
+    assert out.stdout.strip().endswith("OK")
