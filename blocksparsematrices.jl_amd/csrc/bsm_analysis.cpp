@@ -25,6 +25,7 @@ Tunables Tunables::from_env() {
     t.split4_bytes = geti("BSM_SPLIT4_BYTES", t.split4_bytes);
     t.wgitem_max_bytes = geti("BSM_WGITEM_MAX_BYTES", t.wgitem_max_bytes);
     t.wave_bytes = geti("BSM_WAVE_BYTES", t.wave_bytes);
+    t.multi_wave_bytes = geti("BSM_MULTI_WAVE_BYTES", t.multi_wave_bytes);
     t.target_waves = std::max<int64_t>(1, geti("BSM_TARGET_WAVES", t.target_waves));
     if (const char *f = std::getenv("BSM_FAT_FILL_BELOW")) t.fat_fill_below = std::atof(f);
     t.pack_threads = (int)geti("BSM_PACK_THREADS", t.pack_threads);
@@ -961,23 +962,20 @@ void Analysis::stage_waves(BuildState &st) {
     const int64_t own_lo = st.own_lo, own_hi = st.own_hi;
 
     waves.clear();
+    std::vector<WaveWork> *nop_out = &waves;
     auto emit_nop = [&]() {
         WaveWork w;
         std::memset(&w, 0, sizeof w);
         w.work = WORK_NOP;
         w.grp = 1;
         w.rbase = -1;
-        waves.push_back(w);
+        nop_out->push_back(w);
     };
     color_wg_ptr.clear();
     int32_t cur_color = -1;
-    for (const Item &it : items) {
-        if (colored && it.color != cur_color) {  // a colour class starts on a workgroup boundary
-            while (waves.size() % kWavesPerWg) emit_nop();
-            while ((int32_t)color_wg_ptr.size() <= it.color)
-                color_wg_ptr.push_back((int64_t)waves.size() / kWavesPerWg);
-            cur_color = it.color;
-        }
+    std::vector<WaveWork> *out = &waves;  // the list item_waves() appends to
+    auto item_waves = [&](const Item &it) {
+        std::vector<WaveWork> &waves = *out;
         // align the start of a multi-wave item to its group size inside the workgroup
         while ((int)(waves.size() % kWavesPerWg) % it.nw != 0) emit_nop();
         const Group &G = groups[it.group];
@@ -1040,6 +1038,15 @@ void Analysis::stage_waves(BuildState &st) {
             }
             waves.push_back(W);
         }
+    };
+    for (const Item &it : items) {
+        if (colored && it.color != cur_color) {  // a colour class starts on a workgroup boundary
+            while (waves.size() % kWavesPerWg) emit_nop();
+            while ((int32_t)color_wg_ptr.size() <= it.color)
+                color_wg_ptr.push_back((int64_t)waves.size() / kWavesPerWg);
+            cur_color = it.color;
+        }
+        item_waves(it);
     }
     while (waves.size() % kWavesPerWg) emit_nop();
     nwg_main = (int64_t)waves.size() / kWavesPerWg;
@@ -1087,10 +1094,56 @@ void Analysis::stage_waves(BuildState &st) {
         while (waves.size() % kWavesPerWg) emit_nop();
     }
     nwg_total = (int64_t)waves.size() / kWavesPerWg;
-    for (size_t wg = 0; wg + kWavesPerWg <= waves.size(); wg += kWavesPerWg) {
-        uint8_t sync = 0;
-        for (int w = 0; w < kWavesPerWg; w++) sync |= (waves[wg + w].work == WORK_PANEL && waves[wg + w].grp > 1);
-        for (int w = 0; w < kWavesPerWg; w++) waves[wg + w].wg_sync = sync;
+    auto mark_sync = [](std::vector<WaveWork> &ws) {
+        for (size_t wg = 0; wg + kWavesPerWg <= ws.size(); wg += kWavesPerWg) {
+            uint8_t sync = 0;
+            for (int w = 0; w < kWavesPerWg; w++) sync |= (ws[wg + w].work == WORK_PANEL && ws[wg + w].grp > 1);
+            for (int w = 0; w < kWavesPerWg; w++) ws[wg + w].wg_sync = sync;
+        }
+    };
+    mark_sync(waves);
+
+    // ---- the coarser split for multi-RHS products (Tunables::multi_wave_bytes) -------------
+    // Same panels, same value stream, same order (the row groups in the order their panels lie in the
+    // stream), cut with W = multi_wave_bytes: items of at most 4 W, 2 waves from W on, 4 from 3 W on.
+    // Only for launches that accumulate with atomics (no colour classes, no gather slots, no scale work).
+    waves_multi.clear();
+    nwg_multi = 0;
+    if (tun.multi_wave_bytes > 0 && !exclusive_fwd && !colored && !gather) {
+        const int64_t Wm = tun.multi_wave_bytes;
+        std::vector<Item> mi;
+        for (int64_t g : st.layout) {
+            const Group &G = groups[g];
+            if (G.strips <= 0) continue;
+            const int64_t strip_bytes = (int64_t)G.mc * 16;
+            const int64_t maxs = std::max<int64_t>(1, 4 * Wm / strip_bytes);
+            const int64_t nitem = (G.strips + maxs - 1) / maxs;
+            const int64_t per_item = (G.strips + nitem - 1) / nitem;
+            for (int64_t s = 0; s < G.strips; s += per_item) {
+                Item it;
+                it.group = g;
+                it.s_begin = s;
+                it.s_end = std::min(G.strips, s + per_item);
+                it.bytes = (it.s_end - it.s_begin) * strip_bytes;
+                it.nw = it.bytes >= 3 * Wm ? 4 : (it.bytes >= Wm ? 2 : 1);
+                it.color = 0;
+                mi.push_back(it);
+            }
+        }
+        std::stable_sort(mi.begin(), mi.end(), [](const Item &a, const Item &b) { return a.nw > b.nw; });
+        out = nop_out = &waves_multi;
+        for (const Item &it : mi) item_waves(it);
+        while (waves_multi.size() % kWavesPerWg) emit_nop();
+        out = nop_out = &waves;
+        size_t panel_main = 0, panel_multi = 0;
+        for (const WaveWork &w : waves) panel_main += w.work == WORK_PANEL;
+        for (const WaveWork &w : waves_multi) panel_multi += w.work == WORK_PANEL;
+        if (4 * panel_multi > 3 * panel_main) {
+            waves_multi.clear();  // (nearly) the same split: one list serves both
+        } else {
+            mark_sync(waves_multi);
+            nwg_multi = (int64_t)waves_multi.size() / kWavesPerWg;
+        }
     }
     if (rows.empty()) rows.push_back(0);
     if (cols.empty()) cols.push_back(0);

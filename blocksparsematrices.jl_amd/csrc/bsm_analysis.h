@@ -72,6 +72,12 @@ struct Tunables {
     int64_t target_waves = 32768;        // BSM_TARGET_WAVES
     double fat_fill_below = 0.9;         // BSM_FAT_FILL_BELOW
     int64_t wave_bytes_min = 8 << 10, wave_bytes_max = 24 << 10;
+    // Multi-RHS products (bsm_mul_multi) walk a SECOND, coarser split of the same panels (Analysis::waves_multi):
+    // with K right-hand sides a wave's fixed part -- K x rows kept in registers, K-wide x slices, K-wide output
+    // and combine -- is K times that of the single product, and at 8 KB per wave it outweighed the matrix bytes
+    // (C3 x 8: 216 of 383 us were left with the loads, the arithmetic and the atomics all switched off; waves
+    // of 64 KB: 383 -> 266 us).  BSM_MULTI_WAVE_BYTES, 0 = one split for both.
+    int64_t multi_wave_bytes = 64 << 10;
     int64_t split2_bytes = 0;     // row groups at least this big get 2 waves (0: W)
     int64_t split4_bytes = 0;     // ... and 4 waves (0: 3 W)
     int64_t wgitem_max_bytes = 0;   // non-exclusive groups are cut into items this big (0: 4 W)
@@ -158,6 +164,8 @@ class Analysis {
     int64_t value_bytes = 0;   // size of the packed value stream
     std::vector<int32_t> rows, cols;
     std::vector<WaveWork> waves;
+    std::vector<WaveWork> waves_multi;  // the coarser split for multi-RHS products (empty: `waves` serves both)
+    int64_t nwg_multi = 0;
     int64_t nwg_main = 0;   // workgroups holding panel work
     int64_t nwg_total = 0;  // + workgroups of scale work (exclusive forward launch only)
     int64_t ngroups = 0;

@@ -216,7 +216,7 @@ struct DeviceSink : ValueSink {
 std::unique_ptr<ValueSink> make_device_sink(void **d_values) { return std::unique_ptr<ValueSink>(new DeviceSink(d_values)); }
 
 void free_image(DeviceImage &img) {
-    for (void **p : {&img.d_values, &img.d_rows, &img.d_cols, &img.d_waves, &img.d_ws, &img.d_inv_ptr[0],
+    for (void **p : {&img.d_values, &img.d_rows, &img.d_cols, &img.d_waves, &img.d_waves_multi, &img.d_ws, &img.d_inv_ptr[0],
                      &img.d_inv_ptr[1], &img.d_inv_idx[0], &img.d_inv_idx[1]}) {
         if (*p) (void)hipFree(*p);
         *p = nullptr;
@@ -232,6 +232,7 @@ void fill_image(const Analysis &an, const bsm_options &o, bool use_own, DeviceIm
     img.value_bytes = an.value_bytes;
     img.nwg_main = an.nwg_main;
     img.nwg_total = an.nwg_total;
+    img.nwg_multi = an.nwg_multi;
     img.exclusive_fwd = an.exclusive_fwd && (o.accumulate == BSM_ACC_AUTO || o.accumulate == BSM_ACC_DIRECT);
     img.has_off = false;
     for (const WaveWork &w : an.waves)
@@ -239,7 +240,7 @@ void fill_image(const Analysis &an, const bsm_options &o, bool use_own, DeviceIm
     if (!img.exclusive_fwd) img.nwg_total = img.nwg_main;
     img.color_wg_ptr.assign(an.color_wg_ptr.begin(), an.color_wg_ptr.end());
     img.device_bytes = (long long)((size_t)an.value_bytes + an.rows.size() * 4 + an.cols.size() * 4 +
-                                   an.waves.size() * sizeof(WaveWork));
+                                   (an.waves.size() + an.waves_multi.size()) * sizeof(WaveWork));
     if (an.gather)
         img.device_bytes += (long long)((an.ws_slots + 8) * an.es + (an.inv_ptr[0].size() + an.inv_ptr[1].size()) * 8 +
                                         (an.inv_idx[0].size() + an.inv_idx[1].size()) * 4);
@@ -256,6 +257,7 @@ hipError_t upload_image(Analysis &an, DeviceImage &img, int dev) {
     if (e == hipSuccess) e = upload(an.rows, &img.d_rows, total);
     if (e == hipSuccess) e = upload(an.cols, &img.d_cols, total);
     if (e == hipSuccess) e = upload(an.waves, &img.d_waves, total);
+    if (e == hipSuccess && !an.waves_multi.empty()) e = upload(an.waves_multi, &img.d_waves_multi, total);
     if (e == hipSuccess && an.gather) {
         img.ws_fbase = an.ws_fbase;
         for (int k = 0; k < 2 && e == hipSuccess; k++) {
@@ -1076,6 +1078,7 @@ extern "C" int bsm_get_image(bsm_matrix_t A, int which, void *out, int64_t *nbyt
         case 5: src = an.inv_idx[0].data(); bytes = an.inv_idx[0].size() * 4; break;
         case 6: src = an.inv_ptr[1].data(); bytes = an.inv_ptr[1].size() * 8; break;
         case 7: src = an.inv_idx[1].data(); bytes = an.inv_idx[1].size() * 4; break;
+        case 8: src = an.waves_multi.data(); bytes = an.waves_multi.size() * sizeof(WaveWork); break;
         default: return fail(BSM_ERR_INVALID, "unknown image array");
     }
     if (out) {

@@ -15,6 +15,8 @@ struct DeviceImage {
     void *d_values = nullptr, *d_rows = nullptr, *d_cols = nullptr;
     void *d_waves = nullptr;
     long long nwg_main = 0, nwg_total = 0;
+    void *d_waves_multi = nullptr;  // coarser split of the same panels for the multi-RHS kernels (may be null)
+    long long nwg_multi = 0;
     bool exclusive_fwd = false;
     bool has_off = false;  // SymmetricBlockMatrix off-diagonal pieces present
     long long device_bytes = 0;

@@ -248,6 +248,9 @@ constexpr int DBG_NO_BUTTERFLY = 1 << 18;       // lane-local values are parked 
 constexpr int DBG_NO_EMISSION = 1 << 19;        // the emission loop is skipped altogether
 constexpr int DBG_NO_XGATHER = 1 << 20;         // the x slice is a constant (no column-list / x loads)
 constexpr int DBG_NO_FWD_OUT = 1 << 21;         // forward sums are not written
+constexpr int DBG_NO_MATRIX = 1 << 22;          // multi-RHS tile pipeline: the matrix loads are not issued
+constexpr int DBG_NO_FWD_HALF = 1 << 23;        // ... the forward half of an iteration is skipped
+constexpr int DBG_NO_TRN_HALF = 1 << 24;        // ... the transposed half of an iteration is skipped
 #define BSM_DBG(bit) ((flags & (bit)) != 0)
 #else
 #define BSM_DBG(bit) false
@@ -676,17 +679,77 @@ extern "C" int bsm_debug_set_trace(void *buf) {
 template <typename T, int K> constexpr int x_chunk_cols_multi() {
     return (x_chunk_cols<T>() / K) > 64 * TT<T>::E ? (x_chunk_cols<T>() / K) : 64 * TT<T>::E;
 }
+// the tile-pipelined kernels (below) stage shorter slices: their LDS goes to the two matrix tiles.  A chunk
+// must hold whole iterations of every strip height (8 * L strips of E columns) and the 64 * K combine slab.
+template <typename T> constexpr bool kRealType = false;
+template <> constexpr bool kRealType<float> = true;
+template <> constexpr bool kRealType<double> = true;
+// which multi-RHS kernels run the tile pipeline: the transposed / fused 8-column ones in real arithmetic (the
+// complex ones are at the register limit as they are: c64 fused 242 -> 256 VGPRs + scratch with it)
+template <typename T, int L, bool TRN> constexpr bool kTilePipe = TRN && L == 4 && kRealType<T>;
+template <typename T, int L> constexpr int x_chunk_cols_pipe() {
+    return 8 * L * TT<T>::E > 64 ? 8 * L * TT<T>::E : 64;
+}
+
+// XOR swizzle of the LDS matrix tile (16-byte units; strip sI of an iteration, row r of the strip -> unit
+// sI * P + (r ^ tile_swz(sI))): a global -> LDS load writes 64 consecutive units per wave-instruction, so the
+// image cannot be padded; instead every lane FETCHES row (lane ^ swz) of its strip.  The masks make both ways
+// the tile is read -- by row (lane = row, one strip per load) and by column (lane = strip, L rows per lane) --
+// free of bank conflicts under ds_read_b128's four 16-lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31}, ...
+// (found by exhaustive search over the linear maps strip bits -> row bits; value b = mask of strip bit b).
+template <int P, int L> struct TileSwz;
+template <> struct TileSwz<8, 4> { static constexpr int col[6] = {0, 1, 0, 2, 4, 0}; };
+template <> struct TileSwz<16, 4> { static constexpr int col[6] = {1, 2, 0, 8, 0, 0}; };
+template <> struct TileSwz<32, 4> { static constexpr int col[6] = {1, 2, 0, 0, 0, 0}; };
+template <> struct TileSwz<64, 4> { static constexpr int col[6] = {1, 2, 0, 0, 0, 0}; };
+template <int P, int L> __device__ __forceinline__ constexpr int tile_swz(int s) {
+    int h = 0;
+    for (int b = 0; b < 6; ++b)
+        if ((s >> b) & 1) h ^= TileSwz<P, L>::col[b];
+    return h;
+}
+
+// 16 bytes per lane from global memory straight into LDS (global_load_lds_dwordx4 ... nt): lane l's bytes land
+// at lds_dst + 16 * l, lds_dst wave-uniform.  No VGPR destination and hipcc does not count it: the caller waits
+// with vm_wait<N>() (loads, atomics and these complete in issue order).
+__device__ __forceinline__ void glds16_nt(const void *gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_dst)
+                 : "memory");
+}
+// s_waitcnt vmcnt(N) only (expcnt / lgkmcnt fields at their maxima), as the builtin: hipcc's own wait insertion
+// sees it, so loads it still tracks as pending are retired in its model too and it does not add a vmcnt(0) of its
+// own further down (which would drain the prefetched tile)
+__device__ __forceinline__ void vm_wait(int younger) {  // wave-uniform: all but the `younger` newest are done
+    asm volatile("" ::: "memory");  // (the builtin is IntrNoMem: loads and LDS reads may not cross it either way)
+    switch (younger) {
+        case 0: __builtin_amdgcn_s_waitcnt(0x0F70); break;
+        case 1: __builtin_amdgcn_s_waitcnt(0x0F71); break;
+        case 2: __builtin_amdgcn_s_waitcnt(0x0F72); break;
+        case 3: __builtin_amdgcn_s_waitcnt(0x0F73); break;
+        default: __builtin_amdgcn_s_waitcnt(0x0F74); break;
+    }
+    asm volatile("" ::: "memory");
+}
+// a value whose load must be complete -- for hipcc too -- from here on
+template <typename T> __device__ __forceinline__ void settle(T &v) {
+    static_assert(sizeof(T) == 4 || sizeof(T) == 8, "one or two registers");
+    asm volatile("" : "+v"(v));
+}
 
 template <typename T, int L, int P, bool FWD, bool TRN, int K>
 __device__ __forceinline__ void run_panel_multi(const WaveD &wd, const uint4 *__restrict__ values,
                                                 const int *__restrict__ rows,
                                                 const int *__restrict__ cols, const T *__restrict__ x,
                                                 long long ldx, T *__restrict__ y, long long ldy, T alpha,
-                                                int flags, int lane, T *xs, Vec16<T> *tile, T (&out)[K]) {
+                                                int flags, int lane, T *xs, Vec16<T> *tile, int *ci, T (&out)[K]) {
     constexpr int E = TT<T>::E;
     constexpr int G = 64 / P;
     constexpr int NC = G * L * E;
-    constexpr int XCH = x_chunk_cols_multi<T, K>();
+    constexpr bool PIPE = kTilePipe<T, L, TRN>;  // matrix tiles prefetched into LDS (below)
+    constexpr int XCH = PIPE ? x_chunk_cols_pipe<T, L>() : x_chunk_cols_multi<T, K>();
     static_assert(XCH % NC == 0, "x chunk must hold whole iterations");
     const bool opT = (flags & FLAG_OPT) != 0;
     const bool cjf = (flags & FLAG_CONJ) != 0;
@@ -754,7 +817,157 @@ __device__ __forceinline__ void run_panel_multi(const WaveD &wd, const uint4 *__
             return w + (w < s1w ? xbase : (w < s2w ? s1x : s2x));
         };
 
-        for (int c0 = 0; c0 < ncols; c0 += XCH) {
+        if constexpr (PIPE) {
+            // Fused / transposed multi-RHS products at 2-3 waves per SIMD were bound by the bytes in flight (one
+            // 4 KB tile per wave, and only while the wave was not computing: C3 x 8 ran at 2.5 TB/s with the VALU
+            // 39 % and the LDS 43 % busy), and a second register tile costs a resident wave.  The tile goes
+            // through LDS anyway (transposition above), so it is loaded THERE directly, one iteration ahead, with
+            // no register landing: two LDS tiles per wave, global_load_lds into the one while the other is read
+            // by row (forward half) and by column (transposed half).  In-order completion of vector memory
+            // operations does the bookkeeping: the wait for tile n is `all but tile n+1's loads`, which also
+            // covers every older atomic -- so iteration n's y contributions are issued AFTER that wait in
+            // iteration n+1 (held in CF registers meanwhile), and nothing else in the loop may load from global
+            // memory: gathered column lists are staged in LDS with the x slice.
+            {
+                constexpr int NSI = G * L;
+                constexpr int CF = (E * K / RG) > 1 ? (E * K / RG) : 1;
+                constexpr int NE = CF > K ? CF / K : 1;  // columns (of E) a lane's CF sums belong to
+                const int nit = (nstrips + NSI - 1) / NSI;
+                const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)tile);
+                const int hg = tile_swz<P, L>(g);
+                const int cbase = sp * P + ((rg * L) ^ tile_swz<P, L>(sp));
+                auto issue = [&](int it, int buf) {
+                    const int s0 = it * NSI;
+#pragma unroll
+                    for (int l = 0; l < L; ++l) {
+                        if (s0 + l * G < nstrips) {  // wave-uniform: the load is issued, and counted
+                            const int s = s0 + l * G + g;
+                            const int rho = i ^ tile_swz<P, L>(l * G) ^ hg;
+                            if (BSM_DBG(DBG_NO_MATRIX)) {
+                            } else if (rho < m && s < nstrips)
+                                glds16_nt(&vb[(uint32_t)(s * m + rho)], lds0 + (unsigned)((buf * L + l) * 1024));
+                            else
+                                tile[(buf * L + l) * 64 + lane] = Vec16<T>{};
+                        } else {
+                            tile[(buf * L + l) * 64 + lane] = Vec16<T>{};
+                        }
+                    }
+                };
+                auto loads_of = [&](int it) {
+                    const int left = nstrips - it * NSI;
+                    const int nl = (left + G - 1) / G;
+                    return nl < L ? nl : L;
+                };
+                int dq_yi[NE];
+                T dq_val[CF];
+#pragma unroll
+                for (int q = 0; q < NE; ++q) dq_yi[q] = -1;
+                int pos = 0, dup = 0;
+                auto emit = [&]() {
+#pragma unroll
+                    for (int jj = 0; jj < CF; ++jj) {
+                        const int yi = dq_yi[jj / K];
+                        const int k = (pos + jj) % K;
+                        // (atomics in coloured launches too: a read-modify-write's load would be waited for with
+                        // vmcnt(0) by the compiler, i.e. drain the prefetch every iteration)
+                        if (yi >= 0) atomic_acc(&y[yi + k * ldy], mul(alpha, dq_val[jj]));
+                    }
+                };
+                // the x rows above: no load hipcc knows of may be pending inside the loop, or its wait for it (a
+                // vmcnt(0) at the first use, executed every iteration) would drain the prefetched tile
+                if (TRN) {
+#pragma unroll
+                    for (int j = 0; j < L; ++j)
+#pragma unroll
+                        for (int k = 0; k < K; ++k) settle(xrr[j][k]);
+                }
+                if (nit > 0) issue(0, 0);
+                for (int it = 0; it < nit; ++it) {
+                    const int buf = it & 1;
+                    const int s0 = it * NSI;
+                    const int c0 = (s0 * E) / XCH * XCH;
+                    if (s0 * E == c0) {  // a new slice of columns: x values (forward half) and the gathered indices
+#pragma unroll
+                        for (int q = 0; q < XCH / 64; ++q) {
+                            const int c = q * 64 + lane;
+                            const int w = c0 + c;
+                            if (w < ncols + NC) {
+                                bool ok = w < ncols, off = false;
+                                // (load and LDS write in ONE block: a loaded register that some path never
+                                // reads stays pending for hipcc, which then waits vmcnt(0) before every reuse)
+                                if (xbase < 0) ci[c] = ok ? cols[col_off + w] : 0;
+                                if (fwd_en) {
+                                    const int xi = ok ? col_lookup(w, off) : 0;
+                                    ok = ok && (!opT || off);
+#pragma unroll
+                                    for (int k = 0; k < K; ++k) xs[c * K + k] = ok ? x[xi + k * ldx] : zero_of(T{});
+                                }
+                            }
+                        }
+                    }
+                    int younger = 0;
+                    if (it + 1 < nit) {
+                        issue(it + 1, buf ^ 1);
+                        younger = BSM_DBG(DBG_NO_MATRIX) ? 0 : loads_of(it + 1);
+                    }
+                    vm_wait(younger);
+                    if (!BSM_DBG(DBG_NO_GLOBAL_ATOMICS)) emit();  // iteration it-1's sums
+                    if (fwd_en && !BSM_DBG(DBG_NO_FWD_HALF)) {
+                        const int cb = s0 * E - c0;
+#pragma unroll
+                        for (int l = 0; l < L; ++l) {
+                            const Vec16<T> bl = tile[(buf * L + l) * 64 + (lane ^ tile_swz<P, L>(l * G) ^ hg)];
+                            const T *xp = &xs[(cb + (l * G + g) * E) * K];
+#pragma unroll
+                            for (int e = 0; e < E; ++e) {
+                                const T bv = cj(bl.v[e], cjf);
+#pragma unroll
+                                for (int k = 0; k < K; ++k) acc[k] = madd(acc[k], bv, xp[e * K + k]);
+                            }
+                        }
+                    }
+                    if (!trn_en || BSM_DBG(DBG_NO_TRN_HALF)) continue;
+                    T tv[E * K];
+#pragma unroll
+                    for (int q = 0; q < E * K; ++q) tv[q] = zero_of(T{});
+#pragma unroll
+                    for (int j = 0; j < L; ++j) {
+                        const Vec16<T> u = tile[buf * L * 64 + (cbase ^ j)];
+#pragma unroll
+                        for (int e = 0; e < E; ++e) {
+                            const T bv = cj(u.v[e], cjf);
+#pragma unroll
+                            for (int k = 0; k < K; ++k) tv[e * K + k] = madd(tv[e * K + k], bv, xrr[j][k]);
+                        }
+                    }
+                    pos = 0, dup = 0;
+                    ReduceAbove<T, E * K, NS>::run(tv, lane, pos, dup);
+                    const int s = s0 + sp;
+                    const bool mine = (lane & dup) == 0 && s < nstrips;
+#pragma unroll
+                    for (int q = 0; q < NE; ++q) {
+                        const int w = s * E + pos / K + q;
+                        int yi = -1;
+                        if (mine && w < ncols) {
+                            bool off;
+                            if (xbase < 0) {
+                                const int raw = ci[w - c0];
+                                off = raw >= 0 && (kinds & 3) == KIND_OFF;
+                                yi = raw & 0x7fffffff;
+                            } else {
+                                yi = col_lookup(w, off);
+                            }
+                            if (!(opT || off)) yi = -1;
+                        }
+                        dq_yi[q] = yi;
+                    }
+#pragma unroll
+                    for (int jj = 0; jj < CF; ++jj) dq_val[jj] = tv[jj];
+                }
+                emit();
+            }
+        }
+        for (int c0 = 0; !PIPE && c0 < ncols; c0 += XCH) {
             if (fwd_en) {
 #pragma unroll
                 for (int q = 0; q < XCH / 64; ++q) {
@@ -853,16 +1066,23 @@ __device__ __forceinline__ void run_panel_multi(const WaveD &wd, const uint4 *__
     }
 }
 
+// resident workgroups per CU the register allocation must leave room for: 3 for the pipelined fp32 kernels (their
+// LDS admits 3; fused: 189 VGPRs = 2 per CU without the bound, 168 + 16 spilled dwords with it: C3 in fp32 x 8
+// 176 -> 159 us), 2 otherwise (the fp64 ones fit 3 by themselves)
 template <typename T, int L, bool FWD, bool TRN, int K>
-__global__ void __launch_bounds__(64 * kWavesPerWg) __attribute__((amdgpu_waves_per_eu(2)))
+__global__ void __launch_bounds__(64 * kWavesPerWg, (kTilePipe<T, L, TRN> && sizeof(T) == 4 ? 3 : 2))
     panel_kernel_multi(const WaveWork *__restrict__ waves, const uint4 *__restrict__ values,
                        const int *__restrict__ rows, const int *__restrict__ cols,
                        const T *__restrict__ x, long long ldx, T *__restrict__ y, long long ldy, T alpha,
                        T beta, int flags, unsigned wg_base) {
-    constexpr int XS = x_chunk_cols_multi<T, K>() * K;  // >= 64*K: also holds the combine slab
-    constexpr int TILE = L * 72;  // 16-byte units: max over P of (64 / P) * L strips of P + 1 units
+    constexpr bool PIPE = kTilePipe<T, L, TRN>;
+    constexpr int XCH = PIPE ? x_chunk_cols_pipe<T, L>() : x_chunk_cols_multi<T, K>();
+    constexpr int XS = XCH * K;  // >= 64*K: also holds the combine slab
+    // 16-byte units: max over P of (64 / P) * L strips of P + 1 units; the pipelined kernels hold two tiles
+    constexpr int TILE = PIPE ? 2 * L * 64 : L * 72;
     __shared__ __attribute__((aligned(16))) T xs[kWavesPerWg][FWD ? XS : 1];
     __shared__ Vec16<T> tl[kWavesPerWg][TRN ? TILE : 1];
+    __shared__ int ci[kWavesPerWg][PIPE ? XCH : 1];  // the slice's gathered column indices
 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -875,13 +1095,13 @@ __global__ void __launch_bounds__(64 * kWavesPerWg) __attribute__((amdgpu_waves_
     for (int k = 0; k < K; ++k) u[k] = zero_of(T{});
     if (work == WORK_PANEL) {
         if (m <= 8)
-            run_panel_multi<T, L, 8, FWD, TRN, K>(wd, values, rows, cols, x, ldx, y, ldy, alpha, flags, lane, xs[wave], tl[wave], u);
+            run_panel_multi<T, L, 8, FWD, TRN, K>(wd, values, rows, cols, x, ldx, y, ldy, alpha, flags, lane, xs[wave], tl[wave], ci[wave], u);
         else if (m <= 16)
-            run_panel_multi<T, L, 16, FWD, TRN, K>(wd, values, rows, cols, x, ldx, y, ldy, alpha, flags, lane, xs[wave], tl[wave], u);
+            run_panel_multi<T, L, 16, FWD, TRN, K>(wd, values, rows, cols, x, ldx, y, ldy, alpha, flags, lane, xs[wave], tl[wave], ci[wave], u);
         else if (m <= 32)
-            run_panel_multi<T, L, 32, FWD, TRN, K>(wd, values, rows, cols, x, ldx, y, ldy, alpha, flags, lane, xs[wave], tl[wave], u);
+            run_panel_multi<T, L, 32, FWD, TRN, K>(wd, values, rows, cols, x, ldx, y, ldy, alpha, flags, lane, xs[wave], tl[wave], ci[wave], u);
         else
-            run_panel_multi<T, L, 64, FWD, TRN, K>(wd, values, rows, cols, x, ldx, y, ldy, alpha, flags, lane, xs[wave], tl[wave], u);
+            run_panel_multi<T, L, 64, FWD, TRN, K>(wd, values, rows, cols, x, ldx, y, ldy, alpha, flags, lane, xs[wave], tl[wave], ci[wave], u);
     }
     const bool direct = (flags & FLAG_DIRECT) != 0;
     const bool sz = (flags & FLAG_STRONG_ZERO) != 0;
@@ -1145,10 +1365,16 @@ static hipError_t launch_typed_multi(const DeviceImage &img, bool opT, bool conj
     }
     const bool colored = !img.color_wg_ptr.empty();
     if (colored) flags |= FLAG_RMW;
+    // the coarser split of the panels (bsm_analysis.h: Tunables::multi_wave_bytes), where the image has one
+    long long nwg_main = img.nwg_main;
+    if (img.d_waves_multi && !colored) {
+        waves = (const WaveWork *)img.d_waves_multi;
+        nwg_main = img.nwg_multi;
+    }
     const size_t nlaunch = colored ? img.color_wg_ptr.size() - 1 : 1;
     for (size_t c = 0; c < nlaunch; ++c) {
         const long long wg0 = colored ? img.color_wg_ptr[c] : 0;
-        const long long wg1 = colored ? img.color_wg_ptr[c + 1] : img.nwg_main;
+        const long long wg1 = colored ? img.color_wg_ptr[c + 1] : nwg_main;
         if (wg1 <= wg0) continue;
         const dim3 grid((unsigned)(wg1 - wg0));
         const unsigned wg_base = (unsigned)wg0;

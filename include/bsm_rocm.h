@@ -321,7 +321,8 @@ int bsm_stats(bsm_matrix_t A, bsm_stats_t *out);
 /* Debug / test hook: copies one array of the packed device image (host copy) out.
  * which: 0 values (bytes), 1 rows (int32), 2 cols (int32), 3 waves (64-byte records;
  * layout in blocksparsematrices.jl_amd/csrc/bsm_layout.h); gather handles also 4 / 5 = row
- * pointers (int64) / workspace slots (int32) of the op-N inverted index and 6 / 7 for op T.
+ * pointers (int64) / workspace slots (int32) of the op-N inverted index and 6 / 7 for op T;
+ * 8 = the coarser wave records bsm_mul_multi walks (empty when the records of 3 serve both).
  * Add 16 to `which` for the arrays of the transposed image (bsm_options.transpose_image).
  * Only available on analysis-only handles (BSM_DEVICE_NONE), which keep the host copy.
  * Call with out == NULL to obtain the size in bytes. */

@@ -163,10 +163,12 @@ KIND_HAS_OFF = 1 << 8
 KIND_GROUP_HAS_OFF = 1 << 9
 
 
-def get_image(A, timage=False):
+def get_image(A, timage=False, multi=False):
+    """multi: the coarser wave records the multi-RHS kernels walk (bsm_get_image 8) in place of the ordinary ones
+    (an empty list means the ordinary records serve both)"""
     from bsm_amd import _lib as L
     out = []
-    for which, dt in ((0, np.uint8), (1, np.int32), (2, np.int32), (3, WAVE_DT)):
+    for which, dt in ((0, np.uint8), (1, np.int32), (2, np.int32), (8 if multi else 3, WAVE_DT)):
         which += 16 if timage else 0
         n = C.c_int64(0)
         L.check(L.lib().bsm_get_image(A._h.ptr, which, None, C.byref(n)))
@@ -202,11 +204,12 @@ def _image_exclusive(waves, rows, ylen):
     return bool(np.all(seen <= 1))
 
 
-def interpret_image(A, op, x, y0, alpha=1, beta=0, strong=True, timage=False):
+def interpret_image(A, op, x, y0, alpha=1, beta=0, strong=True, timage=False, multi=False):
     """Executes the packed image the way the HIP kernel walks it (same descriptors and index
     arithmetic, numpy arithmetic) -- checks packing + schedule on CPU.
-    timage: run op T / C as a FORWARD product on the handle's second (transposed) ordering."""
-    values, rows, cols, waves = get_image(A, timage)
+    timage: run op T / C as a FORWARD product on the handle's second (transposed) ordering.
+    multi: walk the multi-RHS kernels' coarser wave records instead."""
+    values, rows, cols, waves = get_image(A, timage, multi)
     dt = A.dtype
     E = 16 // dt.itemsize
     vals = values.view(dt)

@@ -346,6 +346,23 @@ def test_multi_rhs_symmetric_and_blocksparse_fixture(torch_cuda, bsm, oracle, ke
     _check_multi(torch_cuda, bsm, oracle, r, bsm.synthetic.build(r), np.float64, nrhs_list=(8, 6), ops=[N, T])
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_multi_rhs_real_fused_and_transposed_tile_pipeline(torch_cuda, bsm, oracle, dtype):
+    """The 8-column fused / transposed kernels in real arithmetic prefetch their matrix tiles into LDS
+    (global_load_lds, counted vmcnt, deferred atomics): every strip height (8 / 16 / 32 / 64 rows, heights that
+    are no power of two), gathered and contiguous columns, panels shorter than one iteration, 8 + 4 + 1 splits."""
+    p = fixture_problem("cuboid", dtype, "real")                       # gathered column lists
+    _check_multi(torch_cuda, bsm, oracle, p, bsm.synthetic.build(p), dtype, nrhs_list=(8, 13), ops=[N, T])
+    _check_multi(torch_cuda, bsm, oracle, p, bsm.synthetic.build(p, accumulate="colored"), dtype, nrhs_list=(8,), ops=[N])
+    q = fixture_as_blocksparse("cuboid", dtype, "real")                # transposed-only launch, index lists
+    _check_multi(torch_cuda, bsm, oracle, q, bsm.synthetic.build(q), dtype, nrhs_list=(8,), ops=[N, T])
+    for lo, hi in ((3, 9), (10, 40), (16, 200)):                       # contiguous segments of every height class
+        r = bsm.synthetic.config5(n=6000 if hi < 100 else 30000, lo=lo, hi=hi, halfband=3, dtype=dtype)
+        _check_multi(torch_cuda, bsm, oracle, r, bsm.synthetic.build(r), dtype, nrhs_list=(8, 16), ops=[N, T])
+    v = bsm.synthetic.config2(n=9000, nblocks=500, dtype=dtype)        # VBCRS: transposed product on the single image
+    _check_multi(torch_cuda, bsm, oracle, v, bsm.synthetic.build(v), dtype, nrhs_list=(8,), ops=[T])
+
+
 # ---- BASELINE.json's big configs at the size ONE GPU of eight owns: size-independent properties ------
 def _dot(a, b):
     return float(np.dot(a.astype(np.float64), b.astype(np.float64)))

@@ -267,6 +267,40 @@ def test_image_config3_symmetric_small(bsm, oracle):
     _check_image(bsm, oracle, p, A, np.float64)
 
 
+def test_coarser_wave_records_of_the_multi_rhs_kernels(bsm, oracle, monkeypatch):
+    # bsm_mul_multi walks a second, coarser split of the same panels (waves of 64 KB instead of 8 KB: a wave's
+    # fixed part is K times the single product's): same value stream, every strip exactly once -- the image
+    # interpreter on those records must give the same products -- and clearly fewer waves; operators whose
+    # ordinary split is as coarse already (small panels), exclusive and coloured ones carry no second list
+    from _common import WORK_PANEL, get_image
+    rng = np.random.default_rng(5)
+    for p in (bsm.synthetic.config3(nseg=24, bs=64, halfband=8), bsm.synthetic.config5(n=9000, lo=16, hi=256, halfband=4)):
+        A = bsm.synthetic.build(p, device=NODEV)
+        main, multi = get_image(A)[3], get_image(A, multi=True)[3]
+        nm, nk = int(np.sum(main["work"] == WORK_PANEL)), int(np.sum(multi["work"] == WORK_PANEL))
+        assert 0 < nk <= 0.75 * nm and len(multi) % 4 == 0
+        n = p["size"][0]
+        x, y0 = rand_vec(rng, n, np.float64), rand_vec(rng, n, np.float64)
+        for op in (N, T):
+            ref = oracle_mul(oracle, p, op, x, y0, 0.5, 2.0, False)
+            assert relerr(interpret_image(A, op, x, y0, 0.5, 2.0, False, multi=True), ref) < 1e-13
+        # panel waves of one group split ITS strips: bytes per wave near the 64 KB target, never above 4 x
+        by = multi["first"]["nstrips"].astype(np.int64) * multi["m"] * 16
+        assert by.max() <= 4 * 65536 and by[multi["work"] == WORK_PANEL].mean() > 3 * (main["first"]["nstrips"].astype(np.int64) * main["m"] * 16)[main["work"] == WORK_PANEL].mean() / 2
+    small = fixture_problem("cuboid", np.float64, "real")              # gathered columns, 3-28-row panels
+    A = bsm.synthetic.build(small, device=NODEV)
+    if len(get_image(A, multi=True)[3]):
+        n = small["size"][0]
+        x, y0 = rand_vec(rng, n, np.float64), rand_vec(rng, n, np.float64)
+        assert relerr(interpret_image(A, N, x, y0, 1, 0, True, multi=True), oracle_mul(oracle, small, N, x, y0, 1, 0, True)) < 1e-13
+    v = bsm.synthetic.config2(n=20000, nblocks=1000)                   # exclusive forward launch
+    assert len(get_image(bsm.synthetic.build(v, device=NODEV), multi=True)[3]) == 0
+    p = bsm.synthetic.config3(nseg=24, bs=64, halfband=8)
+    assert len(get_image(bsm.synthetic.build(p, device=NODEV, accumulate="colored"), multi=True)[3]) == 0
+    monkeypatch.setenv("BSM_MULTI_WAVE_BYTES", "0")
+    assert len(get_image(bsm.synthetic.build(p, device=NODEV), multi=True)[3]) == 0
+
+
 def test_image_config4_vbcrs_small_f32(bsm, oracle):
     p = bsm.synthetic.config4(ngrid=24, bs=128, per_row=6)
     A = bsm.synthetic.build(p, device=NODEV)

@@ -46,6 +46,7 @@ CASES = {
     "c2": lambda: S.config2(on_device=True),
     "c2x20": lambda: S.config2(n=2_000_000, nblocks=100_000, on_device=True),
     "c3": lambda: S.config3(on_device=True),
+    "c3_f32": lambda: S.config3(on_device=True, dtype=np.float32),
     "c4s": lambda: S.config4(on_device=True, row_lo=0, row_hi=1953),
     "c5s": lambda: S.config5(n=625_000, on_device=True),
     "bem_c128": lambda: bem(400, np.complex128, "full"),
