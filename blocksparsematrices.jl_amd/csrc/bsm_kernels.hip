@@ -873,7 +873,33 @@ __device__ __forceinline__ void run_panel_multi(const WaveD &wd, const uint4 *__
                         if (yi >= 0) atomic_acc(&y[yi + k * ldy], mul(alpha, dq_val[jj]));
                     }
                 };
-                // the x rows above: no load hipcc knows of may be pending inside the loop, or its wait for it (a
+                // a slice of columns: x values (forward half) and the gathered indices
+                auto stage_slice = [&](int c0) {
+#pragma unroll
+                    for (int q = 0; q < XCH / 64; ++q) {
+                        const int c = q * 64 + lane;
+                        const int w = c0 + c;
+                        if (w < ncols + NC) {
+                            bool ok = w < ncols, off = false;
+                            // (load and LDS write in ONE block: a loaded register that some path never
+                            // reads stays pending for hipcc, which then waits vmcnt(0) before every reuse)
+                            if (xbase < 0) ci[c] = ok ? cols[col_off + w] : 0;
+                            if (fwd_en) {
+                                const int xi = ok ? col_lookup(w, off) : 0;
+                                ok = ok && (!opT || off);
+#pragma unroll
+                                for (int k = 0; k < K; ++k) xs[c * K + k] = ok ? x[xi + k * ldx] : zero_of(T{});
+                            }
+                        }
+                    }
+                };
+                // A wave's start is a chain of dependent round trips (descriptor -> row list -> x rows, column list
+                // -> x slice -> first tile), and a panel of the BEM fixture is 3-4 iterations long: the first tile's
+                // loads go out first (they need the descriptor only), the first slice is staged while the x rows
+                // above are still in flight, and only then everything is waited for -- three round trips, not six.
+                if (nit > 0) issue(0, 0);
+                if (nit > 0) stage_slice(0);
+                // the x rows: no load hipcc knows of may be pending inside the loop, or its wait for it (a
                 // vmcnt(0) at the first use, executed every iteration) would drain the prefetched tile
                 if (TRN) {
 #pragma unroll
@@ -881,30 +907,11 @@ __device__ __forceinline__ void run_panel_multi(const WaveD &wd, const uint4 *__
 #pragma unroll
                         for (int k = 0; k < K; ++k) settle(xrr[j][k]);
                 }
-                if (nit > 0) issue(0, 0);
                 for (int it = 0; it < nit; ++it) {
                     const int buf = it & 1;
                     const int s0 = it * NSI;
                     const int c0 = (s0 * E) / XCH * XCH;
-                    if (s0 * E == c0) {  // a new slice of columns: x values (forward half) and the gathered indices
-#pragma unroll
-                        for (int q = 0; q < XCH / 64; ++q) {
-                            const int c = q * 64 + lane;
-                            const int w = c0 + c;
-                            if (w < ncols + NC) {
-                                bool ok = w < ncols, off = false;
-                                // (load and LDS write in ONE block: a loaded register that some path never
-                                // reads stays pending for hipcc, which then waits vmcnt(0) before every reuse)
-                                if (xbase < 0) ci[c] = ok ? cols[col_off + w] : 0;
-                                if (fwd_en) {
-                                    const int xi = ok ? col_lookup(w, off) : 0;
-                                    ok = ok && (!opT || off);
-#pragma unroll
-                                    for (int k = 0; k < K; ++k) xs[c * K + k] = ok ? x[xi + k * ldx] : zero_of(T{});
-                                }
-                            }
-                        }
-                    }
+                    if (s0 * E == c0 && it > 0) stage_slice(c0);
                     int younger = 0;
                     if (it + 1 < nit) {
                         issue(it + 1, buf ^ 1);

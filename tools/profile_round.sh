@@ -42,6 +42,13 @@ KB_TIMG=1 python3 tools/kbench.py c2 500 T >> $O/r03_c2_transposed.txt 2>&1 || t
 python3 tools/hostpath.py > $O/r03_hostpath.txt 2>&1 || true
 for c in c3 c5s; do python3 tools/distbench.py $c; done > $O/r03_distbench.txt 2> /dev/null
 python3 tools/multirhs.py > $O/r03_multirhs.txt 2> /dev/null
+# 7. multi-RHS products: SQ / LDS counters (two --pmc passes each) and the timing-only ablations of the pipelined
+#    kernel (experiment build)
+{ echo "Multi right-hand-side products (bsm_mul_multi), rocprofv3 --kernel-trace --pmc (two passes), tools/mrhs_one.py, 6 dispatches each;"
+  echo "SQ_ACTIVE_* / SQ_WAIT_* / SQ_WAVE_CYCLES in quad-cycles summed over the chip, SQ_LDS_* in LDS cycles summed over the 256 CUs."
+  for cfg in "c3 8" "c3 1" "c5s 8" "c4s 8"; do set -- $cfg; bash tools/mrhs_pmc.sh $1 $2; echo "== $1_$2"; cat gpurun_out/mrhs_pmc_$1_$2.txt; done; } > $O/r03_multirhs_counters.txt 2> /dev/null
+{ echo "Timing-only ablations of the pipelined multi-RHS kernel (tools/ablate_multi.py, experiment build: results wrong by construction):"
+  python3 tools/ablate_multi.py c3 8 2> /dev/null | tail -9; python3 tools/ablate_multi.py bem_f64 8 2> /dev/null | tail -9; } > $O/r03_multirhs_ablation.txt
 find $O -name "*.csv" -size +2M -delete
 rm -rf $O/kt $O/pmc_* $O/leg_*_fetch $O/leg_*_write $O/leg_*_tcc $O/leg_*_sq $O/c2T_tcc
 ls -la $O
