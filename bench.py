@@ -141,8 +141,10 @@ def timed(fn, reps, torch):
     return a.elapsed_time(b) * 1e-3 / reps
 
 
-def leg(bsm, torch, prob, reps, **kw):
-    """One driver-timed single-GPU leg: warm device-event time of mul!(y, A, x)."""
+def leg(bsm, torch, prob, reps, multi_rhs=0, **kw):
+    """One driver-timed single-GPU leg: warm device-event time of mul!(y, A, x).
+    multi_rhs = K: also mul!(Y, A, X) with K right-hand sides (bsm_mul_multi: A streamed once per batch of <= 8),
+    its time in single products and its worst column against K single products."""
     A = bsm.synthetic.build(prob, **kw)
     st = A.stats()
     x = prob["x"]
@@ -157,6 +159,26 @@ def leg(bsm, torch, prob, reps, **kw):
            "alg_MB": round(st["alg_bytes"] / 1e6, 1), "device_MB": round(st["device_bytes"] / 1e6, 1)}
     if st.get("win_emissions"):  # fused symmetric launch: share of the y contributions that leave a CU as global atomics
         out["y_contributions_as_atomics"] = round((st["win_emissions"] - st["win_inside"] + st["win_flushed"]) / st["win_emissions"], 3)
+    if multi_rhs:
+        K, n = int(multi_rhs), x.shape[0]
+        X = torch.empty((K, n), dtype=x.dtype, device="cuda").t()  # column-major n x K
+        for k in range(K):
+            X[:, k] = x * (k + 1) / K
+        Y = torch.full((K, n), float("nan"), dtype=x.dtype, device="cuda").t()
+        many = lambda: bsm.mul(Y, A, X)
+        for _ in range(30):
+            many()
+        torch.cuda.synchronize()
+        tk = sorted(timed(many, max(reps // 3, 5), torch) for _ in range(3))[1]
+        worst = 0.0
+        for k in range(K):  # the reference semantics: LinearMaps applies _unsafe_mul! column by column
+            bsm.mul(y, A, X[:, k].contiguous())
+            worst = max(worst, float((Y[:, k] - y).abs().max() / y.abs().max()))
+        plan()  # (y back to the single product of x)
+        torch.cuda.synchronize()
+        out["multi_rhs"] = {"nrhs": K, "us": round(tk * 1e6, 2), "single_products": round(tk / t, 3),
+                            "relerr_vs_single_products": worst}
+        del X, Y
     del plan, A
     return out, y
 
@@ -683,7 +705,7 @@ def run_c2(args, bsm, torch, dist, np, rank, world, barrier, reduce_scalars):
         try:  # (additional figures must never cost the headline line)
             extra["hbm_vbcrs_fp64"], _ = leg(bsm, torch, S.config2(n=2_000_000, nblocks=100_000, on_device=True), 50)
             extra["hbm_vbcrs_fp64"]["workload"] = "C2-shaped VBCRS 2M x 2M, 100 000 fp64 blocks 8-64 (20 x C2), forward mul!"
-            extra["c3_fused"], _ = leg(bsm, torch, S.config3(on_device=True), 50)
+            extra["c3_fused"], _ = leg(bsm, torch, S.config3(on_device=True), 50, multi_rhs=8)
             extra["c3_fused"]["workload"] = "C3: SymmetricBlockMatrix 200k x 200k, 64x64 fp64 blocks, half-bandwidth 8, fused A + A^T mul!"
         except Exception as e:  # pragma: no cover
             extra["legs_error"] = repr(e)
