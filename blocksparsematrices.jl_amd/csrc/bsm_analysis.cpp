@@ -758,13 +758,14 @@ void Analysis::stage_work_items(BuildState &st) {
 
     {  // bytes per wave for this operator (bsm_analysis.h: Tunables::wave_bytes)
         int64_t W = tun.wave_bytes;
+        // lane fill: rows of a group over the lanes its strips occupy (8, 16, 32 or 64 per strip)
+        double rows_b = 0, lanes_b = 0;
+        for (const Group &G : groups) {
+            rows_b += (double)G.mc * (double)G.strips;
+            lanes_b += (double)lanes_per_strip(G.mc) * (double)G.strips;
+        }
+        lane_fill = lanes_b > 0 ? rows_b / lanes_b : 1.0;
         if (W <= 0) {
-            // lane fill: rows of a group over the lanes its strips occupy (8, 16, 32 or 64 per strip)
-            double rows_b = 0, lanes_b = 0;
-            for (const Group &G : groups) {
-                rows_b += (double)G.mc * (double)G.strips;
-                lanes_b += (double)lanes_per_strip(G.mc) * (double)G.strips;
-            }
             const bool low_fill = lanes_b > 0 && rows_b < tun.fat_fill_below * lanes_b;
             W = tun.wave_bytes_min;
             if (low_fill) {

@@ -239,6 +239,9 @@ constexpr int FLAG_CONJ = 4;
 constexpr int FLAG_OPT = 8;
 constexpr int FLAG_RMW = 16;     // coloured launch: conflict-free by construction, plain read-modify-write
 constexpr int FLAG_GATHER = 32;  // contributions are stored in the workspace, gather_kernel sums them
+// multi-RHS kernels: bits 8-11 = number of ACTIVE right-hand sides of a padded batch (0: all K).  Columns past it
+// read the last active column of X (valid memory, arithmetic wasted) and are never written.
+constexpr int FLAG_KACT_SHIFT = 8;
 #ifdef BSM_EXPERIMENT
 // developer build (make exp): timing-only ablations of the fused kernel, selected by BSM_DEBUG_FLAGS
 // (results are WRONG with any bit set; tools/ablate.py)
@@ -753,6 +756,8 @@ __device__ __forceinline__ void run_panel_multi(const WaveD &wd, const uint4 *__
     static_assert(XCH % NC == 0, "x chunk must hold whole iterations");
     const bool opT = (flags & FLAG_OPT) != 0;
     const bool cjf = (flags & FLAG_CONJ) != 0;
+    const int kact = ((flags >> FLAG_KACT_SHIFT) & 15) ? ((flags >> FLAG_KACT_SHIFT) & 15) : K;
+    auto kc = [&](int k) { return k < kact ? k : kact - 1; };  // the column of X a (possibly padded) slot reads
     const int m = wd.m;
     const int i = lane & (P - 1);
     const int g = lane / P;
@@ -784,7 +789,7 @@ __device__ __forceinline__ void run_panel_multi(const WaveD &wd, const uint4 *__
             int ri = 0;
             if (ok) ri = (wd.rbase >= 0) ? wd.rbase + r : rows[wd.row_off + r];
 #pragma unroll
-            for (int k = 0; k < K; ++k) xrr[j][k] = ok ? x[ri + k * ldx] : zero_of(T{});
+            for (int k = 0; k < K; ++k) xrr[j][k] = ok ? x[ri + kc(k) * ldx] : zero_of(T{});
         }
     }
 
@@ -870,7 +875,7 @@ __device__ __forceinline__ void run_panel_multi(const WaveD &wd, const uint4 *__
                         const int k = (pos + jj) % K;
                         // (atomics in coloured launches too: a read-modify-write's load would be waited for with
                         // vmcnt(0) by the compiler, i.e. drain the prefetch every iteration)
-                        if (yi >= 0) atomic_acc(&y[yi + k * ldy], mul(alpha, dq_val[jj]));
+                        if (yi >= 0 && k < kact) atomic_acc(&y[yi + k * ldy], mul(alpha, dq_val[jj]));
                     }
                 };
                 // a slice of columns: x values (forward half) and the gathered indices
@@ -888,7 +893,7 @@ __device__ __forceinline__ void run_panel_multi(const WaveD &wd, const uint4 *__
                                 const int xi = ok ? col_lookup(w, off) : 0;
                                 ok = ok && (!opT || off);
 #pragma unroll
-                                for (int k = 0; k < K; ++k) xs[c * K + k] = ok ? x[xi + k * ldx] : zero_of(T{});
+                                for (int k = 0; k < K; ++k) xs[c * K + k] = ok ? x[xi + kc(k) * ldx] : zero_of(T{});
                             }
                         }
                     }
@@ -985,7 +990,7 @@ __device__ __forceinline__ void run_panel_multi(const WaveD &wd, const uint4 *__
                         const int xi = ok ? col_lookup(w, off) : 0;
                         ok = ok && (!opT || off);
 #pragma unroll
-                        for (int k = 0; k < K; ++k) xs[c * K + k] = ok ? x[xi + k * ldx] : zero_of(T{});
+                        for (int k = 0; k < K; ++k) xs[c * K + k] = ok ? x[xi + kc(k) * ldx] : zero_of(T{});
                     }
                 }
             }
@@ -1047,7 +1052,7 @@ __device__ __forceinline__ void run_panel_multi(const WaveD &wd, const uint4 *__
                             if (w < ncols) {
                                 bool off = false;
                                 const int yi = col_lookup(w, off);
-                                if (opT || off) {
+                                if ((opT || off) && k < kact) {
                                     T *yp = &y[yi + k * ldy];
                                     const T val = mul(alpha, tv[jj]);
                                     if (flags & FLAG_RMW)
@@ -1112,6 +1117,7 @@ __global__ void __launch_bounds__(64 * kWavesPerWg, (kTilePipe<T, L, TRN> && siz
     }
     const bool direct = (flags & FLAG_DIRECT) != 0;
     const bool sz = (flags & FLAG_STRONG_ZERO) != 0;
+    const int kact = ((flags >> FLAG_KACT_SHIFT) & 15) ? ((flags >> FLAG_KACT_SHIFT) & 15) : K;
     if (FWD) {
         if (wd.wg_sync) {
             // a wave's staged x slice is dead once it has left its loop: reuse it as this wave's
@@ -1128,6 +1134,7 @@ __global__ void __launch_bounds__(64 * kWavesPerWg, (kTilePipe<T, L, TRN> && siz
                 const int yi = (wd.rbase >= 0) ? wd.rbase + lane : rows[wd.row_off + lane];
 #pragma unroll
                 for (int k = 0; k < K; ++k) {
+                    if (k >= kact) continue;
                     T *yp = &y[yi + k * ldy];
                     const T val = mul(alpha, u[k]);
                     if (direct) {
@@ -1146,6 +1153,7 @@ __global__ void __launch_bounds__(64 * kWavesPerWg, (kTilePipe<T, L, TRN> && siz
         for (int r = lane; r < cnt; r += 64)
 #pragma unroll
             for (int k = 0; k < K; ++k) {
+                if (k >= kact) continue;
                 T *yp = &y[wd.rbase + r + k * ldy];
                 *yp = sz ? zero_of(T{}) : mul(beta, *yp);
             }
@@ -1334,11 +1342,12 @@ static hipError_t launch_typed(const DeviceImage &img, bool opT, bool conj, cons
 template <typename T, int L, int K>
 static hipError_t launch_typed_multi(const DeviceImage &img, bool opT, bool conj, const T *xd, long long ldx,
                                      T *yd, long long ldy, T alpha, T beta, int strong_zero,
-                                     hipStream_t stream, const long long *zrange) {
+                                     hipStream_t stream, const long long *zrange, int kact = K) {
     int flags = 0;
     if (strong_zero) flags |= FLAG_STRONG_ZERO;
     if (conj) flags |= FLAG_CONJ;
     if (opT) flags |= FLAG_OPT;
+    if (kact < K) flags |= kact << FLAG_KACT_SHIFT;  // a padded batch: kact of the K slots carry columns
 #ifdef BSM_EXPERIMENT
     if (const char *v = std::getenv("BSM_DEBUG_FLAGS")) flags |= std::atoi(v) << 16;
 #endif
@@ -1367,7 +1376,7 @@ static hipError_t launch_typed_multi(const DeviceImage &img, bool opT, bool conj
     if (hi > lo && (strong_zero || !is_one(beta))) {
         long long nblk = (hi - lo + 255) / 256;
         if (nblk > 2048) nblk = 2048;
-        hipLaunchKernelGGL((scale_kernel<T>), dim3((unsigned)nblk, (unsigned)K), dim3(256), 0, stream, yd, ldy, lo,
+        hipLaunchKernelGGL((scale_kernel<T>), dim3((unsigned)nblk, (unsigned)kact), dim3(256), 0, stream, yd, ldy, lo,
                            hi, beta, strong_zero);
     }
     const bool colored = !img.color_wg_ptr.empty();
@@ -1413,15 +1422,28 @@ static hipError_t launch_multi_typed(const DeviceImage &img, bool opT, bool conj
     // kernels keep L = 4 loads per lane in flight instead of 8: with 8 accumulators and 8 x values
     // per lane the registers, i.e. the resident waves, are worth more than the deeper load queue
     // (fp64 fused: 143 -> 103 VGPRs; C3 3.0x -> 3.3x, 8-28-row blocks 2.0x -> 2.4x over 8 products).
+    // A remainder of 5-7 columns is one PADDED 8-column pass and 3 columns one padded 4-column pass (the idle
+    // slots repeat the last column and are never written): a pass costs 1.2-1.8 (8) / 1.1-1.4 (4) single products
+    // on the large operators, 3.9 / 3.0 on the BEM fixture -- never more than the 4 + singles it replaces; two
+    // columns stay two single products (a 4-column pass over 3-28-row panels costs three).
     while (e == hipSuccess && nrhs - k >= 8) {
         e = launch_typed_multi<T, 4, 8>(img, opT, conj, xd + k * ldx, ldx, yd + k * ldy, ldy, alpha, beta,
                                         strong_zero, stream, zrange);
         k += 8;
     }
-    if (e == hipSuccess && nrhs - k >= 4) {
+    if (e == hipSuccess && nrhs - k >= 5) {
+        const int rem = (int)(nrhs - k);
+        e = launch_typed_multi<T, 4, 8>(img, opT, conj, xd + k * ldx, ldx, yd + k * ldy, ldy, alpha, beta,
+                                        strong_zero, stream, zrange, rem);
+        k += rem;
+    }
+    // (two columns: a padded 4-column pass where the row groups fill their lanes -- 1.1-1.3 single products on C3 /
+    // C4 -- and two single products over short panels, where the pass would cost 2.6)
+    if (e == hipSuccess && (nrhs - k >= 3 || (nrhs - k == 2 && img.lane_fill >= 0.85f))) {
+        const int rem = (int)(nrhs - k);  // 2, 3 or 4
         e = launch_typed_multi<T, 8, 4>(img, opT, conj, xd + k * ldx, ldx, yd + k * ldy, ldy, alpha, beta,
-                                        strong_zero, stream, zrange);
-        k += 4;
+                                        strong_zero, stream, zrange, rem);
+        k += rem;
     }
     for (; e == hipSuccess && k < nrhs; ++k)
         e = launch_typed<T, 8>(img, opT, conj, xd + k * ldx, yd + k * ldy, alpha_p, beta_p, strong_zero, stream, false, zrange);

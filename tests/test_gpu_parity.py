@@ -363,6 +363,38 @@ def test_multi_rhs_real_fused_and_transposed_tile_pipeline(torch_cuda, bsm, orac
     _check_multi(torch_cuda, bsm, oracle, v, bsm.synthetic.build(v), dtype, nrhs_list=(8,), ops=[T])
 
 
+@pytest.mark.parametrize("kind", ["symmetric", "vbcrs", "fixture"])
+def test_multi_rhs_padded_batches_touch_only_their_columns(torch_cuda, bsm, oracle, kind):
+    """2, 3 and 5-7 right-hand sides run as PADDED 4- / 8-column passes (idle slots repeat the last column and
+    are never written): every count 1..9 against the oracle, with NaN columns of X and sentinel columns of Y
+    right behind the ones the call owns."""
+    torch = torch_cuda
+    if kind == "symmetric":
+        p = bsm.synthetic.config5(n=12000, lo=16, hi=160, halfband=3)
+    elif kind == "vbcrs":
+        p = bsm.synthetic.config2(n=12000, nblocks=700)
+    else:
+        p = fixture_problem("cuboid", np.float64, "real")
+    A = bsm.synthetic.build(p)
+    n = p["size"][0]
+    rng = np.random.default_rng(17)
+    for op in (N, T):
+        Aop = wrap(bsm, A, op)
+        for k in range(1, 10):
+            X = np.full((n, k + 2), np.nan)
+            X[:, :k] = rng.standard_normal((n, k))
+            Y0 = np.full((n, k + 2), 7.25)
+            Y0[:, :k] = rng.standard_normal((n, k))
+            Xd = torch.from_numpy(np.ascontiguousarray(X.T)).cuda().t()   # column-major n x (k + 2)
+            Yd = torch.from_numpy(np.ascontiguousarray(Y0.T)).cuda().t()
+            bsm.mul(Yd[:, :k], Aop, Xd[:, :k], 0.5, -2.0)
+            torch.cuda.synchronize()
+            got = Yd.cpu().numpy()
+            assert np.all(got[:, k:] == 7.25), (op, k)
+            ref = np.stack([oracle_mul(oracle, p, op, X[:, j].copy(), Y0[:, j].copy(), 0.5, -2.0, False) for j in range(k)], axis=1)
+            assert relerr(got[:, :k].ravel(), ref.ravel()) < 1e-12, (op, k)
+
+
 # ---- BASELINE.json's big configs at the size ONE GPU of eight owns: size-independent properties ------
 def _dot(a, b):
     return float(np.dot(a.astype(np.float64), b.astype(np.float64)))

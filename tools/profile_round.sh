@@ -42,6 +42,7 @@ KB_TIMG=1 python3 tools/kbench.py c2 500 T >> $O/r03_c2_transposed.txt 2>&1 || t
 python3 tools/hostpath.py > $O/r03_hostpath.txt 2>&1 || true
 for c in c3 c5s; do python3 tools/distbench.py $c; done > $O/r03_distbench.txt 2> /dev/null
 python3 tools/multirhs.py > $O/r03_multirhs.txt 2> /dev/null
+{ echo "nrhs = 1..9 right-hand sides in single products (tools/mrhs_sweep.py; batches of 8 / 4, padded remainders):"; python3 tools/mrhs_sweep.py c3 c5s c4s bem_f64 2> /dev/null; } > $O/r03_multirhs_sweep.txt
 # 7. multi-RHS products: SQ / LDS counters (two --pmc passes each) and the timing-only ablations of the pipelined
 #    kernel (experiment build)
 { echo "Multi right-hand-side products (bsm_mul_multi), rocprofv3 --kernel-trace --pmc (two passes), tools/mrhs_one.py, 6 dispatches each;"
