@@ -266,10 +266,11 @@ int bsm_host_unregister(void *ptr);
 
 /* Y = alpha * op(A) * X + beta * Y for nrhs right-hand sides -- `A * X` / `mul!(Y, A, X, a, b)`
  * with matrices.  LinearMaps loops the columns of X through _unsafe_mul! (nrhs full sweeps of A);
- * here A is streamed ONCE per batch of up to 8 columns.  X is size(op(A),2) x nrhs and Y is
- * size(op(A),1) x nrhs, both column-major with leading dimensions ldx / ldy (elements).
- * Every other argument as in bsm_mul; each column gives bit-for-bit what nrhs = 1 semantics
- * prescribe (same alpha, beta, strong zero). */
+ * here A is streamed ONCE per batch of up to 8 columns (a remainder of 2-7 columns is one padded
+ * pass; nothing outside the nrhs columns of X and Y is read or written).  X is size(op(A),2) x nrhs
+ * and Y is size(op(A),1) x nrhs, both column-major with leading dimensions ldx / ldy (elements).
+ * Every other argument as in bsm_mul; each column gives what nrhs = 1 semantics prescribe (same
+ * alpha, beta, strong zero). */
 int bsm_mul_multi(bsm_matrix_t A, int op, int64_t nrhs, const void *X, int64_t ldx, void *Y,
                   int64_t ldy, const void *alpha, const void *beta, int beta_strong_zero, int memspace,
                   void *stream);
