@@ -1441,8 +1441,16 @@ static hipError_t launch_multi_typed(const DeviceImage &img, bool opT, bool conj
     // C4 -- and two single products over short panels, where the pass would cost 2.6)
     if (e == hipSuccess && (nrhs - k >= 3 || (nrhs - k == 2 && img.lane_fill >= 0.85f))) {
         const int rem = (int)(nrhs - k);  // 2, 3 or 4
-        e = launch_typed_multi<T, 8, 4>(img, opT, conj, xd + k * ldx, ldx, yd + k * ldy, ldy, alpha, beta,
-                                        strong_zero, stream, zrange, rem);
+        // (real arithmetic and a transposed half in the product: L = 4, i.e. the tile-pipelined kernels -- BEM fp64
+        // x 4 249 -> 211 us, C3 / C5 +-0; forward-only launches and complex: 8 loads per lane on the register path,
+        // C4 slice x 4 1.10 vs 1.16 single products with L = 4)
+        const bool fwd_only = !opT && (img.exclusive_fwd || !img.has_off);
+        if (kRealType<T> && !fwd_only)
+            e = launch_typed_multi<T, 4, 4>(img, opT, conj, xd + k * ldx, ldx, yd + k * ldy, ldy, alpha, beta,
+                                            strong_zero, stream, zrange, rem);
+        else
+            e = launch_typed_multi<T, 8, 4>(img, opT, conj, xd + k * ldx, ldx, yd + k * ldy, ldy, alpha, beta,
+                                            strong_zero, stream, zrange, rem);
         k += rem;
     }
     for (; e == hipSuccess && k < nrhs; ++k)
