@@ -747,7 +747,7 @@ __device__ __forceinline__ void run_panel_multi(const WaveD &wd, const uint4 *__
                                                 const int *__restrict__ rows,
                                                 const int *__restrict__ cols, const T *__restrict__ x,
                                                 long long ldx, T *__restrict__ y, long long ldy, T alpha,
-                                                int flags, int lane, T *xs, Vec16<T> *tile, int *ci, T (&out)[K]) {
+                                                int flags, int lane, T *xs, Vec16<T> *tile, T (&out)[K]) {
     constexpr int E = TT<T>::E;
     constexpr int G = 64 / P;
     constexpr int NC = G * L * E;
@@ -878,17 +878,26 @@ __device__ __forceinline__ void run_panel_multi(const WaveD &wd, const uint4 *__
                         if (yi >= 0 && k < kact) atomic_acc(&y[yi + k * ldy], mul(alpha, dq_val[jj]));
                     }
                 };
-                // a slice of columns: x values (forward half) and the gathered indices
+                // a slice of columns: x values (forward half) and the gathered indices.  The indices stay in
+                // REGISTERS, lane c of cir[q] holding column q * 64 + c of the slice, and are fetched across lanes
+                // (ds_bpermute) when a lane emits: an LDS array of them was the 256 bytes per wave that kept a fourth
+                // workgroup of the 4-column fp64 kernel off the CU.
+                int cir[XCH / 64];
+#pragma unroll
+                for (int q = 0; q < XCH / 64; ++q) cir[q] = 0;
                 auto stage_slice = [&](int c0) {
 #pragma unroll
                     for (int q = 0; q < XCH / 64; ++q) {
                         const int c = q * 64 + lane;
                         const int w = c0 + c;
+                        if (xbase < 0) {
+                            // (waited for HERE: a loaded register whose first use lies in the loop body makes hipcc
+                            // wait vmcnt(0) there in every iteration, which drains the prefetched tile)
+                            cir[q] = cols[col_off + min(w, ncols - 1)];
+                            settle(cir[q]);
+                        }
                         if (w < ncols + NC) {
                             bool ok = w < ncols, off = false;
-                            // (load and LDS write in ONE block: a loaded register that some path never
-                            // reads stays pending for hipcc, which then waits vmcnt(0) before every reuse)
-                            if (xbase < 0) ci[c] = ok ? cols[col_off + w] : 0;
                             if (fwd_en) {
                                 const int xi = ok ? col_lookup(w, off) : 0;
                                 ok = ok && (!opT || off);
@@ -959,11 +968,19 @@ __device__ __forceinline__ void run_panel_multi(const WaveD &wd, const uint4 *__
 #pragma unroll
                     for (int q = 0; q < NE; ++q) {
                         const int w = s * E + pos / K + q;
+                        int raw = 0;
+                        if (xbase < 0) {  // (every lane takes part in the exchange)
+                            const int c = (w - c0) & (XCH - 1);
+#pragma unroll
+                            for (int h = 0; h < XCH / 64; ++h) {
+                                const int v = __shfl(cir[h], c & 63, 64);
+                                if ((c >> 6) == h) raw = v;
+                            }
+                        }
                         int yi = -1;
                         if (mine && w < ncols) {
                             bool off;
                             if (xbase < 0) {
-                                const int raw = ci[w - c0];
                                 off = raw >= 0 && (kinds & 3) == KIND_OFF;
                                 yi = raw & 0x7fffffff;
                             } else {
@@ -1094,7 +1111,6 @@ __global__ void __launch_bounds__(64 * kWavesPerWg, (kTilePipe<T, L, TRN> && siz
     constexpr int TILE = PIPE ? 2 * L * 64 : L * 72;
     __shared__ __attribute__((aligned(16))) T xs[kWavesPerWg][FWD ? XS : 1];
     __shared__ Vec16<T> tl[kWavesPerWg][TRN ? TILE : 1];
-    __shared__ int ci[kWavesPerWg][PIPE ? XCH : 1];  // the slice's gathered column indices
 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -1107,13 +1123,13 @@ __global__ void __launch_bounds__(64 * kWavesPerWg, (kTilePipe<T, L, TRN> && siz
     for (int k = 0; k < K; ++k) u[k] = zero_of(T{});
     if (work == WORK_PANEL) {
         if (m <= 8)
-            run_panel_multi<T, L, 8, FWD, TRN, K>(wd, values, rows, cols, x, ldx, y, ldy, alpha, flags, lane, xs[wave], tl[wave], ci[wave], u);
+            run_panel_multi<T, L, 8, FWD, TRN, K>(wd, values, rows, cols, x, ldx, y, ldy, alpha, flags, lane, xs[wave], tl[wave], u);
         else if (m <= 16)
-            run_panel_multi<T, L, 16, FWD, TRN, K>(wd, values, rows, cols, x, ldx, y, ldy, alpha, flags, lane, xs[wave], tl[wave], ci[wave], u);
+            run_panel_multi<T, L, 16, FWD, TRN, K>(wd, values, rows, cols, x, ldx, y, ldy, alpha, flags, lane, xs[wave], tl[wave], u);
         else if (m <= 32)
-            run_panel_multi<T, L, 32, FWD, TRN, K>(wd, values, rows, cols, x, ldx, y, ldy, alpha, flags, lane, xs[wave], tl[wave], ci[wave], u);
+            run_panel_multi<T, L, 32, FWD, TRN, K>(wd, values, rows, cols, x, ldx, y, ldy, alpha, flags, lane, xs[wave], tl[wave], u);
         else
-            run_panel_multi<T, L, 64, FWD, TRN, K>(wd, values, rows, cols, x, ldx, y, ldy, alpha, flags, lane, xs[wave], tl[wave], ci[wave], u);
+            run_panel_multi<T, L, 64, FWD, TRN, K>(wd, values, rows, cols, x, ldx, y, ldy, alpha, flags, lane, xs[wave], tl[wave], u);
     }
     const bool direct = (flags & FLAG_DIRECT) != 0;
     const bool sz = (flags & FLAG_STRONG_ZERO) != 0;
