@@ -689,7 +689,7 @@ template <> constexpr bool kRealType<float> = true;
 template <> constexpr bool kRealType<double> = true;
 // which multi-RHS kernels run the tile pipeline: the transposed / fused 8-column ones in real arithmetic (the
 // complex ones are at the register limit as they are: c64 fused 242 -> 256 VGPRs + scratch with it)
-template <typename T, int L, bool TRN> constexpr bool kTilePipe = TRN && L == 4 && kRealType<T>;
+template <typename T, int L, bool TRN, int K> constexpr bool kTilePipe = TRN && L == 4 && kRealType<T> && K >= 4;
 template <typename T, int L> constexpr int x_chunk_cols_pipe() {
     return 8 * L * TT<T>::E > 64 ? 8 * L * TT<T>::E : 64;
 }
@@ -741,6 +741,14 @@ template <typename T> __device__ __forceinline__ void settle(T &v) {
     static_assert(sizeof(T) == 4 || sizeof(T) == 8, "one or two registers");
     asm volatile("" : "+v"(v));
 }
+__device__ __forceinline__ void settle(c64 &v) {
+    settle(v.re);
+    settle(v.im);
+}
+__device__ __forceinline__ void settle(c128 &v) {
+    settle(v.re);
+    settle(v.im);
+}
 
 template <typename T, int L, int P, bool FWD, bool TRN, int K>
 __device__ __forceinline__ void run_panel_multi(const WaveD &wd, const uint4 *__restrict__ values,
@@ -751,7 +759,7 @@ __device__ __forceinline__ void run_panel_multi(const WaveD &wd, const uint4 *__
     constexpr int E = TT<T>::E;
     constexpr int G = 64 / P;
     constexpr int NC = G * L * E;
-    constexpr bool PIPE = kTilePipe<T, L, TRN>;  // matrix tiles prefetched into LDS (below)
+    constexpr bool PIPE = kTilePipe<T, L, TRN, K>;  // matrix tiles prefetched into LDS (below)
     constexpr int XCH = PIPE ? x_chunk_cols_pipe<T, L>() : x_chunk_cols_multi<T, K>();
     static_assert(XCH % NC == 0, "x chunk must hold whole iterations");
     const bool opT = (flags & FLAG_OPT) != 0;
@@ -1099,12 +1107,12 @@ __device__ __forceinline__ void run_panel_multi(const WaveD &wd, const uint4 *__
 // LDS admits 3; fused: 189 VGPRs = 2 per CU without the bound, 168 + 16 spilled dwords with it: C3 in fp32 x 8
 // 176 -> 159 us), 2 otherwise (the fp64 ones fit 3 by themselves)
 template <typename T, int L, bool FWD, bool TRN, int K>
-__global__ void __launch_bounds__(64 * kWavesPerWg, (kTilePipe<T, L, TRN> && sizeof(T) == 4 ? 3 : 2))
+__global__ void __launch_bounds__(64 * kWavesPerWg, (kTilePipe<T, L, TRN, K> && sizeof(T) == 4 ? 3 : 2))
     panel_kernel_multi(const WaveWork *__restrict__ waves, const uint4 *__restrict__ values,
                        const int *__restrict__ rows, const int *__restrict__ cols,
                        const T *__restrict__ x, long long ldx, T *__restrict__ y, long long ldy, T alpha,
                        T beta, int flags, unsigned wg_base) {
-    constexpr bool PIPE = kTilePipe<T, L, TRN>;
+    constexpr bool PIPE = kTilePipe<T, L, TRN, K>;
     constexpr int XCH = PIPE ? x_chunk_cols_pipe<T, L>() : x_chunk_cols_multi<T, K>();
     constexpr int XS = XCH * K;  // >= 64*K: also holds the combine slab
     // 16-byte units: max over P of (64 / P) * L strips of P + 1 units; the pipelined kernels hold two tiles
@@ -1461,7 +1469,7 @@ static hipError_t launch_multi_typed(const DeviceImage &img, bool opT, bool conj
         // x 4 249 -> 211 us, C3 / C5 +-0; forward-only launches and complex: 8 loads per lane on the register path,
         // C4 slice x 4 1.10 vs 1.16 single products with L = 4)
         const bool fwd_only = !opT && (img.exclusive_fwd || !img.has_off);
-        if (kRealType<T> && !fwd_only)
+        if ((kRealType<T> || sizeof(T) == 16) && !fwd_only)  // (ComplexF64: L = 4 on the register path, BEM x 4 518 -> 490 us)
             e = launch_typed_multi<T, 4, 4>(img, opT, conj, xd + k * ldx, ldx, yd + k * ldy, ldy, alpha, beta,
                                             strong_zero, stream, zrange, rem);
         else

@@ -50,6 +50,7 @@ CASES = {
     "c4s": lambda: S.config4(on_device=True, row_lo=0, row_hi=1953),
     "c5s": lambda: S.config5(n=625_000, on_device=True),
     "bem_c128": lambda: bem(400, np.complex128, "full"),
+    "bem_c64": lambda: bem(400, np.complex64, "full"),
     "bem_f64": lambda: bem(400, np.float64, "real"),
 }
 names = sys.argv[1:] or list(CASES)
