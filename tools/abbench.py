@@ -34,6 +34,8 @@ CASES = {
     "c5s": lambda: S.config5(n=625_000, on_device=True),
     "bem_c128": lambda: bem(400, np.complex128, "full"),
     "bem_f64": lambda: bem(400, np.float64, "real"),
+    "bem_c64": lambda: bem(400, np.complex64, "full"),
+    "bem_f32": lambda: bem(400, np.float32, "real"),
 }
 names = sys.argv[1:] or list(CASES)
 tag = os.path.basename(os.environ.get("BSM_LIB", "libbsmrocm.so"))
