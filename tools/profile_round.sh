@@ -34,7 +34,8 @@ python3 tools/pmc_summary.py mfma $O/r03_c4_mfma.json "panel_kernel<float" $O/pm
 find $O/kt -name "*kernel_stats.csv" -exec cp {} $O/r03_c2_bench_default_kernel_stats.csv \;
 python3 tools/kt_summary.py $O/kt $O/r03_c2_bench_default_kernel_trace_by_grid.csv > /dev/null
 head -12 $O/r03_c2_bench_default_kernel_trace_by_grid.csv
-# 6. un-profiled reference runs
+# 6. un-profiled reference runs (bench.py reads the counter files of THIS build: copy them where it looks first)
+cp $O/r03_c2_pmc.json $O/r03_c4_mfma.json $R/profiles/
 python3 bench.py > $O/r03_bench_c2_n1.json 2> /dev/null
 python3 tools/abbench.py > $O/r03_abbench.txt 2> /dev/null
 python3 tools/kbench.py c2 500 T > $O/r03_c2_transposed.txt 2>&1 || true
