@@ -687,8 +687,9 @@ template <typename T, int K> constexpr int x_chunk_cols_multi() {
 template <typename T> constexpr bool kRealType = false;
 template <> constexpr bool kRealType<float> = true;
 template <> constexpr bool kRealType<double> = true;
-// which multi-RHS kernels run the tile pipeline: the transposed / fused 8-column ones in real arithmetic (the
-// complex ones are at the register limit as they are: c64 fused 242 -> 256 VGPRs + scratch with it)
+// which multi-RHS kernels run the tile pipeline: the transposed / fused 8- and 4-column ones in real arithmetic
+// with 4 loads per lane (the complex 8-column ones are at the register limit as they are: c64 fused 242 -> 256
+// VGPRs + scratch with it; the ComplexF64 4-column one gains nothing over its register path: 487 vs 490 us)
 template <typename T, int L, bool TRN, int K> constexpr bool kTilePipe = TRN && L == 4 && kRealType<T> && K >= 4;
 template <typename T, int L> constexpr int x_chunk_cols_pipe() {
     return 8 * L * TT<T>::E > 64 ? 8 * L * TT<T>::E : 64;
@@ -714,7 +715,7 @@ template <int P, int L> __device__ __forceinline__ constexpr int tile_swz(int s)
 
 // 16 bytes per lane from global memory straight into LDS (global_load_lds_dwordx4 ... nt): lane l's bytes land
 // at lds_dst + 16 * l, lds_dst wave-uniform.  No VGPR destination and hipcc does not count it: the caller waits
-// with vm_wait<N>() (loads, atomics and these complete in issue order).
+// with vm_wait(n) (loads, atomics and these complete in issue order).
 __device__ __forceinline__ void glds16_nt(const void *gsrc, unsigned lds_dst) {
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
@@ -740,14 +741,6 @@ __device__ __forceinline__ void vm_wait(int younger) {  // wave-uniform: all but
 template <typename T> __device__ __forceinline__ void settle(T &v) {
     static_assert(sizeof(T) == 4 || sizeof(T) == 8, "one or two registers");
     asm volatile("" : "+v"(v));
-}
-__device__ __forceinline__ void settle(c64 &v) {
-    settle(v.re);
-    settle(v.im);
-}
-__device__ __forceinline__ void settle(c128 &v) {
-    settle(v.re);
-    settle(v.im);
 }
 
 template <typename T, int L, int P, bool FWD, bool TRN, int K>
@@ -840,7 +833,7 @@ __device__ __forceinline__ void run_panel_multi(const WaveD &wd, const uint4 *__
             // operations does the bookkeeping: the wait for tile n is `all but tile n+1's loads`, which also
             // covers every older atomic -- so iteration n's y contributions are issued AFTER that wait in
             // iteration n+1 (held in CF registers meanwhile), and nothing else in the loop may load from global
-            // memory: gathered column lists are staged in LDS with the x slice.
+            // memory: a slice's gathered column indices are fetched with its x values and kept (in registers).
             {
                 constexpr int NSI = G * L;
                 constexpr int CF = (E * K / RG) > 1 ? (E * K / RG) : 1;
