@@ -273,6 +273,26 @@ hipError_t upload_image(Analysis &an, DeviceImage &img, int dev) {
         }
     }
     if (e == hipSuccess) an.values.release();  // packed host copy no longer needed
+    if (std::getenv("BSM_PLACEMENT_DEBUG") && e == hipSuccess && an.value_bytes >= (64 << 20)) {
+        // developer probe (tools/placement_which.py): where the image landed, and what a BARE streaming read of its
+        // value stream takes there
+        void *sink = nullptr;
+        hipEvent_t a, b;
+        float ms = 0.f;
+        if (hipMalloc(&sink, 8192) == hipSuccess && hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess) {
+            for (int r = 0; r < 3; r++) (void)launch_stream_floor(img.d_values, an.value_bytes / 16 * 16, sink, nullptr, nullptr);
+            (void)hipEventRecord(a, nullptr);
+            for (int r = 0; r < 10; r++) (void)launch_stream_floor(img.d_values, an.value_bytes / 16 * 16, sink, nullptr, nullptr);
+            (void)hipEventRecord(b, nullptr);
+            (void)hipEventSynchronize(b);
+            (void)hipEventElapsedTime(&ms, a, b);
+            (void)hipEventDestroy(a);
+            (void)hipEventDestroy(b);
+            (void)hipFree(sink);
+        }
+        std::fprintf(stderr, "[bsm image] values %p (%lld B) bare stream %.1f us | rows %p cols %p waves %p (%zu)\n", img.d_values,
+                     (long long)an.value_bytes, ms * 100.f, img.d_rows, img.d_cols, img.d_waves, an.waves.size());
+    }
     return e;
 }
 

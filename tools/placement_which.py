@@ -1,11 +1,14 @@
 #!/usr/bin/env python3
 """Developer probe: WHICH allocation carries the placement effect of a long fused launch (C5 slice 533 / 578 us with the
-same schedule)?  One handle with several y / x allocations, then one y with several handles."""
+same schedule)?  One handle with several y / x allocations, then one y with several handles.
+usage: placement_which.py [c5s|c2x20]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, bsm_amd as bsm
 S = bsm.synthetic
-p = S.config5(n=600_000, on_device=True)
+which = sys.argv[1] if len(sys.argv) > 1 else "c5s"
+p = {"c5s": lambda: S.config5(n=600_000, on_device=True),
+     "c2x20": lambda: S.config2(n=2_000_000, nblocks=100_000, on_device=True)}[which]()
 x0 = p["x"]
 
 
