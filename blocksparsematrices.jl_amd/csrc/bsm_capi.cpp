@@ -1110,6 +1110,30 @@ extern "C" int bsm_get_image(bsm_matrix_t A, int which, void *out, int64_t *nbyt
     return BSM_OK;
 }
 
+// Developer probe (tools/placement_move.py; not declared in the public header): moves one array of a device image
+// to a fresh allocation -- which = 0 values, 1 rows, 2 cols, 3 wave records -- to find out which one a handle's
+// "placement level" depends on.
+extern "C" int bsm_debug_move_image_array(bsm_matrix_t A, int which) {
+    if (!A || !A->on_device || A->dist) return fail(BSM_ERR_INVALID, "needs a single-device handle");
+    DeviceGuard guard;
+    hipError_t e = guard.enter(A->img.device);
+    if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
+    void **slot = which == 0 ? &A->img.d_values : which == 1 ? &A->img.d_rows : which == 2 ? &A->img.d_cols : &A->img.d_waves;
+    const size_t bytes = which == 0 ? (size_t)A->an.value_bytes
+                         : which == 1 ? A->an.rows.size() * 4
+                         : which == 2 ? A->an.cols.size() * 4
+                                      : A->an.waves.size() * sizeof(WaveWork);
+    if (!*slot || bytes == 0) return BSM_OK;
+    void *fresh = nullptr;
+    if ((e = hipDeviceSynchronize()) != hipSuccess) return hip_fail(e, "sync");
+    if ((e = hipMalloc(&fresh, bytes)) != hipSuccess) return hip_fail(e, "hipMalloc");
+    if ((e = hipMemcpy(fresh, *slot, bytes, hipMemcpyDeviceToDevice)) != hipSuccess) return hip_fail(e, "copy");
+    (void)hipFree(*slot);
+    *slot = fresh;
+    if (std::getenv("BSM_PLACEMENT_DEBUG")) std::fprintf(stderr, "[bsm image] array %d now at %p (%zu B)\n", which, fresh, bytes);
+    return BSM_OK;
+}
+
 extern "C" int bsm_stats(bsm_matrix_t A, bsm_stats_t *out) {
     if (!A || !out) return fail(BSM_ERR_INVALID, "null argument");
     std::memset(out, 0, sizeof *out);
