@@ -104,6 +104,22 @@ int main(int argc, char **argv) {
         CHECK(bsm_mul(S, BSM_OP_N, x, y, NULL, NULL, 1, BSM_MEM_HOST, NULL));
         printf("SymmetricBlockMatrix KAT y = [%g %g %g %g]\n", y[0], y[1], y[2], y[3]);
         if (y[0] != 11 || y[1] != 14 || y[2] != 1 || y[3] != 2) return 1;
+        /* A * X with 5 right-hand sides (bsm_mul_multi: ONE padded 8-column pass over A instead of LinearMaps' five
+         * sweeps): column j = (j + 1) * x, so Y[:, j] = (j + 1) * [11, 14, 1, 2]; column-major, leading dimension 6 */
+        double X5[5 * 6], Y5[5 * 6];
+        for (int j = 0; j < 5; j++)
+            for (int i = 0; i < 6; i++) {
+                X5[j * 6 + i] = i < 4 ? (j + 1) * x[i] : -99;  /* rows 4, 5: padding of the leading dimension */
+                Y5[j * 6 + i] = -7;
+            }
+        CHECK(bsm_mul_multi(S, BSM_OP_N, 5, X5, 6, Y5, 6, NULL, NULL, 1, BSM_MEM_HOST, NULL));
+        for (int j = 0; j < 5; j++)
+            if (Y5[j * 6] != 11 * (j + 1) || Y5[j * 6 + 1] != 14 * (j + 1) || Y5[j * 6 + 2] != 1 * (j + 1) ||
+                Y5[j * 6 + 3] != 2 * (j + 1) || Y5[j * 6 + 4] != -7 || Y5[j * 6 + 5] != -7) {
+                fprintf(stderr, "bsm_mul_multi mismatch in column %d\n", j);
+                return 1;
+            }
+        printf("SymmetricBlockMatrix * X (5 columns): Y[:, 4] = [%g %g %g %g]\n", Y5[24], Y5[25], Y5[26], Y5[27]);
         CHECK(bsm_destroy(A));
         CHECK(bsm_destroy(S));
         /* the same symmetric KAT with the handle spread over a context of TWO (virtual) devices: the
