@@ -34,8 +34,8 @@ if "--full" in sys.argv:  # the complete 8-GPU configs on ONE MI355X (16.4 GB / 
         ("C4 VBCRS 2M^2, 250000x 128x128 fp32, FULL on one GPU", lambda: S.config4(), 1),
         ("C5 Symmetric 5M^2, sizes 16-256 fp64, FULL on one GPU", lambda: S.config5(), 1),
     ]
-lines = ["| config | CPU port 1 core GB/s (-O3 -march=native, pre-marshalled) | GPU N GB/s (% of 8 TB/s) | GPU T GB/s | rel-err N | rel-err T | alg MB |",
-         "|---|---|---|---|---|---|---|"]
+lines = ["| config | CPU port 1 core GB/s (-O3 -march=native, pre-marshalled) | GPU N GB/s (% of 8 TB/s) | GPU T GB/s | rel-err N | rel-err T | alg MB | A*X, 4 / 8 columns (single products; worst column vs single products) |",
+         "|---|---|---|---|---|---|---|---|"]
 for name, make, share in CONFIGS:
     prob = make()
     A = S.build(prob)
@@ -77,8 +77,35 @@ for name, make, share in CONFIGS:
         out[opname] = (st["alg_bytes"] / tt / 1e9, tol_ref, tt)
     g, e, tt = out["N"]
     gt, et, _ = out["T"]
+    # A * X (bsm_mul_multi): cost in single products, parity of every column against its own single product
+    multi = []
+    xd = torch.from_numpy(x).cuda()
+    y1 = torch.zeros(nr, dtype=xd.dtype, device="cuda")
+    for K in (4, 8):
+        X = torch.empty((K, nc), dtype=xd.dtype, device="cuda").t()
+        for k in range(K):
+            X[:, k] = xd * (k + 1) / K
+        Y = torch.zeros((K, nr), dtype=xd.dtype, device="cuda").t()
+        for _ in range(30):  # (the first tens of launches of a kernel on a fresh operator run 5-8 % slower)
+            bsm.mul(Y, A, X)
+        torch.cuda.synchronize()
+        r = 100 if st["alg_bytes"] < 2e8 else 15
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(r):
+            bsm.mul(Y, A, X)
+        b.record()
+        torch.cuda.synchronize()
+        tk = a.elapsed_time(b) * 1e-3 / r
+        worst = 0.0
+        for k in range(K):
+            bsm.mul(y1, A, X[:, k].contiguous())
+            worst = max(worst, float((Y[:, k] - y1).abs().max() / y1.abs().max()))
+        multi.append((tk / tt, worst))
+        del X, Y
     lines.append(f"| {name} | {cpu:.2f} | {g:.0f} ({100 * g / 8000:.0f} %, {tt * 1e6:.1f} us) | {gt:.0f} | "
-                 f"{e:.1e} | {et:.1e} | {st['alg_bytes'] / 1e6:.1f} |")
+                 f"{e:.1e} | {et:.1e} | {st['alg_bytes'] / 1e6:.1f} | {multi[0][0]:.2f} / {multi[1][0]:.2f} "
+                 f"({max(multi[0][1], multi[1][1]):.0e}) |")
     print(lines[-1], flush=True)
     del A, prob
 text = "\n".join(lines)
