@@ -200,11 +200,29 @@ def self_launch(args):
         sk.close()
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
                "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + forwarded + extra
+        # the launcher and its ranks form their own process group: on a timeout the WHOLE group is ended (killing
+        # only the launcher would leave the ranks on the GPUs while the retry starts)
+        import signal
+        proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, start_new_session=True)
         try:
-            r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, timeout=limit)
-            rc, out = r.returncode, r.stdout.decode(errors="replace")
-        except subprocess.TimeoutExpired as e:
-            rc, out = 124, (e.stdout or b"").decode(errors="replace")
+            raw, _ = proc.communicate(timeout=limit)
+            rc, out = proc.returncode, raw.decode(errors="replace")
+        except subprocess.TimeoutExpired:
+            for sig, grace in ((signal.SIGTERM, 10), (signal.SIGKILL, 20)):
+                try:
+                    os.killpg(proc.pid, sig)
+                except ProcessLookupError:
+                    break
+                try:
+                    proc.wait(timeout=grace)
+                    break
+                except subprocess.TimeoutExpired:
+                    continue
+            try:
+                raw, _ = proc.communicate(timeout=10)
+            except Exception:
+                raw = b""
+            rc, out = 124, (raw or b"").decode(errors="replace")
         line = None
         for ln in out.splitlines():
             ln = ln.strip()
@@ -212,12 +230,13 @@ def self_launch(args):
                 line = ln
         return rc, line, out
 
-    rc, line, out = attempt([], 1500)
+    # both attempts together stay inside the driver's own limit for one bench run (25 minutes)
+    rc, line, out = attempt([], 780)
     if line is None and args.backend == "nccl":
         print(f"[bench] the {args.gpus}-rank RCCL run ended with status {rc} and no result line; "
               "one more attempt with the exchanges over gloo", file=sys.stderr, flush=True)
         sys.stderr.write(out[-4000:])
-        rc, line, out = attempt(["--backend", "gloo", "--note", f"the RCCL run ended with status {rc} before its line"], 1500)
+        rc, line, out = attempt(["--backend", "gloo", "--note", f"the RCCL run ended with status {rc} before its line"], 600)
     if line is None:
         sys.stdout.write(out)
         return rc or 1

@@ -714,18 +714,29 @@ extern "C" int bsm_ctx_create(const int32_t *device_ids, int32_t ndevices, bsm_c
         }
         // direct xGMI access between every pair of distinct devices (the halo copies then run device
         // to device; without it the runtime stages them through host memory, still correct)
+        // (what the fused fan-out kernels of bsm_dist.cpp rely on is that the access was ENABLED, not that it is
+        // possible: only hipSuccess / "already enabled" count, anything else leaves the context on the copy path)
+        ctx->peer_ok = true;
         for (int a : ctx->devices)
             for (int b : ctx->devices) {
                 if (a == b) continue;
                 int can = 0;
                 if (hipDeviceCanAccessPeer(&can, a, b) != hipSuccess || !can) {
                     (void)hipGetLastError();
+                    ctx->peer_ok = false;
                     continue;
                 }
                 DeviceGuard g;
-                if (g.enter(a) != hipSuccess) continue;
-                hipError_t pe = hipDeviceEnablePeerAccess(b, 0);
-                if (pe != hipSuccess) (void)hipGetLastError();  // already enabled
+                if (g.enter(a) != hipSuccess) {
+                    (void)hipGetLastError();
+                    ctx->peer_ok = false;
+                    continue;
+                }
+                const hipError_t pe = hipDeviceEnablePeerAccess(b, 0);
+                if (pe != hipSuccess) {
+                    (void)hipGetLastError();
+                    if (pe != hipErrorPeerAccessAlreadyEnabled) ctx->peer_ok = false;
+                }
             }
         *out = ctx.release();
         return BSM_OK;)

@@ -431,17 +431,7 @@ int dist_create(bsm_matrix_s *A, bsm_ctx_s *ctx, int mtype, int dtype, int64_t n
         if (e == hipSuccess && rb) e = hipMalloc(&pt.d_recv, rb);
         if (e != hipSuccess) return hip_fail(e, "multi-device buffers");
     }
-    D.all_peer = true;
-    for (int a : ctx->devices)
-        for (int b : ctx->devices) {
-            if (a == b) continue;
-            int can = 0;
-            if (hipDeviceCanAccessPeer(&can, a, b) != hipSuccess) {
-                (void)hipGetLastError();
-                can = 0;
-            }
-            D.all_peer = D.all_peer && can != 0;
-        }
+    D.all_peer = ctx->peer_ok;  // enabled for every pair when the context was created (bsm_ctx_create)
     if (const char *v = std::getenv("BSM_DIST_COPIES")) D.all_peer = D.all_peer && std::atoi(v) == 0;  // tests: force the copy path
     // one persistent issuing thread per device from five parts on (BSM_DIST_WORKERS = smallest part count that
     // gets them): below, the calling thread issues everything faster than the threads can be woken twice
@@ -464,6 +454,11 @@ static hipError_t grow_buffers(DistState &D, int K) {
         if (e == hipSuccess) e = hipStreamSynchronize(D.parts[p]->stream);
     }
     if (e == hipSuccess && D.ev_tail) e = hipEventSynchronize(D.ev_tail);
+    // the fused path works on the CALLERS' streams (run[p] = the part's caller stream), and a peer's finish kernel
+    // reads this part's work vector over xGMI: ev_done is recorded on run[p] after the part's last use of the
+    // buffers, so every part's ev_done has to be reached too before the first buffer is freed
+    if (D.produced)
+        for (int p = 0; p < P && e == hipSuccess; p++) e = hipEventSynchronize(D.parts[p]->ev_done);
     for (int p = 0; p < P && e == hipSuccess; p++) {
         Part &pt = *D.parts[p];
         DeviceGuard g;
@@ -489,14 +484,17 @@ static hipError_t grow_buffers(DistState &D, int K) {
 struct VecSource {
     const char *base;   // virtual base: entry i of the global vector at base + i * es
     Range valid;        // entries this source holds
-    int device;
+    int device;         // where the MEMORY lives (decides reading in place)
+    int sdev;           // where the STREAM lives (a NULL stream is a different stream on every device): events of
+                        // this source are recorded there, and "same stream" means the same stream on that device
     hipStream_t stream; // where the entries are produced
     hipEvent_t ready;   // recorded on `stream` at the start of the call
     int strided;        // column k of a multi-RHS batch at + k * ldx (else the source holds one column)
 };
 struct VecDest {
     char *base;  // virtual base of the y entries
-    int device;
+    int device;  // where the memory lives (decides multiplying straight into y)
+    int sdev;    // where the stream lives
     hipStream_t stream;
     hipEvent_t ready;
 };
@@ -529,8 +527,8 @@ static int dist_mul_fused(DistState &D, int op, int K, const std::vector<VecSour
             hipError_t e2 = g.enter(dev);
             return e2 == hipSuccess ? hipEventRecord(ev, st) : e2;
         };
-        for (const VecSource &s : src) DCHECK(record(s.ready, s.stream, s.device), "hipEventRecord");
-        for (const VecDest &d : dst) DCHECK(record(d.ready, d.stream, d.device), "hipEventRecord");
+        for (const VecSource &s : src) DCHECK(record(s.ready, s.stream, s.sdev), "hipEventRecord");
+        for (const VecDest &d : dst) DCHECK(record(d.ready, d.stream, d.sdev), "hipEventRecord");
     }
     const bool was_produced = D.produced;
     // The stream a part's work is issued on.  bsm_mul_parts: the caller's stream of that part -- local work needs
@@ -542,7 +540,7 @@ static int dist_mul_fused(DistState &D, int op, int K, const std::vector<VecSour
         bool taken = false;
         for (int p = 0; p < P; p++) {
             const VecDest &yd = dst[dst.size() == 1 ? 0 : (size_t)p];
-            const bool mine = yd.device == D.parts[p]->device && (dst.size() > 1 || !taken);
+            const bool mine = yd.sdev == D.parts[p]->device && (dst.size() > 1 || !taken);
             run[p] = mine ? yd.stream : D.parts[p]->stream;
             if (mine) taken = true;
         }
@@ -585,7 +583,7 @@ static int dist_mul_fused(DistState &D, int op, int K, const std::vector<VecSour
                 DCHECK(hipStreamWaitEvent(st, pt.ev_done, 0), "hipStreamWaitEvent");  // its own previous delivery (another stream, perhaps)
                 if (D.ev_tail) DCHECK(hipStreamWaitEvent(st, D.ev_tail, 0), "hipStreamWaitEvent");
             }
-            DCHECK(wait_for(p, yd.ready, yd.stream, yd.device), "hipStreamWaitEvent");  // the incoming y (numeric beta) / its buffer
+            DCHECK(wait_for(p, yd.ready, yd.stream, yd.sdev), "hipStreamWaitEvent");  // the incoming y (numeric beta) / its buffer
             const Range zr = pl.zr[p];
             if (pt.has_image) {
                 const Range xr = pl.xr[p];
@@ -597,7 +595,7 @@ static int dist_mul_fused(DistState &D, int op, int K, const std::vector<VecSour
                 for (const VecSource &s : src) {
                     const Range o = isect(s.valid, xr);
                     if (o.empty()) continue;
-                    DCHECK(wait_for(p, s.ready, s.stream, s.device), "hipStreamWaitEvent");
+                    DCHECK(wait_for(p, s.ready, s.stream, s.sdev), "hipStreamWaitEvent");
                     if (o.lo == xr.lo && o.hi == xr.hi && s.device == pt.device) {  // everything it reads lies on its own device
                         xp = s.base;
                         xld = s.strided ? ldx : 0;
@@ -666,9 +664,9 @@ static int dist_mul_fused(DistState &D, int op, int K, const std::vector<VecSour
     // the consumers of y continue when the parts that deliver to them are done
     for (int q = 0; q < P; q++) {
         const VecDest &yd = dst[dst.size() == 1 ? 0 : (size_t)q];
-        if (yd.stream == run[(size_t)q] && yd.device == D.parts[q]->device) continue;  // delivered on the consumer's own stream
+        if (yd.stream == run[(size_t)q] && yd.sdev == D.parts[q]->device) continue;  // delivered on the consumer's own stream
         DeviceGuard g;
-        DCHECK(g.enter(yd.device), "hipSetDevice");
+        DCHECK(g.enter(yd.sdev), "hipSetDevice");
         DCHECK(hipStreamWaitEvent(yd.stream, D.parts[q]->ev_done, 0), "hipStreamWaitEvent");
     }
 #undef DCHECK
@@ -950,8 +948,8 @@ static int dist_mul_k(bsm_matrix_s *A, int op, int K, const void *x, long long l
                 it = D.ev_x.emplace(sdev, ev).first;
             }
             const long long xlen = (op == BSM_OP_N) ? D.ncols : D.nrows;
-            std::vector<VecSource> src{VecSource{(const char *)x, Range{0, xlen}, xdev, stream, it->second, 1}};
-            std::vector<VecDest> dst{VecDest{(char *)y, ydev, stream, it->second}};
+            std::vector<VecSource> src{VecSource{(const char *)x, Range{0, xlen}, xdev, sdev, stream, it->second, 1}};
+            std::vector<VecDest> dst{VecDest{(char *)y, ydev, sdev, stream, it->second}};
             return dist_mul_fused(D, op, K, src, ldx, dst, ldy, alpha, beta, beta_strong_zero);
         }
     }
@@ -977,8 +975,16 @@ int dist_mul_parts(bsm_matrix_s *A, int op, const void *const *x_parts, void *co
         if ((!in.empty() && !x_parts[p]) || (!out.empty() && !y_parts[p]))
             return fail(BSM_ERR_INVALID, "part " + std::to_string(p) + ": null vector part");
         hipStream_t st = streams ? (hipStream_t)streams[p] : nullptr;
-        src.push_back(VecSource{(const char *)x_parts[p] - (size_t)in.lo * es, in, pt.device, st, pt.ev_in, 0});
-        dst.push_back(VecDest{(char *)y_parts[p] - (size_t)out.lo * es, pt.device, st, pt.ev_in});
+        if (st) {
+            // like bsm_mul on a multi-device handle (include/bsm_rocm.h): the product waits for events of other streams
+            // and devices, which must not be recorded into a caller's graph
+            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+            if (hipStreamIsCapturing(st, &cs) != hipSuccess) (void)hipGetLastError();
+            if (cs != hipStreamCaptureStatusNone)
+                return fail(BSM_ERR_UNSUPPORTED, "a multi-device handle cannot be captured into a graph");
+        }
+        src.push_back(VecSource{(const char *)x_parts[p] - (size_t)in.lo * es, in, pt.device, pt.device, st, pt.ev_in, 0});
+        dst.push_back(VecDest{(char *)y_parts[p] - (size_t)out.lo * es, pt.device, pt.device, st, pt.ev_in});
     }
     return dist_mul_fused(D, op, 1, src, 0, dst, 0, alpha, beta, beta_strong_zero);
 }

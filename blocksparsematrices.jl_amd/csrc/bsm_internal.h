@@ -14,6 +14,9 @@
 
 struct bsm_ctx_s {
     std::vector<int> devices;  // HIP ordinals; the same ordinal may appear several times (virtual devices)
+    // peer access was ENABLED (hipSuccess or hipErrorPeerAccessAlreadyEnabled) for every ordered pair of distinct
+    // devices: the condition of the fused fan-out kernels, which dereference peer pointers directly
+    bool peer_ok = false;
 };
 
 namespace bsm {

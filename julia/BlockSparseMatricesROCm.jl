@@ -228,6 +228,32 @@ function pin!(v::Vector)
     return v
 end
 
+# mirrors bsm_part_info_t (include/bsm_rocm.h)
+struct BsmPartInfo
+    device::Int32; pad::Int32
+    own_lo::Int64; own_hi::Int64; touched_lo::Int64; touched_hi::Int64
+    device_bytes::Int64; nblocks::Int64; col_lo::Int64; col_hi::Int64
+    reserved::NTuple{2,Int64}
+end
+
+"""
+    part_ranges(A) -> Vector{(device, rows, cols)}
+
+The parts of a matrix spread over several GPUs (`ROCmScheduler(devices=[...])`): part p lives on `device`, owns the y
+entries `rows` and holds the x entries `cols` of a partitioned product (bsm_part_info; 1-based inclusive ranges).
+"""
+function part_ranges(A)
+    h = handle(_base(A))
+    n = length(_base(A).scheduler.devices)   # one part per listed device
+    out = NamedTuple{(:device, :rows, :cols),Tuple{Int32,UnitRange{Int64},UnitRange{Int64}}}[]
+    for p in 0:n-1
+        info = Ref(BsmPartInfo(0, 0, 0, 0, 0, 0, 0, 0, 0, 0, (0, 0)))
+        _check(ccall((:bsm_part_info, libbsm), Cint, (Ptr{Cvoid}, Int32, Ref{BsmPartInfo}), h.ptr, p, info))
+        push!(out, (device=info[].device, rows=info[].own_lo:info[].own_hi, cols=info[].col_lo:info[].col_hi))
+    end
+    return out
+end
+
 # ---- device-resident vectors (AMDGPU.jl) -----------------------------------------------------------------
 # Iterative solvers keep x / y in HBM: BSM_MEM_DEVICE, enqueued on the task-local HIP stream, no
 # synchronisation (the product is 10 us for a C2-sized operator against 74-118 us through host vectors).
@@ -254,6 +280,16 @@ if Base.find_package("AMDGPU") !== nothing
         function mul_parts!(yparts::Vector{<:AMDGPU.ROCVector{T}}, A::ROCmOp{Z}, xparts::Vector{<:AMDGPU.ROCVector{T}},
                 α::Number=true, β::Number=false) where {T<:ROCmEltype,Z<:ROCmMat}
             h = handle(_base(A))
+            # the C side reads one pointer per part and trusts the part lengths: check both here
+            pr = part_ranges(A)
+            (length(xparts) == length(pr) && length(yparts) == length(pr)) ||
+                throw(DimensionMismatch("mul_parts!: \$(length(pr)) parts, got \$(length(xparts)) x parts and \$(length(yparts)) y parts"))
+            for (p, r) in enumerate(pr)
+                # include/bsm_rocm.h at bsm_mul_parts: op N reads the column range and delivers the row range, op T / C the reverse
+                xr, yr = _op(A) == 0 ? (r.cols, r.rows) : (r.rows, r.cols)
+                (length(xparts[p]) == length(xr) && length(yparts[p]) == length(yr)) ||
+                    throw(DimensionMismatch("mul_parts!: part \$p holds x[\$(xr)] and y[\$(yr)]"))
+            end
             xp = Ptr{Cvoid}[Base.unsafe_convert(Ptr{Cvoid}, pointer(v)) for v in xparts]
             yp = Ptr{Cvoid}[Base.unsafe_convert(Ptr{Cvoid}, pointer(v)) for v in yparts]
             a = Ref(T(α)); b = Ref(T(β === false ? 0 : β))

@@ -252,6 +252,36 @@ def test_multi_rhs_through_the_multi_device_handle(torch_cuda, bsm, oracle, kind
                 assert relerr(Yh[:, k], refs[k]) < 1e-12, ("host", op, alpha, k)
 
 
+def test_single_product_then_a_wider_batch_without_a_sync_in_between(torch_cuda, bsm, oracle):
+    """A K = 1 product of a fresh multi-device handle, then -- NO synchronisation -- an 8-column product on the same
+    handle: the second call re-allocates the parts' work vectors for 8 columns while the fused finish kernels of the
+    first may still be reading them on the CALLERS' streams (grow_buffers must reach every part's ev_done
+    before the first free).  Both results against the oracle."""
+    torch = torch_cuda
+    prob = bsm.synthetic.config5(n=60_000, lo=16, hi=128, halfband=3)
+    n = prob["size"][0]
+    rng = np.random.default_rng(33)
+    x1 = rng.standard_normal(n)
+    X8 = np.asfortranarray(rng.standard_normal((n, 8)))
+    ref1 = oracle_mul(oracle, prob, N, x1, np.zeros(n))
+    ref8 = [oracle_mul(oracle, prob, N, np.ascontiguousarray(X8[:, k]), np.zeros(n)) for k in range(8)]
+    for rep in range(3):  # a fresh handle every time: the buffers start at one column
+        A = bsm.synthetic.build(prob, devices=[0, 0, 0])
+        xd = torch.from_numpy(x1).cuda()
+        yd = torch.full((n,), float("nan"), dtype=torch.float64, device="cuda")
+        Xd = torch.from_numpy(np.ascontiguousarray(X8.T)).cuda().t()
+        Yd = torch.full((8, n), float("nan"), dtype=torch.float64, device="cuda").t()
+        torch.cuda.synchronize()
+        bsm.mul(yd, A, xd)
+        bsm.mul(Yd, A, Xd)  # grows the buffers; nothing has been waited for
+        torch.cuda.synchronize()
+        assert relerr(yd.cpu().numpy(), ref1) < 1e-12, rep
+        got = Yd.cpu().numpy()
+        for k in range(8):
+            assert relerr(got[:, k], ref8[k]) < 1e-12, (rep, k)
+        del A
+
+
 # ---- partitioned vectors behind the C ABI: bsm_mul_parts ------------------------------------------------------------
 def _scatter(torch, v, ranges):
     """the parts of a full host vector (1-based inclusive ranges) as CUDA tensors"""

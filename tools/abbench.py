@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Developer probe: warm mul! time of the standard operator set under ONE library build (BSM_LIB) and the
 current BSM_* knobs -- run it once per build, interleaved, to A/B a change over every kind of operator.
-usage: abbench.py [name ...]   (default: all)"""
+usage: abbench.py [name ...]   (default: all); ABB_ACC=gather|atomic|colored picks the accumulation mode"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -38,10 +38,10 @@ CASES = {
     "bem_f32": lambda: bem(400, np.float32, "real"),
 }
 names = sys.argv[1:] or list(CASES)
-tag = os.path.basename(os.environ.get("BSM_LIB", "libbsmrocm.so"))
+tag = os.path.basename(os.environ.get("BSM_LIB", "libbsmrocm.so")) + (":" + os.environ["ABB_ACC"] if os.environ.get("ABB_ACC") else "")
 for name in names:
     prob = CASES[name]()
-    A = S.build(prob)
+    A = S.build(prob, **({"accumulate": os.environ["ABB_ACC"]} if os.environ.get("ABB_ACC") else {}))
     st = A.stats()
     x = prob["x"]
     y = torch.zeros_like(x)
