@@ -506,14 +506,14 @@ def run_partitioned(args, bsm, torch, dist, np, rank, world, barrier, reduce_sca
     if not args.no_extra:
       try:  # (an additional figure must never cost the headline line)
         torch.cuda.empty_cache()
-        r4 = run_checked(c4_share, steps, warmup, 2e-5)
+        r4 = run_checked(c4_share, steps, warmup, 1e-5)
         extra["c4"] = {"workload": r4["desc"] + ", rows and vectors partitioned over %d GPUs, RCCL all-gather of the x slices "
                                                 "(beside the product of the blocks that read own x entries), then the rest" % world,
                        "dtype": "f32", "value": round(r4["total_bytes"] * steps / r4["elapsed"] / 1e9, 1), "unit": "GB/s",
                        "ms_per_step": round(r4["elapsed"] / steps * 1e3, 4),
                        "local_kernel_us_max": round(r4["kdur"] * 1e6, 1),
                        "exchange_us": round(r4["exchange_us"], 1),
-                       "parity_relerr": r4["parity"], "parity_tol": 2e-5, "overlap": r4["overlap"],
+                       "parity_relerr": r4["parity"], "parity_tol": 1e-5, "overlap": r4["overlap"],
                        "frac_of_hbm_peak": round(r4["total_bytes"] * steps / r4["elapsed"] / 1e9 / (HBM_PEAK_GBPS * world), 4),
                        "setup_s": round(r4["setup_s"], 2)}
       except Exception as e:  # pragma: no cover

@@ -20,6 +20,7 @@
 #ifndef BSM_ROCM_H
 #define BSM_ROCM_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -116,6 +117,25 @@ typedef struct {
     int64_t reserved[1];
 } bsm_options;
 
+/* The layout the bindings mirror field by field (julia/BlockSparseMatricesROCm.jl: BsmOptions, BsmPartInfo;
+ * blocksparsematrices.jl_amd/_lib.py: BsmOptions, BsmPartInfo, BsmStats; tests/test_c_abi_from_c.py asserts the
+ * same numbers against the ctypes mirror): a field added or moved here fails the build instead of drifting silently
+ * away from a binding that cannot be compiled against this header. */
+#ifdef __cplusplus
+#define BSM_LAYOUT_ASSERT(cond, msg) static_assert(cond, msg)
+#else
+#define BSM_LAYOUT_ASSERT(cond, msg) _Static_assert(cond, msg)
+#endif
+BSM_LAYOUT_ASSERT(sizeof(bsm_options) == 72, "bsm_options is 72 bytes");
+BSM_LAYOUT_ASSERT(offsetof(bsm_options, device) == 4 && offsetof(bsm_options, scheduler) == 8 &&
+                      offsetof(bsm_options, accumulate) == 12 && offsetof(bsm_options, validate) == 16 &&
+                      offsetof(bsm_options, transpose_image) == 20,
+                  "bsm_options: six int32 fields first");
+BSM_LAYOUT_ASSERT(offsetof(bsm_options, own_lo) == 24 && offsetof(bsm_options, own_hi) == 32 &&
+                      offsetof(bsm_options, ctx) == 40 && offsetof(bsm_options, blocks_memspace) == 48 &&
+                      offsetof(bsm_options, coloring) == 56 && offsetof(bsm_options, reserved) == 64,
+                  "bsm_options: 8-byte fields from offset 24");
+
 /* ---- several GPUs of one node behind ONE handle -------------------------------------------------
  * The reference runs its block rows / colour classes as tasks of one process (OhMyThreads `@tasks`
  * with the scheduler stored in the matrix).  The MI355X counterpart of that fan-out is a context of
@@ -159,6 +179,9 @@ typedef struct {
     int64_t col_lo, col_hi;
     int64_t reserved[2];
 } bsm_part_info_t;
+BSM_LAYOUT_ASSERT(sizeof(bsm_part_info_t) == 88 && offsetof(bsm_part_info_t, own_lo) == 8 &&
+                      offsetof(bsm_part_info_t, col_lo) == 56 && offsetof(bsm_part_info_t, reserved) == 72,
+                  "bsm_part_info_t layout");
 int bsm_part_info(bsm_matrix_t A, int32_t part, bsm_part_info_t *out);
 
 /* fills *o with defaults (device = current, serial scheduler, auto accumulate, validate) */
@@ -317,6 +340,7 @@ typedef struct {
     int64_t win_emissions, win_inside, win_flushed;
     int64_t reserved[5];
 } bsm_stats_t;
+BSM_LAYOUT_ASSERT(sizeof(bsm_stats_t) == 128 && offsetof(bsm_stats_t, win_emissions) == 64, "bsm_stats_t layout");
 int bsm_stats(bsm_matrix_t A, bsm_stats_t *out);
 
 /* Debug / test hook: copies one array of the packed device image (host copy) out.

@@ -28,6 +28,51 @@ def test_c_demo_bookkeeping(tmp_path, bsm):
     assert out.stdout.strip().endswith("OK")
 
 
+def test_struct_layouts_match_the_header_and_the_bindings(tmp_path, bsm):
+    """include/bsm_rocm.h pins the layout of its three structs with static assertions; the same numbers are asserted
+    here against the ctypes mirror (blocksparsematrices.jl_amd/_lib.py) and against a C program compiled from the
+    header, and they are the ones the Julia mirror (julia/BlockSparseMatricesROCm.jl: BsmOptions, BsmPartInfo) is
+    written to -- that file cannot be executed here, so a drift has to fail on this side."""
+    import ctypes as C
+    import re
+    from bsm_amd import _lib as L
+    expect = {"bsm_options": (72, dict(struct_size=0, device=4, scheduler=8, accumulate=12, validate=16, transpose_image=20,
+                                       own_lo=24, own_hi=32, ctx=40, blocks_memspace=48, coloring=56, reserved=64)),
+              "bsm_part_info_t": (88, dict(device=0, own_lo=8, own_hi=16, touched_lo=24, touched_hi=32, device_bytes=40,
+                                           nblocks=48, col_lo=56, col_hi=64, reserved=72)),
+              "bsm_stats_t": (128, dict(nnz=0, stored_entries=8, alg_bytes=16, device_bytes=24, npanels=32, ntasks=40,
+                                        nworkgroups=48, exclusive=56, win_emissions=64, win_inside=72, win_flushed=80,
+                                        reserved=88))}
+    mirror = {"bsm_options": L.BsmOptions, "bsm_part_info_t": L.BsmPartInfo, "bsm_stats_t": L.BsmStats}
+    lines = ["#include <stdio.h>", "#include <stddef.h>", '#include "bsm_rocm.h"', "int main(void) {"]
+    for name, (size, offs) in expect.items():
+        assert C.sizeof(mirror[name]) == size, name
+        for f, o in offs.items():
+            assert getattr(mirror[name], f).offset == o, (name, f)
+            lines.append(f'  printf("{name}.{f} %zu\\n", offsetof({name}, {f}));')
+        lines.append(f'  printf("{name} %zu\\n", sizeof({name}));')
+    lines += ["  return 0;", "}"]
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = str(tmp_path / "layout")
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-I", os.path.join(ROOT, "include"), str(src), "-o", exe])
+    got = dict(l.split() for l in subprocess.run([exe], capture_output=True, text=True, check=True).stdout.splitlines())
+    for name, (size, offs) in expect.items():
+        assert int(got[name]) == size
+        for f, o in offs.items():
+            assert int(got[f"{name}.{f}"]) == o, (name, f)
+    # the Julia mirror lists the same fields in the same order with the same widths
+    jl = open(os.path.join(ROOT, "julia", "BlockSparseMatricesROCm.jl")).read()
+    body = re.search(r"mutable struct BsmOptions.*?\nend", jl, re.S).group(0)
+    fields = re.findall(r"(\w+)::(Int32|Int64|Ptr\{Cvoid\}|NTuple\{1,Int64\})", body)
+    width = {"Int32": 4, "Int64": 8, "Ptr{Cvoid}": 8, "NTuple{1,Int64}": 8}
+    off = 0
+    for f, t in fields:
+        assert expect["bsm_options"][1][f] == off, f
+        off += width[t]
+    assert off == 72 and len(fields) == len(expect["bsm_options"][1])
+
+
 @pytest.mark.gpu
 def test_c_demo_products_on_gpu(tmp_path, bsm):
     out = subprocess.run([_build(tmp_path), "gpu"], capture_output=True, text=True, timeout=300)

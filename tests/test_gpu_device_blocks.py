@@ -70,7 +70,7 @@ def test_generator_in_hbm_is_bit_identical_to_the_numpy_streams(torch_cuda, bsm)
 def test_vbcrs_from_device_blocks_equals_host_construction(torch_cuda, bsm, oracle):
     torch = torch_cuda
     S = bsm.synthetic
-    for dt, tol in ((np.float64, 1e-12), (np.float32, 2e-5)):
+    for dt, tol in ((np.float64, 1e-12), (np.float32, 1e-5)):
         dev = S.config2(n=12_000, nblocks=500, dtype=dt, on_device=True)
         host = to_host(dev)
         Ad = S.build(dev, transpose_image=True)
@@ -238,10 +238,11 @@ def test_config4_FULL_size_properties_on_one_gpu(torch_cuda, bsm):
     assert scale > 0 and bool(torch.isfinite(ax).all())
     lhs, rhs = float(torch.dot(ax.double(), z.double())), float(torch.dot(x.double(), atz.double()))
     assert abs(lhs - rhs) < 1e-4 * max(abs(lhs), float(ax.double().norm() * z.double().norm()) * 1e-3)
+    # (linearity between fp32 results, no oracle at this size: the combination 2x - 3z is itself rounded to fp32)
     assert float((comb - (2 * ax - 3 * az)).abs().max()) < 2e-5 * scale
     del A
     torch.cuda.empty_cache()
     B = S_.build(p, devices=[0, 0, 0])
     y2 = torch.full_like(x, float("nan"))
     bsm.mul(y2, B, x)
-    assert float((y2 - ax).abs().max()) < 2e-5 * scale
+    assert float((y2 - ax).abs().max()) < 1e-5 * scale

@@ -173,5 +173,5 @@ def test_bench_launches_its_own_ranks_and_reports_parity():
     assert c["parity_relerr"] <= 1e-12 and "exchange_us" in c and c["local_kernel_us_max"] > 0
     assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1
     c4 = d["extra"]["c4"]
-    assert c4["parity_relerr"] <= 2e-5 and c4["overlap"] is True
+    assert c4["parity_relerr"] <= 1e-5 and c4["overlap"] is True
     assert "value_invalid" not in d

@@ -8,7 +8,7 @@ from _fuzz import GEN, seed_of
 
 pytestmark = pytest.mark.gpu
 TOL = {np.dtype(np.float64): 1e-12, np.dtype(np.complex128): 1e-12,
-       np.dtype(np.float32): 5e-5, np.dtype(np.complex64): 5e-5}
+       np.dtype(np.float32): 1e-5, np.dtype(np.complex64): 1e-5}
 
 
 @pytest.fixture(scope="module")

@@ -14,7 +14,7 @@ from _common import Cc, N, T, fixture_as_blocksparse, fixture_problem, oracle_mu
 
 pytestmark = pytest.mark.gpu
 TOL = {np.dtype(np.float64): 1e-12, np.dtype(np.complex128): 1e-12,
-       np.dtype(np.float32): 2e-5, np.dtype(np.complex64): 2e-5}
+       np.dtype(np.float32): 1e-5, np.dtype(np.complex64): 1e-5}
 
 
 @pytest.fixture(scope="module")
@@ -492,4 +492,4 @@ def test_partitioned_vectors_fp32_and_device_resident_blocks(torch_cuda, bsm, or
             bsm.mul_parts(yp, wrap(bsm, A, op), xp)
             torch.cuda.synchronize()
             got = np.concatenate([t.cpu().numpy() for t in yp])
-            assert relerr(got, ref) < 2e-5, op
+            assert relerr(got, ref) < 1e-5, op

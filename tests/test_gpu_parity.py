@@ -4,7 +4,7 @@ mirror), against the CPU oracle on identical inputs.
 Tolerances (the reference's own norm max|y - y_ref| / max|y_ref|, test/test_vbcrs.jl:35):
     fp64 / complex128 : 1e-12   (BASELINE.json north_star; the reference's tests use 1e-13 on
                                  ~1e3-sized fixtures and `isapprox` rtol 1.5e-8 for products)
-    fp32 / complex64  : 2e-5
+    fp32 / complex64  : 1e-5   (observed <= 2e-6)
 Bookkeeping (perm / rowptr / colindices / rowindices / colour classes) is bit-exact and is
 covered in the CPU suite (tests/test_host_logic.py), which needs no GPU.
 """
@@ -16,7 +16,7 @@ from _common import (Cc, N, T, fixture_as_blocksparse, fixture_problem, oracle_m
 
 pytestmark = pytest.mark.gpu
 TOL = {np.dtype(np.float64): 1e-12, np.dtype(np.complex128): 1e-12,
-       np.dtype(np.float32): 2e-5, np.dtype(np.complex64): 2e-5}
+       np.dtype(np.float32): 1e-5, np.dtype(np.complex64): 1e-5}
 OPS = [N, T, Cc]
 
 
@@ -414,11 +414,13 @@ def test_config4_one_gpu_share_properties(torch_cuda, bsm):
     assert abs(_dot(ax, z) - _dot(x, atz)) < 1e-4 * abs(_dot(ax, z))
     az = gpu_mul(torch_cuda, bsm, A, N, z, zero, 1, 0, True)
     both = gpu_mul(torch_cuda, bsm, A, N, (2 * x - 3 * z).astype(np.float32), zero, 1, 0, True)
+    # (not a comparison with the oracle: two fp32 results combined in fp32 against a product of the fp32-ROUNDED
+    # combination 2x - 3z -- three roundings of size eps * 5 max|x| on top of the product's own error)
     assert relerr(both, 2 * ax - 3 * az) < 2e-5
     del A
     B = bsm.synthetic.build(p)                                          # single image: atomics
     atz2 = gpu_mul(torch_cuda, bsm, B, T, z, zero, 1, 0, True)
-    assert relerr(atz2, atz) < 2e-5
+    assert relerr(atz2, atz) < 1e-5
     rows_touched = np.zeros(n, bool)
     rows_touched[:1953 * 128] = True
     assert not np.any(ax[~rows_touched])                                # rows without blocks are exactly zero

@@ -182,7 +182,7 @@ def test_error_behaviour(bsm):
 def _check_image(bsm, oracle, problem, A, dtype, ops=OPS, tol=None):
     rng = np.random.default_rng(42)
     nr, nc = problem["size"]
-    tol = tol or (2e-5 if np.dtype(dtype) in (np.float32, np.complex64) else 1e-13)
+    tol = tol or (1e-5 if np.dtype(dtype) in (np.float32, np.complex64) else 1e-13)
     for op in ops:
         if op == Cc and np.dtype(dtype).kind != "c":
             continue
