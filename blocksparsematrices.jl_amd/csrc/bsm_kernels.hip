@@ -236,6 +236,9 @@ __shared__ unsigned long long t_trace[kWavesPerWg][16];
 #ifndef BSM_C64_FUSED_WAVES
 #define BSM_C64_FUSED_WAVES 5
 #endif
+#ifndef BSM_C64_L
+#define BSM_C64_L 4
+#endif
 constexpr int FLAG_STRONG_ZERO = 1;
 constexpr int FLAG_DIRECT = 2;
 constexpr int FLAG_CONJ = 4;
@@ -338,6 +341,8 @@ __device__ __forceinline__ T run_panel(const WaveD &wd, const uint4 *__restrict_
     // matrix loads; emitted at the chunk end of a small panel, nothing ever waits for them.
     constexpr int BF = XCH / NC;
     static_assert(XCH % NC == 0, "x chunk must hold whole iterations");
+    constexpr bool INPLACE = FWD && TRN;  // column sums parked in the x slice, y indices of the chunk kept in `vs`
+    int *ix = reinterpret_cast<int *>(vs);
     const bool opT = (flags & FLAG_OPT) != 0;
     const bool cjf = (flags & FLAG_CONJ) != 0;
     const int m = wd.m;
@@ -429,20 +434,34 @@ __device__ __forceinline__ T run_panel(const WaveD &wd, const uint4 *__restrict_
             for (int k = 0; k < KX; ++k) {
                 const int w = c0 + k * 64 + lane;
                 bool off;
+                int yi = raw[k] & 0x7fffffff;
                 if (pool)
                     off = raw[k] >= 0 && (kinds & 3) == KIND_OFF;
                 else
-                    (void)col_lookup(w, off);
+                    yi = col_lookup(min(w, ncols - 1), off);
                 xs[k * 64 + lane] = (w < ncols && (!opT || off)) ? xv[k] : zero_of(T{});
+                // fused kernels: the transposed emission of this chunk finds its y index here (sign bit: the column
+                // takes no part in it) instead of reading the column list a second time, a dependent round trip per
+                // 64 columns in front of the atomics
+                if (INPLACE) ix[k * 64 + lane] = (w < ncols && (opT || off)) ? yi : -1;
             }
         };
 
         // the x slice of the chunk that starts at column c0
         auto stage_chunk = [&](int c0) {
-            if (!fwd_en) return;
+            // (a fused wave whose piece has no forward half in this op still needs the chunk's y indices)
+            if (!fwd_en && !(INPLACE && trn_en)) return;
             if (BSM_DBG(DBG_NO_XGATHER)) {
 #pragma unroll
-                for (int k = 0; k < XCH / 64; ++k) xs[k * 64 + lane] = alpha;
+                for (int k = 0; k < XCH / 64; ++k) {
+                    xs[k * 64 + lane] = alpha;
+                    if (INPLACE) {
+                        const int w = c0 + k * 64 + lane;
+                        bool off = false;
+                        const int yi = col_lookup(min(w, ncols - 1), off);
+                        ix[k * 64 + lane] = (w < ncols && (opT || off)) ? yi : -1;
+                    }
+                }
                 return;
             }
             constexpr int KXM = XCH / 64;
@@ -483,30 +502,40 @@ __device__ __forceinline__ T run_panel(const WaveD &wd, const uint4 *__restrict_
                 // the column sums of the chunk's iterations are parked in LDS and leave the wave
                 // together (64 busy lanes per atomic wave-instruction instead of NC)
                 const int slot = (s0 - c0 / E) / (G * L);
+                // fused kernels park IN PLACE: slot c of the x slice holds x of chunk column c until the forward half of
+                // its iteration has read it (above: the same wave, LDS in program order), then the column's sum
+                T *park = INPLACE ? xs : vs;
                 if ((i & dup) == 0) {
 #pragma unroll
                     for (int j = 0; j < CF; ++j) {
                         const int q = pos + j;  // original value index l*E + e
                         const int l = q / E, e = q % E;
-                        vs[slot * NC + (l * G + g) * E + e] = vals[j];
+                        park[slot * NC + (l * G + g) * E + e] = vals[j];
                     }
                 }
                 const bool last_it = (s0 + G * L >= s_end);
                 if ((slot == BF - 1 || last_it) && !BSM_DBG(DBG_NO_EMISSION)) {
                     const int sb = s0 - slot * (G * L);  // first strip of the batch
+                    const int nbatch = min((slot + 1) * NC, ncols - sb * E);  // columns of the batch
 #pragma unroll 1
-                    for (int k = 0; k < (BF * NC + 63) / 64; ++k) {
+                    for (int k = 0; k * 64 < nbatch; ++k) {
                         const int c = k * 64 + lane;
                         const int w = sb * E + c;
-                        if (c < (slot + 1) * NC && w < ncols) {
-                            bool off;
-                            const int yi = col_lookup(w, off);
-                            if (!(opT || off)) continue;  // a diagonal column in op N: forward only
+                        if (c < nbatch) {
+                            int yi;
+                            if (INPLACE) {
+                                yi = ix[c];
+                                if (yi < 0) continue;  // a diagonal column in op N: forward only
+                            } else {
+                                bool off;
+                                yi = col_lookup(w, off);
+                                if (!(opT || off)) continue;
+                            }
                             if (flags & FLAG_GATHER) {  // one plain, coalesced store per column sum
-                                ws[col_off + w] = vs[c];
+                                ws[col_off + w] = park[c];
                                 continue;
                             }
-                            const T val = mul(alpha, vs[c]);
+                            const T val = mul(alpha, park[c]);
                             const unsigned wi = (unsigned)(yi - wd.win_base);
                             if (wi < (unsigned)win_n) {
                                 if (!BSM_DBG(DBG_NO_WINDOW_ADD)) lds_acc(&win[wi], val);  // leaves the CU once, with the window
@@ -567,8 +596,8 @@ __device__ __forceinline__ T run_panel(const WaveD &wd, const uint4 *__restrict_
 //   fp32 / complex64: capped at 96 = 5 waves (fp32 fused compiles to 80: 6), no scratch anywhere.
 template <typename T, int L, bool FWD, bool TRN, bool NT>
 __global__ void __launch_bounds__(64 * kWavesPerWg) __attribute__((amdgpu_waves_per_eu(
-    (FWD && TRN && std::is_same<T, double>::value) ? 8 :
-    (FWD && TRN && std::is_same<T, c64>::value) ? BSM_C64_FUSED_WAVES :
+    (FWD && TRN && (std::is_same<T, double>::value || std::is_same<T, float>::value)) ? 8 :
+    (FWD && TRN && std::is_same<T, c64>::value) ? (L == 4 ? 8 : BSM_C64_FUSED_WAVES) :
     (((!TRN && std::is_same<T, double>::value) || std::is_same<T, c128>::value) ? 6 : 5))))
     // <= 96 SGPRs: a CU admits 7 workgroups of 256 threads (the ComplexF64 fused instance compiled to 106 =
     // 6 workgroups; tiled BEM fixture 147.7 -> 143.9 us with the cap, nothing else changes)
@@ -1290,10 +1319,13 @@ static bool stream_policy(const DeviceImage &img) {
     // (operators of a few tens of MB are a single round of resident workgroups bound by one
     // workgroup's dependency chain, where the hint costs ~5 %: 27 MB 5.8 vs 6.3 us)
     const long long mb = img.value_bytes >> 20;
-    // the retention effect was only seen on exclusive forward launches; a 242 MB fused symmetric
-    // product runs the same warm either way (39.8 vs 39.5 us) and twice as fast cold with the hint
-    if (!img.exclusive_fwd) return mb >= 40;
-    return (mb >= 40 && mb < 100) || mb > 300;  // measured crossovers: ~105 MB and ~310 MB of values
+    // One rule for exclusive AND accumulate-mode launches.  (Round 2 kept the hint for every fused operator from 40 MB
+    // on: "a 242 MB fused symmetric product runs the same warm either way".  The tiled BEM fixture does not --
+    // profiles/r04_nt_sweep.txt, hint / plain in us: fp32 109 MB 30.9 / 29.0, 163 MB 44.2 / 39.8, 218 MB 61.4 / 53.5;
+    // fp64 203 MB 50.1 / 42.7, 254 MB 60.7 / 51.1, 305 MB 71.4 / 68.4, 407 MB 85.7 / 85.9; ComplexF64 98 MB 24.1 / 25.8,
+    // 196 MB 45.9 / 43.9, 392 MB 81.8 / 85.0, 783 MB 145 / 151: between ~100 and ~320 MB of values the operator stays in
+    // the Infinity Cache between two products only when it is loaded like ordinary data.)
+    return (mb >= 40 && mb < 100) || mb > 320;  // measured crossovers: ~105 MB and ~310-330 MB of values
 }
 
 // one launch of panel_kernel<T, L, FWD, TRN, NT> with NT taken from the run-time policy `nt`
@@ -1525,7 +1557,12 @@ hipError_t launch_mul(const DeviceImage &img, bool opT, bool conj, const void *x
     switch (img.dtype) {
         case 0: return launch_typed<float, 8>(img, opT, conj, x, y, alpha, beta, strong_zero, stream, use_gather, zrange);
         case 1: return launch_typed<double, 8>(img, opT, conj, x, y, alpha, beta, strong_zero, stream, use_gather, zrange);
-        case 2: return launch_typed<c64, 8>(img, opT, conj, x, y, alpha, beta, strong_zero, stream, use_gather, zrange);
+        // complex64 fused products: 4 loads per lane in flight -- 61 VGPRs, 8 waves per SIMD; with 8 the fused instance
+        // needs 93-95 (5 waves): tiled BEM fixture 105.9 -> 95.1 us (profiles/r04_c64_l4.txt)
+        case 2:
+            if (img.has_off && !img.exclusive_fwd)
+                return launch_typed<c64, BSM_C64_L>(img, opT, conj, x, y, alpha, beta, strong_zero, stream, use_gather, zrange);
+            return launch_typed<c64, 8>(img, opT, conj, x, y, alpha, beta, strong_zero, stream, use_gather, zrange);
         case 3: return launch_typed<c128, 8>(img, opT, conj, x, y, alpha, beta, strong_zero, stream, use_gather, zrange);
     }
     return hipErrorInvalidValue;

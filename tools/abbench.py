@@ -26,16 +26,17 @@ def bem(K, dtype, part):
     return prob
 
 
+KB = int(os.environ.get("ABB_K", 400))  # tiles of the BEM fixture
 CASES = {
     "c2": lambda: S.config2(on_device=True),
     "c2x20": lambda: S.config2(n=2_000_000, nblocks=100_000, on_device=True),
     "c3": lambda: S.config3(on_device=True),
     "c4s": lambda: S.config4(on_device=True, row_lo=0, row_hi=1953),
     "c5s": lambda: S.config5(n=625_000, on_device=True),
-    "bem_c128": lambda: bem(400, np.complex128, "full"),
-    "bem_f64": lambda: bem(400, np.float64, "real"),
-    "bem_c64": lambda: bem(400, np.complex64, "full"),
-    "bem_f32": lambda: bem(400, np.float32, "real"),
+    "bem_c128": lambda: bem(KB, np.complex128, "full"),
+    "bem_f64": lambda: bem(KB, np.float64, "real"),
+    "bem_c64": lambda: bem(KB, np.complex64, "full"),
+    "bem_f32": lambda: bem(KB, np.float32, "real"),
 }
 names = sys.argv[1:] or list(CASES)
 tag = os.path.basename(os.environ.get("BSM_LIB", "libbsmrocm.so")) + (":" + os.environ["ABB_ACC"] if os.environ.get("ABB_ACC") else "")
@@ -46,7 +47,7 @@ for name in names:
     x = prob["x"]
     y = torch.zeros_like(x)
     plan = bsm.MulPlan(y, A, x)
-    reps = 200 if st["alg_bytes"] < 200e6 else 30
+    reps = int(os.environ.get("ABB_REPS", 0)) or (200 if st["alg_bytes"] < 200e6 else 30)
     for _ in range(10):
         plan()
     torch.cuda.synchronize()
@@ -60,6 +61,6 @@ for name in names:
         torch.cuda.synchronize()
         ts.append(a.elapsed_time(b) * 1e3 / reps)
     ts.sort()
-    print(f"{tag:22s} {name:9s} median {ts[2]:8.2f} us  min {ts[0]:8.2f}  {st['alg_bytes']/ts[2]/1e3:6.0f} GB/s", flush=True)
+    print(f"{tag:22s} {name + (f'x{KB}' if name.startswith('bem') and KB != 400 else ''):13s} median {ts[2]:8.2f} us  min {ts[0]:8.2f}  {st['alg_bytes']/ts[2]/1e3:6.0f} GB/s", flush=True)
     del plan, A, prob
     torch.cuda.empty_cache()

@@ -2,7 +2,7 @@
 """Developer probe: timing-only ablations of the fused symmetric kernel on the tiled BEM fixture (or a
 synthetic config): which part of a wave's life costs what.  Needs the experiment build
 (make -C blocksparsematrices.jl_amd/csrc exp; BSM_LIB=.../libbsmrocm_exp.so); results of a run with any
-bit set are WRONG by construction, only the time means something.  usage: ablate.py [K] [c128|f64] [rounds]"""
+bit set are WRONG by construction, only the time means something.  usage: ablate.py [K] [c128|f64|c64|f32] [rounds]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 os.environ.setdefault("BSM_LIB", os.path.join(ROOT, "blocksparsematrices.jl_amd", "libbsmrocm_exp.so"))
@@ -20,15 +20,20 @@ if len(sys.argv) > 1 and not sys.argv[1].isdigit():  # a synthetic configuration
     x = prob["x"]
 else:
     K = int(sys.argv[1]) if len(sys.argv) > 1 else 400
-    real = len(sys.argv) > 2 and sys.argv[2] == "f64"
-    p = fixture_problem("cuboid", np.float64 if real else np.complex128, "real" if real else "full")
+    tname = sys.argv[2] if len(sys.argv) > 2 else "c128"
+    ftype = {"c128": np.complex128, "f64": np.float64, "c64": np.complex64, "f32": np.float32}[tname]
+    real = tname in ("f64", "f32")
+    p = fixture_problem("cuboid", ftype, "real" if real else "full")
     n0 = p["size"][0]
     tile = lambda lists: [l + k * n0 for k in range(K) for l in lists]
     prob = dict(kind="symmetric", diagonals=p["diagonals"] * K, diagonalindices=tile(p["diagonalindices"]),
                 offdiagonals=p["offdiagonals"] * K, rowindices=tile(p["rowindices"]), colindices=tile(p["colindices"]),
                 size=(n0 * K, n0 * K))
     dt = p["diagonals"][0].dtype
-    xh = np.random.default_rng(0).standard_normal(n0 * K).astype(dt)
+    xh = np.random.default_rng(0).standard_normal(n0 * K)
+    if not real:
+        xh = xh + 1j * np.random.default_rng(1).standard_normal(n0 * K)
+    xh = xh.astype(dt)
     A = bsm.synthetic.build(prob)
     st = A.stats()
     x = torch.from_numpy(xh).cuda()
