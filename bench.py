@@ -41,8 +41,10 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("OMP_NUM_THREADS", str(min(len(os.sched_getaffinity(0)), 16)))
 
 HBM_PEAK_GBPS = 8000.0  # MI355X spec (MI355X_MICROARCH.md); measured-copy ceiling 6290
-PMC_FILE = os.path.join(ROOT, "profiles", "r03_c2_pmc.json")  # written by tools/pmc_summary.py, stamped with the build id
-MFMA_FILE = os.path.join(ROOT, "profiles", "r03_c4_mfma.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r04_c2_pmc.json")  # written by tools/pmc_summary.py, stamped with the build id
+MFMA_FILE = os.path.join(ROOT, "profiles", "r04_c4_mfma.json")
+C5N1_FILE = os.path.join(ROOT, "profiles", "r04_c5_n1.json")  # the N > 1 workload on ONE GPU (tools/profile_round.sh)
+MIN_TIMED_S = 5e-3  # a timed region shorter than this is repeated (config.replays) so that host synchronisation stays below 1 %
 
 
 def read_json(path):
@@ -66,6 +68,63 @@ def counter_file(path, build, kernel=None, alg_bytes=None):
     if alg_bytes is not None and d.get("alg_bytes_per_launch") != alg_bytes:
         return None, "%s is for %s algorithmic bytes per launch, this run has %d" % (os.path.relpath(path, ROOT), d.get("alg_bytes_per_launch"), alg_bytes)
     return d, None
+
+
+def live_traffic(kernel_sub, alg_bytes):
+    """HBM traffic of the C2 product measured NOW: two rocprofv3 passes (FETCH_SIZE, WRITE_SIZE -- one counter per
+    pass, --kernel-trace only, MI355X_MICROARCH.md) over a child process that runs this script's C2 launches
+    (--pmc-child); per-launch means, FETCH_SIZE KiB x 1024 x 2 (gfx950: the 128-B requests of 16-byte-per-lane
+    streaming reads are tallied at 64 B) + WRITE_SIZE KiB x 1024.  (None, why) when rocprofv3 is not on the box or
+    a pass fails: the caller falls back to the stamped file under profiles/."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return None, "rocprofv3 is not on this box"
+    means = {}
+    env = dict(os.environ, TMPDIR="/tmp")
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="bsm_pmc_", dir="/tmp")
+        try:
+            # (the program itself follows `--`: no shell, no env wrapper between the profiler and python)
+            r = subprocess.run([exe, "--output-format", "csv", "--kernel-trace", "--pmc", counter, "-d", d, "-o", "p", "--",
+                                sys.executable, os.path.abspath(__file__), "--pmc-child"], cwd="/tmp", env=env,
+                               stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=240)
+            vals = []
+            for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                with open(path, newline="") as f:
+                    for row in csv.DictReader(f):
+                        if kernel_sub in row["Kernel_Name"] and row["Counter_Name"] == counter:
+                            vals.append(float(row["Counter_Value"]))
+            if r.returncode != 0 or len(vals) < 10:
+                return None, "the %s pass gave %d dispatches (status %d): %s" % (counter, len(vals), r.returncode,
+                                                                                r.stderr.decode(errors="replace")[-200:])
+            means[counter] = (sum(vals) / len(vals), len(vals))
+        except Exception as e:  # noqa: BLE001
+            return None, "the %s pass failed: %r" % (counter, e)
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    traffic = int(means["FETCH_SIZE"][0] * 1024 * 2 + means["WRITE_SIZE"][0] * 1024)
+    return {"traffic_bytes_per_launch": traffic, "fetch_size_kib_mean": round(means["FETCH_SIZE"][0], 2),
+            "write_size_kib_mean": round(means["WRITE_SIZE"][0], 2), "dispatches": [means["FETCH_SIZE"][1], means["WRITE_SIZE"][1]],
+            "traffic_over_algorithmic": round(traffic / alg_bytes, 4)}, None
+
+
+def pmc_child():
+    """what live_traffic() profiles: 60 plain C2 launches (no graph: every dispatch gets its counter record)"""
+    import torch
+    import bsm_amd as bsm
+    prob = bsm.synthetic.config2()
+    A = bsm.VariableBlockCompressedRowStorage(prob["blocks"], prob["rowstart"], prob["colstart"], prob["size"])
+    x = torch.from_numpy(prob["x"]).cuda()
+    y = torch.zeros_like(x)
+    plan = bsm.MulPlan(y, A, x)
+    for _ in range(60):
+        plan()
+    torch.cuda.synchronize()
 
 
 def graph_timed(fn, steps, torch):
@@ -262,7 +321,12 @@ def main():
     ap.add_argument("--note", default=None, help="free text carried into config.note (set by the self-launcher)")
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: strictly serial exchange / product / exchange "
                     "(the round-2 step) instead of the overlapped one")
+    ap.add_argument("--no-live-pmc", action="store_true", help="take roofline.traffic from the stamped file under profiles/ "
+                    "instead of two rocprofv3 passes of this run")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.pmc_child:
+        return pmc_child()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # plain `python bench.py --gpus N`: the parallel entry is INSIDE the call, like the reference's
@@ -463,7 +527,8 @@ def run_partitioned(args, bsm, torch, dist, np, rank, world, barrier, reduce_sca
         for _ in range(3):
             local_only()
         torch.cuda.synchronize()
-        kdur = timed(local_only, max(5, steps // 4), torch)
+        # (median of three batches: exchange_us is the difference of two millisecond figures)
+        kdur = sorted(timed(local_only, max(5, steps // 4), torch) for _ in range(3))[1]
         del plans, yk
         elapsed, total = reduce_scalars(elapsed, rank_bytes)
         total += 2 * n * es
@@ -556,6 +621,23 @@ def run_partitioned(args, bsm, torch, dist, np, rank, world, barrier, reduce_sca
         "roofline": roofline,
     }
     notes = [t for t in (args.note, r5.get("note")) if t]
+    if world > 1 and args.scale == 1.0:
+        # the same operator on ONE GPU (profiles/r04_c5_n1.json: `bench.py --gpus 1 --workload c5` on an MI355X box of this
+        # pool, stamped with the build of the kernels): what this line's value has to be divided by for a speed-up --
+        # the driver's own N = 1 run times C2, another operator
+        from bsm_amd import _lib
+        build = _lib.lib().bsm_version().decode().split("build ")[-1]
+        n1 = read_json(C5N1_FILE)
+        if n1 and n1.get("value"):
+            out["config"]["n1_same_workload_GBps"] = n1["value"]
+            out["config"]["n1_same_workload"] = {"GBps": n1["value"], "ms_per_step": n1.get("ms_per_step"), "build": n1.get("build"),
+                                                 "same_build": n1.get("build") == build, "file": os.path.relpath(C5N1_FILE, ROOT)}
+            out["config"]["speedup_vs_n1_same_workload"] = round(value / n1["value"], 3)
+        else:
+            out["config"]["n1_same_workload_GBps"] = None
+        notes.append("the default N = 1 line of this script times C2 (BASELINE.json's 1-GPU configuration: another operator, "
+                     "Infinity-Cache-resident); the N = 1 figure of THIS workload is config.n1_same_workload (also extra.c5_n1 of the "
+                     "N = 1 line), and config.speedup_vs_n1_same_workload divides by it")
     if notes:
         out["config"]["note"] = "; ".join(notes)
     if extra:
@@ -572,14 +654,19 @@ def run_partitioned(args, bsm, torch, dist, np, rank, world, barrier, reduce_sca
 # ------------------------------------------------------------------------------------------------
 # N = 1 (and --workload c2 at N > 1: weak scaling, no collective): C2
 # ------------------------------------------------------------------------------------------------
-def bem_tiled_problem(torch, np, K=400):
+BEM_TYPES = (("c128", "complex128", "full", 1e-12), ("f64", "float64", "real", 1e-12),
+             ("c64", "complex64", "full", 1e-5), ("f32", "float32", "real", 1e-5))
+
+
+def bem_tiled_problem(torch, np, K=400, dtype="complex128", part="full"):
     """The reference's own workload: its BEM test fixture (test/assets/symmetricblockexamples.jld2 "cuboid",
     decoded to tests/golden/symmetric_cuboid.bin: ComplexF64, 96 leaves of 3-28 rows, wide near-field panels
     with scattered columns) tiled K times along the diagonal -- the true block shapes at a size that
     streams from HBM (SURVEY.md 8d, C3').  The 188 blocks are uploaded once and referenced K times."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from _common import fixture_problem
-    p = fixture_problem("cuboid", np.complex128, "full")
+    dtype = np.dtype(dtype)
+    p = fixture_problem("cuboid", dtype, part)
     n0 = p["size"][0]
     dd = [torch.from_numpy(np.ascontiguousarray(b.T)).cuda().t() for b in p["diagonals"]]   # column-major on the GPU
     oo = [torch.from_numpy(np.ascontiguousarray(b.T)).cuda().t() for b in p["offdiagonals"]]
@@ -588,9 +675,26 @@ def bem_tiled_problem(torch, np, K=400):
                 offdiagonals=oo * K, rowindices=tile(p["rowindices"]), colindices=tile(p["colindices"]),
                 size=(n0 * K, n0 * K))
     rng = np.random.default_rng(0)
-    xh = (rng.standard_normal(n0 * K) + 1j * rng.standard_normal(n0 * K)).astype(np.complex128)
-    prob["x"] = torch.from_numpy(xh).cuda()
+    xh = rng.standard_normal(n0 * K)
+    if dtype.kind == "c":  # a FULL complex x (zero imaginary parts run 5-8 % faster: less switching, higher clock)
+        xh = xh + 1j * rng.standard_normal(n0 * K)
+    prob["x"] = torch.from_numpy(xh.astype(dtype)).cuda()
     return prob, p, n0
+
+
+def fixture_coo(np, fx, n0):
+    """the fixture's operator through an independent COO sum (the reference's test oracle, src/sparse.jl), in double"""
+    import scipy.sparse as sp
+    rr, cc_, vv = [], [], []
+    for blk, idx in zip(fx["diagonals"], fx["diagonalindices"]):
+        R, Cq = np.meshgrid(idx - 1, idx - 1, indexing="ij")
+        rr.append(R.ravel()); cc_.append(Cq.ravel()); vv.append(blk.ravel())
+    for blk, ri, ci in zip(fx["offdiagonals"], fx["rowindices"], fx["colindices"]):
+        R, Cq = np.meshgrid(ri - 1, ci - 1, indexing="ij")
+        rr += [R.ravel(), Cq.ravel()]; cc_ += [Cq.ravel(), R.ravel()]; vv += [blk.ravel(), blk.ravel()]
+    vals = np.concatenate(vv)
+    vals = vals.astype(np.complex128 if vals.dtype.kind == "c" else np.float64)
+    return sp.coo_matrix((vals, (np.concatenate(rr), np.concatenate(cc_))), shape=(n0, n0)).tocsr()
 
 
 def run_c2(args, bsm, torch, dist, np, rank, world, barrier, reduce_scalars):
@@ -639,20 +743,36 @@ def run_c2(args, bsm, torch, dist, np, rank, world, barrier, reduce_scalars):
     if graph is None:
         launch = "eager"
 
-    # ---- timed region: EXACTLY K steps ----------------------------------------------------------------
+    # ---- timed region: the K steps, R times --------------------------------------------------------------
+    # K launches of a 10 us product are 0.2 ms at the driver's K = 20: the barrier + synchronize on both sides would be
+    # 8 % of that.  When K steps take less than MIN_TIMED_S the K-step region is repeated R times back to back (the
+    # same captured graph replayed R times) and ms_per_step = total / (K R); `steps` stays K, config.replays = R.
+    def k_steps():
+        if graph is not None:
+            graph.replay()
+        else:
+            for _ in range(args.steps):
+                plan()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    k_steps()  # (untimed: sizes R)
+    ev1.record()
+    torch.cuda.synchronize()
+    once = max(ev0.elapsed_time(ev1) * 1e-3, 1e-6)
+    replays = 1 if once >= MIN_TIMED_S else min(1000, int(MIN_TIMED_S / once) + 1)
+    if dist is not None:  # every rank repeats the same number of times
+        rr = torch.tensor([float(replays)], dtype=torch.float64, device=reduce_scalars.comm["dev"])
+        dist.all_reduce(rr, op=dist.ReduceOp.MAX, group=reduce_scalars.comm["group"])
+        replays = int(rr.item())
     barrier()
     t0 = time.perf_counter()
     ev0.record()  # HIP events on the stream the kernels are launched on
-    if graph is not None:
-        graph.replay()
-    else:
-        for _ in range(args.steps):
-            plan()
+    for _ in range(replays):
+        k_steps()
     ev1.record()
     barrier()
-    elapsed = time.perf_counter() - t0
-    dev_elapsed = ev0.elapsed_time(ev1) * 1e-3
+    elapsed = (time.perf_counter() - t0) / replays
+    dev_elapsed = ev0.elapsed_time(ev1) * 1e-3 / replays
     elapsed, total_bytes = reduce_scalars(elapsed, alg_bytes)
     value = total_bytes * args.steps / elapsed / 1e9
 
@@ -663,10 +783,22 @@ def run_c2(args, bsm, torch, dist, np, rank, world, barrier, reduce_scalars):
     KERNEL = "bsm::panel_kernel<double,8,true,false,true>"
     kdur = dev_elapsed / args.steps
     achieved = alg_bytes / kdur / 1e9
-    pmc, why = counter_file(PMC_FILE, build, kernel=KERNEL, alg_bytes=int(alg_bytes))
+    pmc, why, traffic_src = None, None, None
+    if rank == 0 and world == 1 and not args.no_live_pmc:
+        pmc, why_live = live_traffic("panel_kernel<double, 8, true, false", int(alg_bytes))
+        traffic_src = "two rocprofv3 --pmc passes of THIS run (FETCH_SIZE, WRITE_SIZE; 60 eager launches each)" if pmc else None
+        if pmc is None:
+            why = "live passes: " + why_live
+    if pmc is None:
+        pmc, why_file = counter_file(PMC_FILE, build, kernel=KERNEL, alg_bytes=int(alg_bytes))
+        if pmc is not None:
+            traffic_src = os.path.relpath(PMC_FILE, ROOT) + " (same build, kernel and byte count)" + ("; " + why if why else "")
+        else:
+            why = (why + "; " if why else "") + why_file
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 4),
                 "traffic": pmc["traffic_bytes_per_launch"] if pmc else None,
+                "traffic_source": traffic_src if pmc else "none -- " + str(why),
                 "kernel": KERNEL, "build": build,
                 "alg_bytes_per_launch": int(alg_bytes), "avg_launch_us": round(kdur * 1e6, 3),
                 "note": "warm: the 54 MB operator stays in the 256 MiB Infinity Cache between launches, so `frac` divides "
@@ -674,8 +806,7 @@ def run_c2(args, bsm, torch, dist, np, rank, world, barrier, reduce_scalars):
                         "same byte count takes in the same state (same request shape, nothing else to do) and "
                         "frac_of_stream_floor the honest distance; extra.hbm_vbcrs_fp64 / extra.c3_fused / "
                         "extra.bem_tiled are HBM-streaming legs.  traffic = rocprofv3 FETCH_SIZE x2 (gfx950 "
-                        "correction) + WRITE_SIZE per launch from " + os.path.relpath(PMC_FILE, ROOT)
-                        + (" -- NOT used: " + why if why else " (same build, kernel and byte count)")}
+                        "correction) + WRITE_SIZE per launch (traffic_source)"}
     floor = None
     if rank == 0:
         try:
@@ -729,28 +860,45 @@ def run_c2(args, bsm, torch, dist, np, rank, world, barrier, reduce_scalars):
         except Exception as e:  # pragma: no cover
             extra["legs_error"] = repr(e)
         torch.cuda.empty_cache()
+        # the reference's own workload in the four element types of the library (its fixture is ComplexF64; Float64 =
+        # its real part; the 4-byte types the same data rounded): driver-timed, each with its parity number
+        bem = {"workload": "the reference's BEM fixture (test/assets/symmetricblockexamples.jld2 'cuboid', 96 leaves of 3-28 rows, "
+                           "scattered near-field columns) tiled 400 x along the diagonal, fused A + A^T mul!; legs c128 (the "
+                           "fixture's own type), f64 (real part), c64, f32 (rounded)"}
+        for tname, dtn, part, tol in BEM_TYPES:
+            try:
+                bp, fx, n0 = bem_tiled_problem(torch, np, 400, dtn, part)
+                one, yb = leg(bsm, torch, bp, 50, multi_rhs=8 if tname in ("c128", "f64") else 0)
+                one["dtype"] = tname
+                # parity of the leg: tile 0 of y against the fixture's own product through an independent COO sum
+                ref = fixture_coo(np, fx, n0) @ bp["x"][:n0].cpu().numpy().astype(np.complex128 if np.dtype(dtn).kind == "c" else np.float64)
+                got = yb[:n0].cpu().numpy()
+                one["relerr_vs_coo"] = float(np.max(np.abs(got - ref)) / np.max(np.abs(ref)))
+                one["parity_tol"] = tol
+                one["parity_ok"] = bool(one["relerr_vs_coo"] <= tol)
+                bem[tname] = one
+                del bp, yb
+            except Exception as e:  # pragma: no cover
+                bem[tname] = {"error": repr(e)}
+            torch.cuda.empty_cache()
+        if "us" in bem.get("c128", {}):  # (the round-3 fields of the ComplexF64 leg stay where they were)
+            bem.update({k: v for k, v in bem["c128"].items() if k not in bem})
+        extra["bem_tiled"] = bem
+        torch.cuda.empty_cache()
+        # the workload of the N > 1 lines (C5, strong-scaled) on THIS one GPU, through the same code path (the overlapped
+        # step with no neighbour): the same-operator anchor of a scaling curve -- the headline of this line is C2
+        # (BASELINE.json's 1-GPU configuration), a different operator in a different cache state
         try:
-            bp, fx, n0 = bem_tiled_problem(torch, np)
-            extra["bem_tiled"], yb = leg(bsm, torch, bp, 50)
-            extra["bem_tiled"]["workload"] = ("the reference's BEM fixture (test/assets/symmetricblockexamples.jld2 'cuboid', ComplexF64, "
-                                              "3-28-row leaves, scattered near-field columns) tiled 400 x along the diagonal, fused A + A^T mul!")
-            extra["bem_tiled"]["dtype"] = "c128"
-            # parity of the leg: tile 0 of y against the fixture's own product through an independent COO sum
-            import scipy.sparse as sp
-            rr, cc_, vv = [], [], []
-            for blk, idx in zip(fx["diagonals"], fx["diagonalindices"]):
-                R, Cq = np.meshgrid(idx - 1, idx - 1, indexing="ij")
-                rr.append(R.ravel()); cc_.append(Cq.ravel()); vv.append(blk.ravel())
-            for blk, ri, ci in zip(fx["offdiagonals"], fx["rowindices"], fx["colindices"]):
-                R, Cq = np.meshgrid(ri - 1, ci - 1, indexing="ij")
-                rr += [R.ravel(), Cq.ravel()]; cc_ += [Cq.ravel(), R.ravel()]; vv += [blk.ravel(), blk.ravel()]
-            M0 = sp.coo_matrix((np.concatenate(vv), (np.concatenate(rr), np.concatenate(cc_))), shape=(n0, n0)).tocsr()
-            ref = M0 @ bp["x"][:n0].cpu().numpy()
-            got = yb[:n0].cpu().numpy()
-            extra["bem_tiled"]["relerr_vs_coo"] = float(np.max(np.abs(got - ref)) / np.max(np.abs(ref)))
-            del bp, yb
+            a5 = argparse.Namespace(**vars(args))
+            a5.steps, a5.warmup, a5.no_extra, a5.scale, a5.no_overlap, a5.note = 20, 3, True, 1.0, False, None
+            o5 = run_partitioned(a5, bsm, torch, None, np, 0, 1, barrier, reduce_scalars)
+            extra["c5_n1"] = {"workload": o5["config"]["workload"], "value": o5["value"], "unit": "GB/s", "ms_per_step": o5["ms_per_step"],
+                              "steps": 20, "exchange_us": o5["config"]["exchange_us"], "local_kernel_us_max": o5["config"]["local_kernel_us_max"],
+                              "parity_relerr": o5["config"]["parity_relerr"], "frac_of_hbm_peak": o5["config"]["frac_of_hbm_peak"],
+                              "build": build, "note": "what `python bench.py --gpus 1 --workload c5` prints; N > 1 lines carry the "
+                                                      "committed copy of this figure as config.n1_same_workload"}
         except Exception as e:  # pragma: no cover
-            extra["bem_tiled"] = {"error": repr(e)}
+            extra["c5_n1"] = {"error": repr(e)}
         torch.cuda.empty_cache()
     mf, why_mf = counter_file(MFMA_FILE, build)
     if rank == 0:
@@ -765,7 +913,8 @@ def run_c2(args, bsm, torch, dist, np, rank, world, barrier, reduce_scalars):
         "config": {"workload": "C2: VBCRS 100000x100000 per GPU, 5000 variable 8-64 fp64 blocks per GPU "
                                "(SplitMix64 seed 0xB5A2), mul!(y, A, x), x/y/A resident in HBM",
                    "global_rows": n, "blocks_per_gpu": len(prob["blocks"]),
-                   "alg_bytes_per_gpu": int(alg_bytes), "launch": launch,
+                   "alg_bytes_per_gpu": int(alg_bytes), "launch": launch, "replays": replays,
+                   "timed_region": "%d x (K = %d steps): ms_per_step = wall time between the two barriers / (K x replays)" % (replays, args.steps),
                    "partition": "block rows, no data-path collective",
                    "frac_of_hbm_peak": round(value / (HBM_PEAK_GBPS * world), 4)},
         "roofline": roofline,
@@ -803,6 +952,42 @@ def run_c2(args, bsm, torch, dist, np, rank, world, barrier, reduce_scalars):
                 "relerr_vs_1core": float(np.max(np.abs(yp - yh)) / np.max(np.abs(yh)))}
         except Exception as e:  # pragma: no cover
             out.setdefault("extra", {})["cpu_allcores"] = {"error": str(e)}
+        # the reference's three-sweep symmetric product (src/symmetricblockmatrix.jl:386-435) beside the fused legs, on
+        # bounded samples of the same operators, loop and clock in C (orc_sym_bench_*), one host core
+        if not args.no_extra:
+            def sym_cpu(prob, seconds, what):
+                dt = prob["diagonals"][0].dtype
+                es = dt.itemsize
+                nn = prob["size"][0]
+                xs_ = np.random.default_rng(1).standard_normal(nn).astype(dt)
+                ys_ = np.zeros(nn, dt)
+                reps, secs = orc.sym_bench(prob["diagonals"], prob["diagonalindices"], prob["offdiagonals"], prob["rowindices"],
+                                           prob["colindices"], xs_, ys_, seconds=seconds)
+                stored = sum(b.size for b in prob["diagonals"]) + sum(b.size for b in prob["offdiagonals"])
+                meta = 8 * (sum(len(d) for d in prob["diagonalindices"]) + sum(len(r) + len(c) for r, c in zip(prob["rowindices"], prob["colindices"])))
+                alg = stored * es + meta + 2 * nn * es  # every stored entry once (the reference reads the off-diagonal ones twice)
+                return {"value": round(alg * reps / secs / 1e9, 3), "unit": "GB/s", "cores": 1, "kind": "port",
+                        "sample": f"{reps} mul! calls of {what} ({alg / 1e6:.0f} MB algorithmic) in {secs:.1f} s, oracle/bsm_oracle.c "
+                                  "orc_sym_mul (three sweeps, serial colour sets), timed in C"}
+            try:
+                ex = out.setdefault("extra", {})
+                if "c3_fused" in ex and "error" not in ex["c3_fused"]:
+                    ex["c3_fused"]["cpu_baseline"] = sym_cpu(bsm.synthetic.config3(nseg=300), 4.0, "C3 with 300 of its 3 125 diagonal segments")
+                if "bem_tiled" in ex:
+                    sys.path.insert(0, os.path.join(ROOT, "tests"))
+                    from _common import fixture_problem
+                    for tname, dtn, part, _tol in BEM_TYPES:
+                        if "error" in ex["bem_tiled"].get(tname, {"error": 1}):
+                            continue
+                        fx = fixture_problem("cuboid", np.dtype(dtn), part)
+                        n0, KC = fx["size"][0], 24  # 24 tiles with their OWN copies of the blocks (a CPU cache must not hold the operator)
+                        tile = lambda lists: [l + k * n0 for k in range(KC) for l in lists]
+                        pc = dict(diagonals=[b.copy() for _ in range(KC) for b in fx["diagonals"]], diagonalindices=tile(fx["diagonalindices"]),
+                                  offdiagonals=[b.copy() for _ in range(KC) for b in fx["offdiagonals"]], rowindices=tile(fx["rowindices"]),
+                                  colindices=tile(fx["colindices"]), size=(n0 * KC, n0 * KC))
+                        ex["bem_tiled"][tname]["cpu_baseline"] = sym_cpu(pc, 2.0, f"the fixture tiled {KC} x in {tname}")
+            except Exception as e:  # pragma: no cover
+                out.setdefault("extra", {})["cpu_symmetric_error"] = repr(e)
     return out
 
 

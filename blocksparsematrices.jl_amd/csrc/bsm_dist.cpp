@@ -156,6 +156,17 @@ struct DistState {
     bool produced = false;       // some product has been issued: ev_done / ev_tail carry a record
     hipEvent_t ev_tail = nullptr;  // end of the last copy-path product on its caller's stream
     int tail_dev = -1;
+    // Cross-stream ordering of the fused path by FLAGS instead of events (BSM_DIST_FLAGS): a product has a sequence
+    // number, "recorded" = hipStreamWriteValue64(stream, flag, seq), "waited for" = hipStreamWaitValue64(stream, flag,
+    // seq, >=) on 64-bit counters in coherent pinned host memory (every device's command processor can poll them).
+    // tools/hop_latency.hip: a dependency between two streams costs ~6 us this way against ~12.4 us through
+    // hipEventRecord + hipStreamWaitEvent, and a product has two to three of them on its critical path.
+    // flag[k * P + p], k = 0 "inputs of part p ready", 1 "product of part p done", 2 "delivery of part p done";
+    // flag[3 P] "x / y of a full-vector call ready".
+    bool use_flags = false;
+    uint64_t *flags = nullptr;
+    uint64_t seq = 0;
+    int last_mode = -1;  // 0 events, 1 flags: a change drains every stream first (the two forms do not see each other)
 };
 
 }  // namespace bsm
@@ -330,6 +341,7 @@ void dist_destroy(bsm_matrix_s *A) {
         (void)g.enter(D.res_dev);
         (void)hipFree(D.d_res);
     }
+    if (D.flags) (void)hipHostFree(D.flags);
     A->dist.reset();
 }
 
@@ -433,6 +445,33 @@ int dist_create(bsm_matrix_s *A, bsm_ctx_s *ctx, int mtype, int dtype, int64_t n
     }
     D.all_peer = ctx->peer_ok;  // enabled for every pair when the context was created (bsm_ctx_create)
     if (const char *v = std::getenv("BSM_DIST_COPIES")) D.all_peer = D.all_peer && std::atoi(v) == 0;  // tests: force the copy path
+    {
+        // flags: on by default where they have been exercised -- every part on ONE physical device (virtual devices); on
+        // distinct devices (a flag polled by another GPU's command processor has never run on this pool) only on request
+        bool one_device = true;
+        for (int d : ctx->devices) one_device = one_device && d == ctx->devices[0];
+        int can = 0;
+        for (int d : ctx->devices) {
+            int c = 0;
+            if (hipDeviceGetAttribute(&c, hipDeviceAttributeCanUseStreamWaitValue, d) != hipSuccess) {
+                (void)hipGetLastError();
+                c = 0;
+            }
+            can = (d == ctx->devices[0]) ? c : (can && c);
+        }
+        D.use_flags = one_device && can;
+        if (const char *v = std::getenv("BSM_DIST_FLAGS")) D.use_flags = std::atoi(v) != 0 && can;
+        if (D.use_flags) {
+            hipError_t e = hipHostMalloc((void **)&D.flags, (size_t)(3 * P + 1) * sizeof(uint64_t), hipHostMallocCoherent | hipHostMallocPortable);
+            if (e != hipSuccess) {
+                (void)hipGetLastError();
+                D.flags = nullptr;
+                D.use_flags = false;
+            } else {
+                std::memset(D.flags, 0, (size_t)(3 * P + 1) * sizeof(uint64_t));
+            }
+        }
+    }
     // one persistent issuing thread per device from five parts on (BSM_DIST_WORKERS = smallest part count that
     // gets them): below, the calling thread issues everything faster than the threads can be woken twice
     int wmin = 5;
@@ -457,8 +496,15 @@ static hipError_t grow_buffers(DistState &D, int K) {
     // the fused path works on the CALLERS' streams (run[p] = the part's caller stream), and a peer's finish kernel
     // reads this part's work vector over xGMI: ev_done is recorded on run[p] after the part's last use of the
     // buffers, so every part's ev_done has to be reached too before the first buffer is freed
-    if (D.produced)
+    if (D.produced && D.last_mode != 1)
         for (int p = 0; p < P && e == hipSuccess; p++) e = hipEventSynchronize(D.parts[p]->ev_done);
+    if (D.produced && D.last_mode == 1) {  // ordered by flags: no event carries the last use -- drain the devices
+        for (int p = 0; p < P && e == hipSuccess; p++) {
+            DeviceGuard g;
+            e = g.enter(D.parts[p]->device);
+            if (e == hipSuccess) e = hipDeviceSynchronize();
+        }
+    }
     for (int p = 0; p < P && e == hipSuccess; p++) {
         Part &pt = *D.parts[p];
         DeviceGuard g;
@@ -490,6 +536,7 @@ struct VecSource {
     hipStream_t stream; // where the entries are produced
     hipEvent_t ready;   // recorded on `stream` at the start of the call
     int strided;        // column k of a multi-RHS batch at + k * ldx (else the source holds one column)
+    int ready_flag = -1;  // flags mode: the counter that stands for `ready`
 };
 struct VecDest {
     char *base;  // virtual base of the y entries
@@ -497,6 +544,7 @@ struct VecDest {
     int sdev;    // where the stream lives
     hipStream_t stream;
     hipEvent_t ready;
+    int ready_flag = -1;
 };
 
 static int dist_mul_fused(DistState &D, int op, int K, const std::vector<VecSource> &src, long long ldx,
@@ -516,21 +564,6 @@ static int dist_mul_fused(DistState &D, int op, int K, const std::vector<VecSour
         if (e != hipSuccess) return hip_fail(e, what); \
     } while (0)
     DCHECK(grow_buffers(D, K), "multi-device buffers");
-    // "x (and the incoming y) are ready" on every stream that produces them
-    {
-        std::vector<hipEvent_t> done;
-        auto record = [&](hipEvent_t ev, hipStream_t st, int dev) -> hipError_t {
-            for (hipEvent_t d : done)
-                if (d == ev) return hipSuccess;
-            done.push_back(ev);
-            DeviceGuard g;
-            hipError_t e2 = g.enter(dev);
-            return e2 == hipSuccess ? hipEventRecord(ev, st) : e2;
-        };
-        for (const VecSource &s : src) DCHECK(record(s.ready, s.stream, s.sdev), "hipEventRecord");
-        for (const VecDest &d : dst) DCHECK(record(d.ready, d.stream, d.sdev), "hipEventRecord");
-    }
-    const bool was_produced = D.produced;
     // The stream a part's work is issued on.  bsm_mul_parts: the caller's stream of that part -- local work needs
     // no cross-stream hop at all, only what depends on a PEER waits for an event.  bsm_mul: the first part that
     // lives on the caller's device works on the caller's stream for the same reason (the hops of the other
@@ -545,6 +578,50 @@ static int dist_mul_fused(DistState &D, int op, int K, const std::vector<VecSour
             if (mine) taken = true;
         }
     }
+    // flags pay where streams wait for each other (a write-value packet costs ~2 us more than an event record that
+    // nobody waits for: a product whose parts all work on ONE stream -- partitioned vectors driven from one stream of
+    // one virtual device -- keeps events: tools/distbench.py, 2 parts 202 vs 188 us)
+    bool several_streams = false;
+    for (int p = 1; p < P; p++) several_streams = several_streams || run[p] != run[0] || D.parts[p]->device != D.parts[0]->device;
+    const bool flags = D.use_flags && several_streams;
+    if (D.last_mode >= 0 && D.last_mode != (flags ? 1 : 0)) {
+        // the previous product of the handle was ordered the other way (events / flags, e.g. the copy path of a host
+        // vector in between): the two forms do not see each other, so everything is drained once
+        for (int p = 0; p < P; p++) {
+            DeviceGuard g;
+            DCHECK(g.enter(D.parts[p]->device), "hipSetDevice");
+            DCHECK(hipDeviceSynchronize(), "hipDeviceSynchronize");
+        }
+    }
+    D.last_mode = flags ? 1 : 0;
+    // (the counters only ever hold numbers of products ordered by flags: a product ordered by events in between must not
+    // consume one, or the next one would wait for a value nobody writes)
+    const uint64_t prev_seq = D.seq;
+    const uint64_t seq = flags ? ++D.seq : D.seq;
+    uint64_t *const F = D.flags;
+    const uint64_t kAll = ~(uint64_t)0;
+    // "recorded" / "waited for": an event, or (flags) the product's sequence number in a counter
+    auto signal = [&](hipEvent_t ev, int flag, hipStream_t st) -> hipError_t {
+        return flags ? hipStreamWriteValue64(st, F + flag, seq, 0) : hipEventRecord(ev, st);
+    };
+    auto await = [&](hipStream_t st, hipEvent_t ev, int flag, uint64_t value) -> hipError_t {
+        return flags ? hipStreamWaitValue64(st, F + flag, value, hipStreamWaitValueGte, kAll) : hipStreamWaitEvent(st, ev, 0);
+    };
+    // "x (and the incoming y) are ready" on every stream that produces them
+    {
+        std::vector<std::pair<hipEvent_t, int>> done;
+        auto record = [&](hipEvent_t ev, int flag, hipStream_t st, int dev) -> hipError_t {
+            for (const auto &d : done)
+                if (d.first == ev && d.second == flag) return hipSuccess;
+            done.emplace_back(ev, flag);
+            DeviceGuard g;
+            hipError_t e2 = g.enter(dev);
+            return e2 == hipSuccess ? signal(ev, flag, st) : e2;
+        };
+        for (const VecSource &s : src) DCHECK(record(s.ready, s.ready_flag, s.stream, s.sdev), "record: inputs ready");
+        for (const VecDest &d : dst) DCHECK(record(d.ready, d.ready_flag, d.stream, d.sdev), "record: inputs ready");
+    }
+    const bool was_produced = D.produced;
     // A part that neither sends nor receives a y segment (VBCRS forward: block rows own disjoint y ranges,
     // reference src/vbcrs.jl:275-283) multiplies straight into the caller's y -- beta fused, no work vector,
     // no delivery launch.
@@ -559,9 +636,9 @@ static int dist_mul_fused(DistState &D, int op, int K, const std::vector<VecSour
         direct[p] = alone;
     }
     // (a NULL stream is a different stream on every device: "same stream" needs the same device too)
-    auto wait_for = [&](int p, hipEvent_t ev, hipStream_t recorded_on, int recorded_dev) -> hipError_t {
+    auto wait_for = [&](int p, hipEvent_t ev, int flag, hipStream_t recorded_on, int recorded_dev) -> hipError_t {
         if (recorded_on == run[p] && recorded_dev == D.parts[p]->device) return hipSuccess;  // same stream: already ordered
-        return hipStreamWaitEvent(run[p], ev, 0);
+        return await(run[p], ev, flag, seq);
     };
     // phase 0 (part p): wait for its inputs, gather the x pieces it reads (one launch), local product
     // phase 1 (part q): add the y segments its peers produced for its rows, deliver (one launch)
@@ -576,14 +653,15 @@ static int dist_mul_fused(DistState &D, int op, int K, const std::vector<VecSour
             // peers that read this part's work vector in the previous product have finished (their ev_done
             // carries that product's record until phase 1 of THIS product re-records it, after a host barrier)
             if (was_produced) {
+                // (flags: the previous product's number; a first fused product after copy-path ones was drained above)
                 for (const Transfer &t : D.plan_n.transfers)
-                    if (t.from == p) DCHECK(hipStreamWaitEvent(st, D.parts[t.to]->ev_done, 0), "hipStreamWaitEvent");
+                    if (t.from == p) DCHECK(await(st, D.parts[t.to]->ev_done, 2 * P + t.to, prev_seq), "wait: previous delivery");
                 for (const Transfer &t : D.plan_t.transfers)
-                    if (t.from == p) DCHECK(hipStreamWaitEvent(st, D.parts[t.to]->ev_done, 0), "hipStreamWaitEvent");
-                DCHECK(hipStreamWaitEvent(st, pt.ev_done, 0), "hipStreamWaitEvent");  // its own previous delivery (another stream, perhaps)
-                if (D.ev_tail) DCHECK(hipStreamWaitEvent(st, D.ev_tail, 0), "hipStreamWaitEvent");
+                    if (t.from == p) DCHECK(await(st, D.parts[t.to]->ev_done, 2 * P + t.to, prev_seq), "wait: previous delivery");
+                DCHECK(await(st, pt.ev_done, 2 * P + p, prev_seq), "wait: previous delivery");  // its own previous delivery (another stream, perhaps)
+                if (!flags && D.ev_tail) DCHECK(hipStreamWaitEvent(st, D.ev_tail, 0), "hipStreamWaitEvent");
             }
-            DCHECK(wait_for(p, yd.ready, yd.stream, yd.sdev), "hipStreamWaitEvent");  // the incoming y (numeric beta) / its buffer
+            DCHECK(wait_for(p, yd.ready, yd.ready_flag, yd.stream, yd.sdev), "wait: y ready");  // the incoming y (numeric beta) / its buffer
             const Range zr = pl.zr[p];
             if (pt.has_image) {
                 const Range xr = pl.xr[p];
@@ -595,7 +673,7 @@ static int dist_mul_fused(DistState &D, int op, int K, const std::vector<VecSour
                 for (const VecSource &s : src) {
                     const Range o = isect(s.valid, xr);
                     if (o.empty()) continue;
-                    DCHECK(wait_for(p, s.ready, s.stream, s.sdev), "hipStreamWaitEvent");
+                    DCHECK(wait_for(p, s.ready, s.ready_flag, s.stream, s.sdev), "wait: x ready");
                     if (o.lo == xr.lo && o.hi == xr.hi && s.device == pt.device) {  // everything it reads lies on its own device
                         xp = s.base;
                         xld = s.strided ? ldx : 0;
@@ -626,7 +704,7 @@ static int dist_mul_fused(DistState &D, int op, int K, const std::vector<VecSour
                 for (int k = 0; k < K; k++)
                     DCHECK(hipMemsetAsync((char *)pt.d_w + ((size_t)k * vlen + zr.lo) * es, 0, (size_t)zr.len() * es, st), "memset");
             }
-            DCHECK(hipEventRecord(pt.ev_prod, st), "hipEventRecord");
+            DCHECK(signal(pt.ev_prod, P + p, st), "record: product done");
             return BSM_OK;
         }
         const Range o = pl.out[p];
@@ -635,7 +713,7 @@ static int dist_mul_fused(DistState &D, int op, int K, const std::vector<VecSour
         for (const Transfer &t : pl.transfers) {
             if (t.to != p) continue;
             Part &from = *D.parts[t.from];
-            DCHECK(wait_for(p, from.ev_prod, run[(size_t)t.from], from.device), "hipStreamWaitEvent");
+            DCHECK(wait_for(p, from.ev_prod, P + t.from, run[(size_t)t.from], from.device), "wait: peer's product");
             if (np == kMaxVecPieces) {  // more peers than one launch takes: fold these into the work vector first
                 DCHECK(launch_vec_finish(D.dtype, nullptr, 0, pt.d_w, (long long)vlen, pc, np, o.lo, o.hi, nullptr, 1, 1, K, st), "halo add");
                 np = 0;
@@ -649,7 +727,7 @@ static int dist_mul_fused(DistState &D, int op, int K, const std::vector<VecSour
         if (!o.empty() && !direct[p])
             DCHECK(launch_vec_finish(D.dtype, yd.base, ldy, pt.d_w, (long long)vlen, pc, np, o.lo, o.hi, beta, beta_strong_zero, 0, K,
                                      st), "y delivery");
-        DCHECK(hipEventRecord(pt.ev_done, st), "hipEventRecord");
+        DCHECK(signal(pt.ev_done, 2 * P + p, st), "record: delivery done");
         return BSM_OK;
     };
     for (int ph = 0; ph < 2; ph++) {
@@ -667,7 +745,7 @@ static int dist_mul_fused(DistState &D, int op, int K, const std::vector<VecSour
         if (yd.stream == run[(size_t)q] && yd.sdev == D.parts[q]->device) continue;  // delivered on the consumer's own stream
         DeviceGuard g;
         DCHECK(g.enter(yd.sdev), "hipSetDevice");
-        DCHECK(hipStreamWaitEvent(yd.stream, D.parts[q]->ev_done, 0), "hipStreamWaitEvent");
+        DCHECK(await(yd.stream, D.parts[q]->ev_done, 2 * P + q, seq), "wait: delivery");
     }
 #undef DCHECK
     return BSM_OK;
@@ -700,6 +778,14 @@ static int dist_mul_copies(bsm_matrix_s *A, int op, int K, const void *x, long l
     } while (0)
 
     DCHECK(grow_buffers(D, K), "multi-device buffers");
+    if (D.last_mode == 1) {  // the previous product was ordered by flags, this path orders by events: drain once
+        for (int p = 0; p < P; p++) {
+            DeviceGuard g;
+            DCHECK(g.enter(D.parts[p]->device), "hipSetDevice");
+            DCHECK(hipDeviceSynchronize(), "hipDeviceSynchronize");
+        }
+    }
+    D.last_mode = 0;
     int cur = 0;
     DCHECK(hipGetDevice(&cur), "hipGetDevice");
     int xdev = -1, ydev = -1, sdev = cur;
@@ -948,8 +1034,9 @@ static int dist_mul_k(bsm_matrix_s *A, int op, int K, const void *x, long long l
                 it = D.ev_x.emplace(sdev, ev).first;
             }
             const long long xlen = (op == BSM_OP_N) ? D.ncols : D.nrows;
-            std::vector<VecSource> src{VecSource{(const char *)x, Range{0, xlen}, xdev, sdev, stream, it->second, 1}};
-            std::vector<VecDest> dst{VecDest{(char *)y, ydev, sdev, stream, it->second}};
+            const int P = (int)D.parts.size();
+            std::vector<VecSource> src{VecSource{(const char *)x, Range{0, xlen}, xdev, sdev, stream, it->second, 1, 3 * P}};
+            std::vector<VecDest> dst{VecDest{(char *)y, ydev, sdev, stream, it->second, 3 * P}};
             return dist_mul_fused(D, op, K, src, ldx, dst, ldy, alpha, beta, beta_strong_zero);
         }
     }
@@ -983,8 +1070,8 @@ int dist_mul_parts(bsm_matrix_s *A, int op, const void *const *x_parts, void *co
             if (cs != hipStreamCaptureStatusNone)
                 return fail(BSM_ERR_UNSUPPORTED, "a multi-device handle cannot be captured into a graph");
         }
-        src.push_back(VecSource{(const char *)x_parts[p] - (size_t)in.lo * es, in, pt.device, pt.device, st, pt.ev_in, 0});
-        dst.push_back(VecDest{(char *)y_parts[p] - (size_t)out.lo * es, pt.device, pt.device, st, pt.ev_in});
+        src.push_back(VecSource{(const char *)x_parts[p] - (size_t)in.lo * es, in, pt.device, pt.device, st, pt.ev_in, 0, p});
+        dst.push_back(VecDest{(char *)y_parts[p] - (size_t)out.lo * es, pt.device, pt.device, st, pt.ev_in, p});
     }
     return dist_mul_fused(D, op, 1, src, 0, dst, 0, alpha, beta, beta_strong_zero);
 }

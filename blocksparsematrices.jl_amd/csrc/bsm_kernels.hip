@@ -236,6 +236,9 @@ __shared__ unsigned long long t_trace[kWavesPerWg][16];
 #ifndef BSM_C64_FUSED_WAVES
 #define BSM_C64_FUSED_WAVES 5
 #endif
+#ifndef BSM_C128_FUSED_WAVES
+#define BSM_C128_FUSED_WAVES 6
+#endif
 #ifndef BSM_C64_L
 #define BSM_C64_L 4
 #endif
@@ -597,6 +600,7 @@ __device__ __forceinline__ T run_panel(const WaveD &wd, const uint4 *__restrict_
 template <typename T, int L, bool FWD, bool TRN, bool NT>
 __global__ void __launch_bounds__(64 * kWavesPerWg) __attribute__((amdgpu_waves_per_eu(
     (FWD && TRN && (std::is_same<T, double>::value || std::is_same<T, float>::value)) ? 8 :
+    (FWD && TRN && std::is_same<T, c128>::value) ? BSM_C128_FUSED_WAVES :
     (FWD && TRN && std::is_same<T, c64>::value) ? (L == 4 ? 8 : BSM_C64_FUSED_WAVES) :
     (((!TRN && std::is_same<T, double>::value) || std::is_same<T, c128>::value) ? 6 : 5))))
     // <= 96 SGPRs: a CU admits 7 workgroups of 256 threads (the ComplexF64 fused instance compiled to 106 =

@@ -458,6 +458,17 @@ class RowPartitioned:
         olo, ohi = self.own
         tlo, thi = self.touched
         own_slice = slice(olo - 1, ohi) if ohi >= olo else None
+        halo = any(th >= tl and (tl < rl or th > rh) for rl, rh, tl, th in ranges)
+        if not halo and self.local is None and local_mul is None and self.world == 1:
+            # nothing to exchange and no boundary block (one rank): the step IS the interior product -- no side stream to
+            # fork and join, no work vector (a fork / join pair costs ~30 us of an otherwise idle queue per step)
+            if interior_mul is not None:
+                interior_mul(y, x, alpha, beta)
+            elif self.interior is not None:
+                M.mul(y, self.interior, x, alpha, beta)
+            elif own_slice is not None:
+                self._combine(y, own_slice, 0, beta)
+            return y
         if cuda:
             main = torch.cuda.current_stream(y.device)
             if self._side is None:
@@ -468,7 +479,6 @@ class RowPartitioned:
         else:
             import contextlib
             side_ctx = contextlib.nullcontext()
-        halo = any(th >= tl and (tl < rl or th > rh) for rl, rh, tl, th in ranges)
         with side_ctx:
             self.fetch_x(x)
         # interior rows: y[own] = alpha * A_int x[own] + beta * y[own]

@@ -207,6 +207,23 @@ void FN(orc_coo_mul)(int64_t nrows_y, int64_t nnz, const int64_t *rows, const in
     for (int64_t k = 0; k < nnz; k++) y[rows[k] - 1] += alpha * (vals[k] * x[cols[k] - 1]);
 }
 
+/* Timed loop for bench.py's CPU figures of the symmetric legs: `reps` products S * x (the 3-argument form, alpha = 1,
+ * strong-zero beta: the reference's three coloured sweeps, src/symmetricblockmatrix.jl:386-435) on PRE-MARSHALLED
+ * arguments, the loop and the clock in C.  Returns the elapsed seconds. */
+double FN(orc_sym_bench)(int64_t reps, int64_t nrows_y, int64_t ndiag, const T *const *diag, const int64_t *dsize,
+                         const int64_t *dld, const int64_t *const *didx, int64_t noff, const T *const *off,
+                         const int64_t *m, const int64_t *n, const int64_t *ld, const int64_t *const *rowidx,
+                         const int64_t *const *colidx, const int64_t *ncolors, const int64_t *const *colorptr,
+                         const int64_t *const *colorblk, const T *x, T *y) {
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (int64_t r = 0; r < reps; r++)
+        FN(orc_sym_mul)(0, nrows_y, ndiag, diag, dsize, dld, didx, noff, off, m, n, ld, rowidx, colidx, ncolors, colorptr,
+                        colorblk, x, y, (T)1, (T)0, 1);
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+}
+
 #undef FN
 #undef CAT
 #undef CAT_

@@ -259,6 +259,38 @@ class Oracle:
         reps = max(3, int(seconds / max(t1, 1e-6)))
         return reps, fn(C.c_int64(reps), par, *args)
 
+    def sym_bench(self, diag, didx, off, rowidx, colidx, x, y, seconds=5.0):
+        """Timed products S * x of a SymmetricBlockMatrix (3-argument form, the reference's three sweeps, serial colour
+        sets) with everything marshalled ONCE: the loop and the clock live in C (orc_sym_bench_*).
+        Returns (reps, elapsed seconds)."""
+        dt = np.dtype(x.dtype)
+        fd = _fblocks(diag, dt)
+        fo = _fblocks(off, dt)
+        di = [_i64(d) for d in didx]
+        ri = [_i64(r) for r in rowidx]
+        ci = [_i64(c) for c in colidx]
+        ds = _i64([b.shape[0] for b in fd])
+        dld = _i64([max(b.shape[0], 1) for b in fd])
+        m = _i64([b.shape[0] for b in fo])
+        n = _i64([b.shape[1] for b in fo])
+        ld = _i64([max(b.shape[0], 1) for b in fo])
+        single = lambda k: [list(range(1, k + 1))]
+        csr = [_colors_csr(c) for c in (single(len(fo)), single(len(fo)), single(len(fd)))]
+        ncol = _i64([c[0] for c in csr])
+        cptr = _ptr_array([c[1] for c in csr])
+        cblk = _ptr_array([c[2] for c in csr])
+        x = np.ascontiguousarray(x, dt)
+        assert y.dtype == dt and y.flags.c_contiguous
+        fn = getattr(self.lib, "orc_sym_bench_" + _SFX[dt])
+        fn.restype = C.c_double
+        keep = (_ptr_array(fd), _ptr_array(di), _ptr_array(fo), _ptr_array(ri), _ptr_array(ci))
+        args = [C.c_int64(len(y)), C.c_int64(len(fd)), keep[0], ds.ctypes.data_as(_I64P), dld.ctypes.data_as(_I64P), keep[1],
+                C.c_int64(len(fo)), keep[2], m.ctypes.data_as(_I64P), n.ctypes.data_as(_I64P), ld.ctypes.data_as(_I64P),
+                keep[3], keep[4], ncol.ctypes.data_as(_I64P), cptr, cblk, C.c_void_p(x.ctypes.data), C.c_void_p(y.ctypes.data)]
+        t1 = fn(C.c_int64(2), *args) / 2  # calibrate
+        reps = max(2, int(seconds / max(t1, 1e-6)))
+        return reps, fn(C.c_int64(reps), *args)
+
     def coo_mul(self, rows, cols, vals, x, y, alpha=1, beta=0, strong_zero=True):
         dt = np.dtype(x.dtype)
         r, c = _i64(rows), _i64(cols)

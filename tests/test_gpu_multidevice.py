@@ -282,6 +282,51 @@ def test_single_product_then_a_wider_batch_without_a_sync_in_between(torch_cuda,
         del A
 
 
+@pytest.mark.parametrize("mode", ["1", "0"])
+def test_flag_and_event_ordering_of_the_fan_out(torch_cuda, bsm, oracle, monkeypatch, mode):
+    """The cross-stream ordering of a multi-device product by stream memory operations (hipStreamWriteValue64 /
+    hipStreamWaitValue64 on sequence counters, BSM_DIST_FLAGS=1: the default on virtual devices) and by events (=0):
+    chained device products with no synchronisation in between, a host-vector product (copy path: events) in the middle
+    -- the switch between the two forms drains the streams --, partitioned vectors, a second caller stream; everything
+    against the oracle."""
+    torch = torch_cuda
+    monkeypatch.setenv("BSM_DIST_FLAGS", mode)
+    prob = bsm.synthetic.config5(n=40_000, lo=16, hi=96, halfband=3)
+    n = prob["size"][0]
+    A = bsm.synthetic.build(prob, devices=[0, 0, 0])
+    rng = np.random.default_rng(8)
+    xs = [rng.standard_normal(n) for _ in range(4)]
+    refs = [oracle_mul(oracle, prob, N, x, np.zeros(n)) for x in xs]
+    xd = [torch.from_numpy(x).cuda() for x in xs]
+    yd = [torch.full((n,), float("nan"), dtype=torch.float64, device="cuda") for _ in xs]
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    bsm.mul(yd[0], A, xd[0])
+    bsm.mul(yd[1], A, xd[1])                      # back to back on the same handle
+    yh = np.zeros(n)
+    bsm.mul(yh, A, xs[2])                         # host vectors: the copy path (events)
+    with torch.cuda.stream(side):                 # another caller stream
+        side.wait_stream(torch.cuda.current_stream())
+        bsm.mul(yd[3], A, xd[3])
+    torch.cuda.current_stream().wait_stream(side)
+    # y of one product as x of the next (alpha, beta): z = A (A x0) - 2 x1
+    z = xd[1].clone()
+    bsm.mul(z, A, yd[0], 1.0, -2.0)
+    torch.cuda.synchronize()
+    for k in (0, 1, 3):
+        assert relerr(yd[k].cpu().numpy(), refs[k]) < 1e-12, (mode, k)
+    assert relerr(yh, refs[2]) < 1e-12
+    assert relerr(z.cpu().numpy(), oracle_mul(oracle, prob, N, refs[0], xs[1].copy(), 1.0, -2.0, False)) < 1e-12
+    parts = A.parts()
+    xp = [xd[0][p["cols"][0] - 1:p["cols"][1]].clone() for p in parts]
+    yp = [torch.full((max(p["own"][1] - p["own"][0] + 1, 0),), float("nan"), dtype=torch.float64, device="cuda") for p in parts]
+    bsm.mul_parts(yp, A, xp)
+    bsm.mul(yd[1], A, xd[0])                      # full vectors right behind partitioned ones
+    torch.cuda.synchronize()
+    assert relerr(torch.cat(yp).cpu().numpy(), refs[0]) < 1e-12
+    assert relerr(yd[1].cpu().numpy(), refs[0]) < 1e-12
+
+
 # ---- partitioned vectors behind the C ABI: bsm_mul_parts ------------------------------------------------------------
 def _scatter(torch, v, ranges):
     """the parts of a full host vector (1-based inclusive ranges) as CUDA tensors"""
