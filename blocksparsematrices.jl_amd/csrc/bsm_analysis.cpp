@@ -765,6 +765,15 @@ void Analysis::stage_work_items(BuildState &st) {
             lanes_b += (double)lanes_per_strip(G.mc) * (double)G.strips;
         }
         lane_fill = lanes_b > 0 ? rows_b / lanes_b : 1.0;
+        {  // byte-weighted mean of the rows of a row group (what a strip of a typical streamed byte is tall)
+            double w = 0, wr = 0;
+            for (const Group &G : groups) {
+                const double b = (double)G.mc * (double)G.strips;
+                w += b;
+                wr += b * (double)G.mc;
+            }
+            mean_rows = w > 0 ? wr / w : 64.0;
+        }
         if (W <= 0) {
             const bool low_fill = lanes_b > 0 && rows_b < tun.fat_fill_below * lanes_b;
             W = tun.wave_bytes_min;

@@ -167,6 +167,7 @@ class Analysis {
     std::vector<WaveWork> waves_multi;  // the coarser split for multi-RHS products (empty: `waves` serves both)
     int64_t nwg_multi = 0;
     double lane_fill = 1.0;  // byte-weighted share of the lanes the row groups' strips fill (stage_work_items)
+    double mean_rows = 64.0;  // byte-weighted mean height of the row groups
     int64_t nwg_main = 0;   // workgroups holding panel work
     int64_t nwg_total = 0;  // + workgroups of scale work (exclusive forward launch only)
     int64_t ngroups = 0;

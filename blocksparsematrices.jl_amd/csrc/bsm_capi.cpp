@@ -234,6 +234,7 @@ void fill_image(const Analysis &an, const bsm_options &o, bool use_own, DeviceIm
     img.nwg_total = an.nwg_total;
     img.nwg_multi = an.nwg_multi;
     img.lane_fill = (float)an.lane_fill;
+    img.mean_rows = (float)an.mean_rows;
     img.exclusive_fwd = an.exclusive_fwd && (o.accumulate == BSM_ACC_AUTO || o.accumulate == BSM_ACC_DIRECT);
     img.has_off = false;
     for (const WaveWork &w : an.waves)

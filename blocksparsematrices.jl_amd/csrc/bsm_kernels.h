@@ -17,6 +17,7 @@ struct DeviceImage {
     long long nwg_main = 0, nwg_total = 0;
     void *d_waves_multi = nullptr;  // coarser split of the same panels for the multi-RHS kernels (may be null)
     long long nwg_multi = 0;
+    float mean_rows = 64.f;  // Analysis::mean_rows: fused fp32 products of short panels keep 4 loads per lane in flight
     float lane_fill = 1.f;  // Analysis::lane_fill: two right-hand sides go through a padded 4-column pass above 0.85
     bool exclusive_fwd = false;
     bool has_off = false;  // SymmetricBlockMatrix off-diagonal pieces present

@@ -242,6 +242,16 @@ __shared__ unsigned long long t_trace[kWavesPerWg][16];
 #ifndef BSM_C64_L
 #define BSM_C64_L 4
 #endif
+// (developer builds: loads per lane of the fused kernels of the other element types)
+#ifndef BSM_F32_L
+#define BSM_F32_L 4
+#endif
+#ifndef BSM_F64_L
+#define BSM_F64_L 8
+#endif
+#ifndef BSM_C128_L
+#define BSM_C128_L 8
+#endif
 constexpr int FLAG_STRONG_ZERO = 1;
 constexpr int FLAG_DIRECT = 2;
 constexpr int FLAG_CONJ = 4;
@@ -600,7 +610,7 @@ __device__ __forceinline__ T run_panel(const WaveD &wd, const uint4 *__restrict_
 template <typename T, int L, bool FWD, bool TRN, bool NT>
 __global__ void __launch_bounds__(64 * kWavesPerWg) __attribute__((amdgpu_waves_per_eu(
     (FWD && TRN && (std::is_same<T, double>::value || std::is_same<T, float>::value)) ? 8 :
-    (FWD && TRN && std::is_same<T, c128>::value) ? BSM_C128_FUSED_WAVES :
+    (FWD && TRN && std::is_same<T, c128>::value) ? (L == 4 ? 8 : BSM_C128_FUSED_WAVES) :
     (FWD && TRN && std::is_same<T, c64>::value) ? (L == 4 ? 8 : BSM_C64_FUSED_WAVES) :
     (((!TRN && std::is_same<T, double>::value) || std::is_same<T, c128>::value) ? 6 : 5))))
     // <= 96 SGPRs: a CU admits 7 workgroups of 256 threads (the ComplexF64 fused instance compiled to 106 =
@@ -1559,15 +1569,26 @@ hipError_t launch_mul(const DeviceImage &img, bool opT, bool conj, const void *x
                       const void *alpha, const void *beta, int strong_zero, hipStream_t stream,
                       bool use_gather, const long long *zrange) {
     switch (img.dtype) {
-        case 0: return launch_typed<float, 8>(img, opT, conj, x, y, alpha, beta, strong_zero, stream, use_gather, zrange);
-        case 1: return launch_typed<double, 8>(img, opT, conj, x, y, alpha, beta, strong_zero, stream, use_gather, zrange);
+        case 0:
+            // fp32 fused products of SHORT panels: 4 loads per lane (tiled BEM fixture 48.6 -> 46.5 us; 16-256-row
+            // operators lose 3-5 % with it and keep 8: profiles/r04_fused_loads_per_lane.txt)
+            if (BSM_F32_L != 8 && img.has_off && !img.exclusive_fwd && img.mean_rows < 32.f)
+                return launch_typed<float, BSM_F32_L>(img, opT, conj, x, y, alpha, beta, strong_zero, stream, use_gather, zrange);
+            return launch_typed<float, 8>(img, opT, conj, x, y, alpha, beta, strong_zero, stream, use_gather, zrange);
+        case 1:
+            if (BSM_F64_L != 8 && img.has_off && !img.exclusive_fwd)
+                return launch_typed<double, BSM_F64_L>(img, opT, conj, x, y, alpha, beta, strong_zero, stream, use_gather, zrange);
+            return launch_typed<double, 8>(img, opT, conj, x, y, alpha, beta, strong_zero, stream, use_gather, zrange);
         // complex64 fused products: 4 loads per lane in flight -- 61 VGPRs, 8 waves per SIMD; with 8 the fused instance
         // needs 93-95 (5 waves): tiled BEM fixture 105.9 -> 95.1 us (profiles/r04_c64_l4.txt)
         case 2:
             if (img.has_off && !img.exclusive_fwd)
                 return launch_typed<c64, BSM_C64_L>(img, opT, conj, x, y, alpha, beta, strong_zero, stream, use_gather, zrange);
             return launch_typed<c64, 8>(img, opT, conj, x, y, alpha, beta, strong_zero, stream, use_gather, zrange);
-        case 3: return launch_typed<c128, 8>(img, opT, conj, x, y, alpha, beta, strong_zero, stream, use_gather, zrange);
+        case 3:
+            if (BSM_C128_L != 8 && img.has_off && !img.exclusive_fwd)
+                return launch_typed<c128, BSM_C128_L>(img, opT, conj, x, y, alpha, beta, strong_zero, stream, use_gather, zrange);
+            return launch_typed<c128, 8>(img, opT, conj, x, y, alpha, beta, strong_zero, stream, use_gather, zrange);
     }
     return hipErrorInvalidValue;
 }

@@ -33,6 +33,8 @@ CASES = {
     "c3": lambda: S.config3(on_device=True),
     "c4s": lambda: S.config4(on_device=True, row_lo=0, row_hi=1953),
     "c5s": lambda: S.config5(n=625_000, on_device=True),
+    "c5s_f32": lambda: S.config5(n=625_000, dtype=np.float32, on_device=True),
+    "c3_f32": lambda: S.config3(dtype=np.float32, on_device=True),
     "bem_c128": lambda: bem(KB, np.complex128, "full"),
     "bem_f64": lambda: bem(KB, np.float64, "real"),
     "bem_c64": lambda: bem(KB, np.complex64, "full"),

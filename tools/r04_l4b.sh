@@ -1,0 +1,7 @@
+set -e
+L=$PWD/blocksparsematrices.jl_amd
+for i in 1 2; do
+python tools/abbench.py c5s_f32 c3_f32 c5s 2>/dev/null | sed "s/^/L8 /"
+BSM_LIB=$L/libbsmrocm_l4.so python tools/abbench.py c5s_f32 c3_f32 c5s 2>/dev/null | sed "s/^/L4 /"
+done > gpurun_out/r04_l4b.txt
+cat gpurun_out/r04_l4b.txt
