@@ -216,6 +216,12 @@ def leg(bsm, torch, prob, reps, multi_rhs=0, **kw):
     out = {"us": round(t * 1e6, 2), "GBps": round(st["alg_bytes"] / t / 1e9, 1),
            "frac_of_hbm_peak": round(st["alg_bytes"] / t / 1e9 / HBM_PEAK_GBPS, 4),
            "alg_MB": round(st["alg_bytes"] / 1e6, 1), "device_MB": round(st["device_bytes"] / 1e6, 1)}
+    # the same products as ONE captured hipGraph of `reps` launches (how the C2 headline is launched): without the host
+    # issuing every `y .*= beta` and product launch of its own
+    tg = graph_timed(plan, reps, torch)
+    if tg is not None:
+        out["graph_us"] = round(tg * 1e6, 2)
+        out["graph_frac_of_hbm_peak"] = round(st["alg_bytes"] / tg / 1e9 / HBM_PEAK_GBPS, 4)
     if st.get("win_emissions"):  # fused symmetric launch: share of the y contributions that leave a CU as global atomics
         out["y_contributions_as_atomics"] = round((st["win_emissions"] - st["win_inside"] + st["win_flushed"]) / st["win_emissions"], 3)
     if multi_rhs:
