@@ -236,6 +236,10 @@ __shared__ unsigned long long t_trace[kWavesPerWg][16];
 #ifndef BSM_C64_FUSED_WAVES
 #define BSM_C64_FUSED_WAVES 5
 #endif
+// multi-RHS register path: y indices of a chunk kept in LDS (0: read from the column list in every iteration)
+#ifndef BSM_MULTI_IX
+#define BSM_MULTI_IX 1
+#endif
 #ifndef BSM_C128_FUSED_WAVES
 #define BSM_C128_FUSED_WAVES 6
 #endif
@@ -795,7 +799,7 @@ __device__ __forceinline__ void run_panel_multi(const WaveD &wd, const uint4 *__
                                                 const int *__restrict__ rows,
                                                 const int *__restrict__ cols, const T *__restrict__ x,
                                                 long long ldx, T *__restrict__ y, long long ldy, T alpha,
-                                                int flags, int lane, T *xs, Vec16<T> *tile, T (&out)[K]) {
+                                                int flags, int lane, T *xs, Vec16<T> *tile, int *ixm, T (&out)[K]) {
     constexpr int E = TT<T>::E;
     constexpr int G = 64 / P;
     constexpr int NC = G * L * E;
@@ -1045,7 +1049,7 @@ __device__ __forceinline__ void run_panel_multi(const WaveD &wd, const uint4 *__
             }
         }
         for (int c0 = 0; !PIPE && c0 < ncols; c0 += XCH) {
-            if (fwd_en) {
+            if (fwd_en || (BSM_MULTI_IX && trn_en)) {
 #pragma unroll
                 for (int q = 0; q < XCH / 64; ++q) {
                     const int c = q * 64 + lane;
@@ -1053,9 +1057,15 @@ __device__ __forceinline__ void run_panel_multi(const WaveD &wd, const uint4 *__
                     if (w < ncols + NC) {
                         bool ok = w < ncols, off = false;
                         const int xi = ok ? col_lookup(w, off) : 0;
+                        // the chunk's y indices stay in LDS for the emission of its iterations (-1: the column takes no
+                        // part): read from the column list there, every iteration waited for a dependent load in front
+                        // of its atomics
+                        if (BSM_MULTI_IX && TRN) ixm[c] = (ok && (opT || off)) ? xi : -1;
                         ok = ok && (!opT || off);
+                        if (fwd_en) {
 #pragma unroll
-                        for (int k = 0; k < K; ++k) xs[c * K + k] = ok ? x[xi + kc(k) * ldx] : zero_of(T{});
+                            for (int k = 0; k < K; ++k) xs[c * K + k] = ok ? x[xi + kc(k) * ldx] : zero_of(T{});
+                        }
                     }
                 }
             }
@@ -1116,8 +1126,15 @@ __device__ __forceinline__ void run_panel_multi(const WaveD &wd, const uint4 *__
                             const int w = s * E + e;
                             if (w < ncols) {
                                 bool off = false;
-                                const int yi = col_lookup(w, off);
-                                if ((opT || off) && k < kact) {
+                                int yi;
+                                if (BSM_MULTI_IX) {
+                                    yi = ixm[w - c0];
+                                    off = yi >= 0;
+                                } else {
+                                    yi = col_lookup(w, off);
+                                    off = opT || off;
+                                }
+                                if (off && k < kact) {
                                     T *yp = &y[yi + k * ldy];
                                     const T val = mul(alpha, tv[jj]);
                                     if (flags & FLAG_RMW)
@@ -1159,6 +1176,7 @@ __global__ void __launch_bounds__(64 * kWavesPerWg, (kTilePipe<T, L, TRN, K> && 
     constexpr int TILE = PIPE ? 2 * L * 64 : L * 72;
     __shared__ __attribute__((aligned(16))) T xs[kWavesPerWg][FWD ? XS : 1];
     __shared__ Vec16<T> tl[kWavesPerWg][TRN ? TILE : 1];
+    __shared__ int ixm[kWavesPerWg][(TRN && !PIPE && BSM_MULTI_IX) ? XCH : 1];  // y indices of the staged chunk (register path)
 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -1171,13 +1189,13 @@ __global__ void __launch_bounds__(64 * kWavesPerWg, (kTilePipe<T, L, TRN, K> && 
     for (int k = 0; k < K; ++k) u[k] = zero_of(T{});
     if (work == WORK_PANEL) {
         if (m <= 8)
-            run_panel_multi<T, L, 8, FWD, TRN, K>(wd, values, rows, cols, x, ldx, y, ldy, alpha, flags, lane, xs[wave], tl[wave], u);
+            run_panel_multi<T, L, 8, FWD, TRN, K>(wd, values, rows, cols, x, ldx, y, ldy, alpha, flags, lane, xs[wave], tl[wave], ixm[wave], u);
         else if (m <= 16)
-            run_panel_multi<T, L, 16, FWD, TRN, K>(wd, values, rows, cols, x, ldx, y, ldy, alpha, flags, lane, xs[wave], tl[wave], u);
+            run_panel_multi<T, L, 16, FWD, TRN, K>(wd, values, rows, cols, x, ldx, y, ldy, alpha, flags, lane, xs[wave], tl[wave], ixm[wave], u);
         else if (m <= 32)
-            run_panel_multi<T, L, 32, FWD, TRN, K>(wd, values, rows, cols, x, ldx, y, ldy, alpha, flags, lane, xs[wave], tl[wave], u);
+            run_panel_multi<T, L, 32, FWD, TRN, K>(wd, values, rows, cols, x, ldx, y, ldy, alpha, flags, lane, xs[wave], tl[wave], ixm[wave], u);
         else
-            run_panel_multi<T, L, 64, FWD, TRN, K>(wd, values, rows, cols, x, ldx, y, ldy, alpha, flags, lane, xs[wave], tl[wave], u);
+            run_panel_multi<T, L, 64, FWD, TRN, K>(wd, values, rows, cols, x, ldx, y, ldy, alpha, flags, lane, xs[wave], tl[wave], ixm[wave], u);
     }
     const bool direct = (flags & FLAG_DIRECT) != 0;
     const bool sz = (flags & FLAG_STRONG_ZERO) != 0;
