@@ -68,3 +68,28 @@ def test_interior_boundary_split():
         if len(outer["blocks"]):
             assert own[0] <= bt[0] and bt[1] <= own[1]  # they write own rows only, but read beyond
     assert total == len(vp["blocks"])
+
+
+def test_live_traffic_falls_back_when_the_profiler_is_absent(monkeypatch):
+    """bench.live_traffic: no rocprofv3 on the box -> (None, reason); the caller then reads the stamped file"""
+    import shutil
+    import bench
+    monkeypatch.setattr(shutil, "which", lambda name: None)
+    d, why = bench.live_traffic("panel_kernel<double, 8, true, false", 54553920)
+    assert d is None and "rocprofv3" in why
+
+
+def test_fixture_coo_of_the_bench_is_the_reference_operator():
+    """bench.fixture_coo (the parity reference of the BEM legs) against the test suite's own COO product, per element type"""
+    import numpy as np
+    import bench
+    from _common import fixture_problem, scipy_mul, relerr, N
+    for tname, dtn, part, tol in bench.BEM_TYPES:
+        fx = fixture_problem("cuboid", np.dtype(dtn), part)
+        n0 = fx["size"][0]
+        rng = np.random.default_rng(3)
+        x = rng.standard_normal(n0).astype(np.complex128 if np.dtype(dtn).kind == "c" else np.float64)
+        got = bench.fixture_coo(np, fx, n0) @ x
+        ref = scipy_mul({k: ([b.astype(x.dtype) for b in v] if k in ("diagonals", "offdiagonals") else v) for k, v in fx.items()},
+                        N, x, np.zeros(n0, x.dtype))
+        assert relerr(got, ref) < 1e-13, tname
