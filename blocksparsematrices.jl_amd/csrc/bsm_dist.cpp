@@ -63,6 +63,8 @@ struct Part {
     Range rows, cols;  // hull of the row / column indices of its blocks
     hipStream_t stream = nullptr;
     hipEvent_t ev_prod = nullptr, ev_done = nullptr, ev_in = nullptr;
+    hipStream_t done_stream = nullptr;  // where ev_done (or its flag) was last recorded, on `device`
+    bool w_clean = false;               // d_w is zero everywhere (DistState::rezero)
     void *d_x = nullptr, *d_w = nullptr, *d_recv = nullptr;
     Range colpart;  // the part's share of the COLUMN partition (vectors of length ncols held in parts)
 };
@@ -166,7 +168,17 @@ struct DistState {
     bool use_flags = false;
     uint64_t *flags = nullptr;
     uint64_t seq = 0;
-    int last_mode = -1;  // 0 events, 1 flags: a change drains every stream first (the two forms do not see each other)
+    // 0 events, 1 flags, 2 nothing at all (every part AND the caller's vectors on one stream of one device: stream order
+    // is the order): a change drains every device first (the forms do not see each other)
+    int last_mode = -1;
+    hipStream_t last_single_stream = nullptr;  // mode 2: the stream (a different one next time drains as well)
+    // The work vectors of the fused path are ZERO between two products: the finish kernels write zeros behind what they
+    // read (every entry a product writes is read exactly once -- by its owner's finish kernel or by the peer it is
+    // for), so a product accumulates into its work vector without the `w = 0` launch in front (one dependent launch
+    // per part off the critical path).  Part::w_clean = false: unknown contents (fresh buffers, a copy-path product,
+    // a failed product) -- the next fused product that uses the vector clears the whole buffer once.
+    bool rezero = true;  // BSM_DIST_REZERO=0: the zeroing launch in front of every product, as before (A/B, diagnosis)
+    bool one_stream = true;  // BSM_DIST_ONE_STREAM=0: parts that share the caller's device still get streams of their own
 };
 
 }  // namespace bsm
@@ -445,6 +457,8 @@ int dist_create(bsm_matrix_s *A, bsm_ctx_s *ctx, int mtype, int dtype, int64_t n
     }
     D.all_peer = ctx->peer_ok;  // enabled for every pair when the context was created (bsm_ctx_create)
     if (const char *v = std::getenv("BSM_DIST_COPIES")) D.all_peer = D.all_peer && std::atoi(v) == 0;  // tests: force the copy path
+    if (const char *v = std::getenv("BSM_DIST_REZERO")) D.rezero = std::atoi(v) != 0;
+    if (const char *v = std::getenv("BSM_DIST_ONE_STREAM")) D.one_stream = std::atoi(v) != 0;
     {
         // flags: on by default where they have been exercised -- every part on ONE physical device (virtual devices); on
         // distinct devices (a flag polled by another GPU's command processor has never run on this pool) only on request
@@ -496,9 +510,9 @@ static hipError_t grow_buffers(DistState &D, int K) {
     // the fused path works on the CALLERS' streams (run[p] = the part's caller stream), and a peer's finish kernel
     // reads this part's work vector over xGMI: ev_done is recorded on run[p] after the part's last use of the
     // buffers, so every part's ev_done has to be reached too before the first buffer is freed
-    if (D.produced && D.last_mode != 1)
+    if (D.produced && D.last_mode == 0)
         for (int p = 0; p < P && e == hipSuccess; p++) e = hipEventSynchronize(D.parts[p]->ev_done);
-    if (D.produced && D.last_mode == 1) {  // ordered by flags: no event carries the last use -- drain the devices
+    if (D.produced && D.last_mode >= 1) {  // ordered by flags / by one stream: no event carries the last use -- drain the devices
         for (int p = 0; p < P && e == hipSuccess; p++) {
             DeviceGuard g;
             e = g.enter(D.parts[p]->device);
@@ -520,6 +534,7 @@ static hipError_t grow_buffers(DistState &D, int K) {
         if (e == hipSuccess && rb) e = hipMalloc(&pt.d_recv, rb * K);
     }
     if (e == hipSuccess) D.kcap = K;
+    for (auto &pt : D.parts) pt->w_clean = false;
     return e;
 }
 
@@ -573,7 +588,9 @@ static int dist_mul_fused(DistState &D, int op, int K, const std::vector<VecSour
         bool taken = false;
         for (int p = 0; p < P; p++) {
             const VecDest &yd = dst[dst.size() == 1 ? 0 : (size_t)p];
-            const bool mine = yd.sdev == D.parts[p]->device && (dst.size() > 1 || !taken);
+            // (bsm_mul: EVERY part on the caller's device works on the caller's stream -- parts that share a device gain
+            // nothing from streams of their own, and each one costs two cross-stream hops per product)
+            const bool mine = yd.sdev == D.parts[p]->device && (dst.size() > 1 || !taken || D.one_stream);
             run[p] = mine ? yd.stream : D.parts[p]->stream;
             if (mine) taken = true;
         }
@@ -583,8 +600,16 @@ static int dist_mul_fused(DistState &D, int op, int K, const std::vector<VecSour
     // one virtual device -- keeps events: tools/distbench.py, 2 parts 202 vs 188 us)
     bool several_streams = false;
     for (int p = 1; p < P; p++) several_streams = several_streams || run[p] != run[0] || D.parts[p]->device != D.parts[0]->device;
+    // everything on ONE stream of one device -- the parts and the caller's vectors (one part, or partitioned vectors
+    // driven from one stream of one virtual device): stream order is all the ordering there is to do, no event is
+    // recorded and none waited for (every record is a barrier packet between two launches: one part through a
+    // context cost +15 us over the plain handle, tools/distbench.py)
+    bool single = !several_streams;
+    for (const VecSource &s : src) single = single && s.stream == run[0] && s.sdev == D.parts[0]->device;
+    for (const VecDest &d : dst) single = single && d.stream == run[0] && d.sdev == D.parts[0]->device;
     const bool flags = D.use_flags && several_streams;
-    if (D.last_mode >= 0 && D.last_mode != (flags ? 1 : 0)) {
+    const int mode = single ? 2 : (flags ? 1 : 0);
+    if (D.last_mode >= 0 && (D.last_mode != mode || (single && D.last_single_stream != run[0]))) {
         // the previous product of the handle was ordered the other way (events / flags, e.g. the copy path of a host
         // vector in between): the two forms do not see each other, so everything is drained once
         for (int p = 0; p < P; p++) {
@@ -593,7 +618,8 @@ static int dist_mul_fused(DistState &D, int op, int K, const std::vector<VecSour
             DCHECK(hipDeviceSynchronize(), "hipDeviceSynchronize");
         }
     }
-    D.last_mode = flags ? 1 : 0;
+    D.last_mode = mode;
+    D.last_single_stream = single ? run[0] : nullptr;
     // (the counters only ever hold numbers of products ordered by flags: a product ordered by events in between must not
     // consume one, or the next one would wait for a value nobody writes)
     const uint64_t prev_seq = D.seq;
@@ -602,9 +628,11 @@ static int dist_mul_fused(DistState &D, int op, int K, const std::vector<VecSour
     const uint64_t kAll = ~(uint64_t)0;
     // "recorded" / "waited for": an event, or (flags) the product's sequence number in a counter
     auto signal = [&](hipEvent_t ev, int flag, hipStream_t st) -> hipError_t {
+        if (single) return hipSuccess;
         return flags ? hipStreamWriteValue64(st, F + flag, seq, 0) : hipEventRecord(ev, st);
     };
     auto await = [&](hipStream_t st, hipEvent_t ev, int flag, uint64_t value) -> hipError_t {
+        if (single) return hipSuccess;
         return flags ? hipStreamWaitValue64(st, F + flag, value, hipStreamWaitValueGte, kAll) : hipStreamWaitEvent(st, ev, 0);
     };
     // "x (and the incoming y) are ready" on every stream that produces them
@@ -622,6 +650,10 @@ static int dist_mul_fused(DistState &D, int op, int K, const std::vector<VecSour
         for (const VecDest &d : dst) DCHECK(record(d.ready, d.ready_flag, d.stream, d.sdev), "record: inputs ready");
     }
     const bool was_produced = D.produced;
+    const bool rezero = D.rezero;  // this product leaves the work vectors it uses zero again
+    static const float kOneF[2] = {1.f, 0.f};
+    static const double kOneD[2] = {1.0, 0.0};
+    const void *one = (D.dtype == 0 || D.dtype == 2) ? (const void *)kOneF : (const void *)kOneD;
     // A part that neither sends nor receives a y segment (VBCRS forward: block rows own disjoint y ranges,
     // reference src/vbcrs.jl:275-283) multiplies straight into the caller's y -- beta fused, no work vector,
     // no delivery launch.
@@ -652,13 +684,24 @@ static int dist_mul_fused(DistState &D, int op, int K, const std::vector<VecSour
         if (ph == 0) {
             // peers that read this part's work vector in the previous product have finished (their ev_done
             // carries that product's record until phase 1 of THIS product re-records it, after a host barrier)
-            if (was_produced) {
-                // (flags: the previous product's number; a first fused product after copy-path ones was drained above)
+            if (was_produced && !single) {
+                // (flags: the previous product's number; a first fused product after copy-path ones was drained above.
+                // Every wait is a packet in front of the product: each delivery once, and none for a delivery that was
+                // recorded on this very stream)
+                std::vector<int> waited;
+                auto previous = [&](int q) -> hipError_t {
+                    const Part &pq = *D.parts[q];
+                    if (pq.done_stream == st && pq.device == pt.device) return hipSuccess;
+                    for (int w : waited)
+                        if (w == q) return hipSuccess;
+                    waited.push_back(q);
+                    return await(st, pq.ev_done, 2 * P + q, prev_seq);
+                };
                 for (const Transfer &t : D.plan_n.transfers)
-                    if (t.from == p) DCHECK(await(st, D.parts[t.to]->ev_done, 2 * P + t.to, prev_seq), "wait: previous delivery");
+                    if (t.from == p) DCHECK(previous(t.to), "wait: previous delivery");
                 for (const Transfer &t : D.plan_t.transfers)
-                    if (t.from == p) DCHECK(await(st, D.parts[t.to]->ev_done, 2 * P + t.to, prev_seq), "wait: previous delivery");
-                DCHECK(await(st, pt.ev_done, 2 * P + p, prev_seq), "wait: previous delivery");  // its own previous delivery (another stream, perhaps)
+                    if (t.from == p) DCHECK(previous(t.to), "wait: previous delivery");
+                DCHECK(previous(p), "wait: previous delivery");  // its own previous delivery (another stream, perhaps)
                 if (!flags && D.ev_tail) DCHECK(hipStreamWaitEvent(st, D.ev_tail, 0), "hipStreamWaitEvent");
             }
             DCHECK(wait_for(p, yd.ready, yd.ready_flag, yd.stream, yd.sdev), "wait: y ready");  // the incoming y (numeric beta) / its buffer
@@ -694,12 +737,20 @@ static int dist_mul_fused(DistState &D, int op, int K, const std::vector<VecSour
                 const long long z[2] = {zr.lo, zr.hi};
                 void *target = direct[p] ? (void *)yd.base : pt.d_w;
                 const long long tld = direct[p] ? ldy : (long long)vlen;
-                const void *b = direct[p] ? beta : nullptr;
-                const int sz = direct[p] ? beta_strong_zero : 1;
+                // into the work vector: `w = 0` first -- or, when the finish kernels keep it zero, plain accumulation
+                // (beta = 1: no launch in front; unknown contents are cleared once, whole buffer)
+                if (!direct[p] && rezero && !pt.w_clean)
+                    DCHECK(hipMemsetAsync(pt.d_w, 0, (size_t)D.kcap * vlen * es, st), "memset");
+                if (!direct[p]) pt.w_clean = false;  // (until the whole product has been issued)
+                const void *b = direct[p] ? beta : (rezero ? one : nullptr);
+                const int sz = direct[p] ? beta_strong_zero : (rezero ? 0 : 1);
                 if (K == 1)
                     DCHECK(launch_mul(pt.img, opT, conj, xp, target, alpha, b, sz, st, false, z), "kernel launch");
                 else
                     DCHECK(launch_mul_multi(pt.img, opT, conj, K, xp, xld, target, tld, alpha, b, sz, st, z), "kernel launch");
+            } else if (rezero) {
+                if (!pt.w_clean) DCHECK(hipMemsetAsync(pt.d_w, 0, (size_t)D.kcap * vlen * es, st), "memset");
+                pt.w_clean = false;
             } else if (!zr.empty()) {
                 for (int k = 0; k < K; k++)
                     DCHECK(hipMemsetAsync((char *)pt.d_w + ((size_t)k * vlen + zr.lo) * es, 0, (size_t)zr.len() * es, st), "memset");
@@ -715,7 +766,7 @@ static int dist_mul_fused(DistState &D, int op, int K, const std::vector<VecSour
             Part &from = *D.parts[t.from];
             DCHECK(wait_for(p, from.ev_prod, P + t.from, run[(size_t)t.from], from.device), "wait: peer's product");
             if (np == kMaxVecPieces) {  // more peers than one launch takes: fold these into the work vector first
-                DCHECK(launch_vec_finish(D.dtype, nullptr, 0, pt.d_w, (long long)vlen, pc, np, o.lo, o.hi, nullptr, 1, 1, K, st), "halo add");
+                DCHECK(launch_vec_finish(D.dtype, nullptr, 0, pt.d_w, (long long)vlen, pc, np, o.lo, o.hi, nullptr, 1, 1, rezero, K, st), "halo add");
                 np = 0;
             }
             pc.base[np] = from.d_w;
@@ -725,9 +776,10 @@ static int dist_mul_fused(DistState &D, int op, int K, const std::vector<VecSour
             np++;
         }
         if (!o.empty() && !direct[p])
-            DCHECK(launch_vec_finish(D.dtype, yd.base, ldy, pt.d_w, (long long)vlen, pc, np, o.lo, o.hi, beta, beta_strong_zero, 0, K,
-                                     st), "y delivery");
+            DCHECK(launch_vec_finish(D.dtype, yd.base, ldy, pt.d_w, (long long)vlen, pc, np, o.lo, o.hi, beta, beta_strong_zero, 0, rezero,
+                                     K, st), "y delivery");
         DCHECK(signal(pt.ev_done, 2 * P + p, st), "record: delivery done");
+        pt.done_stream = st;
         return BSM_OK;
     };
     for (int ph = 0; ph < 2; ph++) {
@@ -739,6 +791,8 @@ static int dist_mul_fused(DistState &D, int op, int K, const std::vector<VecSour
         if (rc != BSM_OK) return rc;
     }
     D.produced = true;
+    for (int p = 0; p < P; p++)
+        if (!direct[p]) D.parts[p]->w_clean = rezero;
     // the consumers of y continue when the parts that deliver to them are done
     for (int q = 0; q < P; q++) {
         const VecDest &yd = dst[dst.size() == 1 ? 0 : (size_t)q];
@@ -778,7 +832,7 @@ static int dist_mul_copies(bsm_matrix_s *A, int op, int K, const void *x, long l
     } while (0)
 
     DCHECK(grow_buffers(D, K), "multi-device buffers");
-    if (D.last_mode == 1) {  // the previous product was ordered by flags, this path orders by events: drain once
+    if (D.last_mode >= 1) {  // the previous product was ordered by flags (or by one stream), this path orders by events: drain once
         for (int p = 0; p < P; p++) {
             DeviceGuard g;
             DCHECK(g.enter(D.parts[p]->device), "hipSetDevice");
@@ -786,6 +840,7 @@ static int dist_mul_copies(bsm_matrix_s *A, int op, int K, const void *x, long l
         }
     }
     D.last_mode = 0;
+    for (auto &pt : D.parts) pt->w_clean = false;  // (this path leaves its partial sums in the work vectors)
     int cur = 0;
     DCHECK(hipGetDevice(&cur), "hipGetDevice");
     int xdev = -1, ydev = -1, sdev = cur;

@@ -60,7 +60,7 @@ hipError_t launch_vec_fetch(int dtype, void *dst, long long ld_dst, const VecPie
 // y[i] = beta * y[i] + w[i] + sum of the pieces covering i, i in [lo, hi), K columns (w and the pieces: column stride
 // ldw); accumulate_only: the sum goes back to w instead (more than kMaxVecPieces contributions)
 hipError_t launch_vec_finish(int dtype, void *y, long long ldy, void *w, long long ldw, const VecPieces &pc, int npieces,
-                             long long lo, long long hi, const void *beta, int strong_zero, int accumulate_only, int K,
+                             long long lo, long long hi, const void *beta, int strong_zero, int accumulate_only, int rezero, int K,
                              hipStream_t stream);
 
 // nrhs right-hand sides: X (ldx) and Y (ldy) column-major; A is streamed once per batch of <= 8.

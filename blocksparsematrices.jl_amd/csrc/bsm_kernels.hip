@@ -1642,20 +1642,28 @@ __global__ void __launch_bounds__(256) vec_fetch_kernel(T *__restrict__ dst, lon
         d[i] = src[i];
 }
 
-// y[i] = (strong ? 0 : beta * y[i]) + w[i] + sum over the pieces that cover i;  accumulate_only: w[i] += ... (no y)
+// y[i] = (strong ? 0 : beta * y[i]) + w[i] + sum over the pieces that cover i;  accumulate_only: w[i] += ... (no y).
+// rezero: zeros are written behind everything that is read (own work vector and the peers' segments, over xGMI where
+// they are remote), so the work vectors are zero again when the launch is over -- the next product accumulates into
+// them without a `w = 0` launch in front (bsm_dist.cpp: DistState::w_clean)
 template <typename T>
 __global__ void __launch_bounds__(256) vec_finish_kernel(T *__restrict__ y, long long ldy, T *__restrict__ w, long long ldw,
                                                          VecPieces pc, int npieces, long long lo, long long hi, T beta,
-                                                         int strong_zero, int accumulate_only) {
+                                                         int strong_zero, int accumulate_only, int rezero) {
     const long long k = blockIdx.y;
     T *__restrict__ wk = w + k * ldw;
     for (long long i = lo + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < hi; i += (long long)gridDim.x * blockDim.x) {
         T v = wk[i];
         for (int c = 0; c < npieces; ++c)
-            if (i >= pc.lo[c] && i < pc.hi[c]) v = add(v, (reinterpret_cast<const T *>(pc.base[c]) + k * ldw)[i]);
+            if (i >= pc.lo[c] && i < pc.hi[c]) {
+                T *pe = const_cast<T *>(reinterpret_cast<const T *>(pc.base[c])) + k * ldw + i;
+                v = add(v, *pe);
+                if (rezero) *pe = zero_of(T{});
+            }
         if (accumulate_only) {
             wk[i] = v;
         } else {
+            if (rezero) wk[i] = zero_of(T{});
             T *__restrict__ yk = y + k * ldy;
             yk[i] = strong_zero ? v : madd(v, beta, yk[i]);
         }
@@ -1686,22 +1694,23 @@ hipError_t launch_vec_fetch(int dtype, void *dst, long long ld_dst, const VecPie
 }
 template <typename T>
 static hipError_t finish_typed(void *y, long long ldy, void *w, long long ldw, const VecPieces &pc, int npieces, long long lo,
-                               long long hi, const void *beta_p, int strong_zero, int accumulate_only, int K, hipStream_t stream) {
+                               long long hi, const void *beta_p, int strong_zero, int accumulate_only, int rezero, int K,
+                               hipStream_t stream) {
     if (hi <= lo) return hipSuccess;
     long long nblk = (hi - lo + 255) / 256;
     if (nblk > 2048) nblk = 2048;
     hipLaunchKernelGGL((vec_finish_kernel<T>), dim3((unsigned)nblk, (unsigned)K), dim3(256), 0, stream, (T *)y, ldy, (T *)w, ldw, pc,
-                       npieces, lo, hi, load_scalar<T>(beta_p, 0.0), strong_zero, accumulate_only);
+                       npieces, lo, hi, load_scalar<T>(beta_p, 0.0), strong_zero, accumulate_only, rezero);
     return hipGetLastError();
 }
 hipError_t launch_vec_finish(int dtype, void *y, long long ldy, void *w, long long ldw, const VecPieces &pc, int npieces,
-                             long long lo, long long hi, const void *beta, int strong_zero, int accumulate_only, int K,
+                             long long lo, long long hi, const void *beta, int strong_zero, int accumulate_only, int rezero, int K,
                              hipStream_t stream) {
     switch (dtype) {
-        case 0: return finish_typed<float>(y, ldy, w, ldw, pc, npieces, lo, hi, beta, strong_zero, accumulate_only, K, stream);
-        case 1: return finish_typed<double>(y, ldy, w, ldw, pc, npieces, lo, hi, beta, strong_zero, accumulate_only, K, stream);
-        case 2: return finish_typed<c64>(y, ldy, w, ldw, pc, npieces, lo, hi, beta, strong_zero, accumulate_only, K, stream);
-        case 3: return finish_typed<c128>(y, ldy, w, ldw, pc, npieces, lo, hi, beta, strong_zero, accumulate_only, K, stream);
+        case 0: return finish_typed<float>(y, ldy, w, ldw, pc, npieces, lo, hi, beta, strong_zero, accumulate_only, rezero, K, stream);
+        case 1: return finish_typed<double>(y, ldy, w, ldw, pc, npieces, lo, hi, beta, strong_zero, accumulate_only, rezero, K, stream);
+        case 2: return finish_typed<c64>(y, ldy, w, ldw, pc, npieces, lo, hi, beta, strong_zero, accumulate_only, rezero, K, stream);
+        case 3: return finish_typed<c128>(y, ldy, w, ldw, pc, npieces, lo, hi, beta, strong_zero, accumulate_only, rezero, K, stream);
     }
     return hipErrorInvalidValue;
 }

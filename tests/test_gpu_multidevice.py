@@ -282,15 +282,20 @@ def test_single_product_then_a_wider_batch_without_a_sync_in_between(torch_cuda,
         del A
 
 
-@pytest.mark.parametrize("mode", ["1", "0"])
-def test_flag_and_event_ordering_of_the_fan_out(torch_cuda, bsm, oracle, monkeypatch, mode):
+@pytest.mark.parametrize("mode,own_streams,rezero", [("1", "1", "1"), ("0", "1", "1"), ("1", "0", "1"), ("1", "1", "0"), ("0", "0", "0")])
+def test_flag_and_event_ordering_of_the_fan_out(torch_cuda, bsm, oracle, monkeypatch, mode, own_streams, rezero):
     """The cross-stream ordering of a multi-device product by stream memory operations (hipStreamWriteValue64 /
-    hipStreamWaitValue64 on sequence counters, BSM_DIST_FLAGS=1: the default on virtual devices) and by events (=0):
+    hipStreamWaitValue64 on sequence counters, BSM_DIST_FLAGS=1: the default on virtual devices) and by events (=0),
+    with the parts on streams of their own (BSM_DIST_ONE_STREAM=0: what distinct devices do) and all on the caller's
+    stream (the default for parts that share the caller's device: no ordering packets at all), work vectors kept zero
+    by the finish kernels (BSM_DIST_REZERO=1) or cleared in front of every product (=0):
     chained device products with no synchronisation in between, a host-vector product (copy path: events) in the middle
-    -- the switch between the two forms drains the streams --, partitioned vectors, a second caller stream; everything
+    -- the switch between the forms drains the streams --, partitioned vectors, a second caller stream; everything
     against the oracle."""
     torch = torch_cuda
     monkeypatch.setenv("BSM_DIST_FLAGS", mode)
+    monkeypatch.setenv("BSM_DIST_ONE_STREAM", "0" if own_streams == "1" else "1")
+    monkeypatch.setenv("BSM_DIST_REZERO", rezero)
     prob = bsm.synthetic.config5(n=40_000, lo=16, hi=96, halfband=3)
     n = prob["size"][0]
     A = bsm.synthetic.build(prob, devices=[0, 0, 0])
@@ -325,6 +330,54 @@ def test_flag_and_event_ordering_of_the_fan_out(torch_cuda, bsm, oracle, monkeyp
     torch.cuda.synchronize()
     assert relerr(torch.cat(yp).cpu().numpy(), refs[0]) < 1e-12
     assert relerr(yd[1].cpu().numpy(), refs[0]) < 1e-12
+
+
+@pytest.mark.parametrize("own_streams", ["0", "1"])
+def test_work_vectors_stay_zero_across_directions_batches_and_paths(torch_cuda, bsm, oracle, monkeypatch, own_streams):
+    """The finish kernels write zeros behind what they read, so a product accumulates into its part's work vector
+    without a `w = 0` launch in front (csrc/bsm_dist.cpp: DistState::w_clean).  The invariant has to survive
+    everything that touches those vectors: the two directions of a VBCRS operator (different segments travel), a
+    multi-RHS batch that re-allocates them, a copy-path product (host vectors) that leaves partial sums in them,
+    NaN in the incoming y, numeric beta -- chained without synchronisation, each against the oracle."""
+    torch = torch_cuda
+    monkeypatch.setenv("BSM_DIST_ONE_STREAM", "0" if own_streams == "1" else "1")
+    for prob in (bsm.synthetic.config2(n=12_000, nblocks=500), bsm.synthetic.config5(n=30_000, lo=16, hi=96, halfband=3)):
+        n = prob["size"][0]
+        A = bsm.synthetic.build(prob, devices=[0, 0, 0])
+        rng = np.random.default_rng(31)
+        x = rng.standard_normal(n)
+        xd = torch.from_numpy(x).cuda()
+        got, want = [], []
+
+        def dev(op, alpha=1.0, beta=0.0, strong=True):
+            y0 = rng.standard_normal(n)
+            if strong:
+                y0[::5] = np.nan
+            yd = torch.from_numpy(y0.copy()).cuda()
+            bsm.mul(yd, wrap(bsm, A, op), xd, alpha, False if strong else beta)
+            got.append(yd)
+            want.append(oracle_mul(oracle, prob, op, x, y0, alpha, beta, strong))
+
+        dev(N)
+        dev(T)                                    # the other plan: other segments of the work vectors travel
+        dev(T, 0.5, -2.0, False)
+        X = rng.standard_normal((n, 5))           # a batch: the work vectors are re-allocated (5 columns)
+        Xd = torch.from_numpy(np.ascontiguousarray(X.T)).cuda().t()
+        Yd = torch.full((5, n), float("nan"), dtype=torch.float64, device="cuda").t()
+        bsm.mul(Yd, wrap(bsm, A, T), Xd)
+        dev(N, 2.0, 1.0, False)
+        yh = np.zeros(n)
+        bsm.mul(yh, wrap(bsm, A, T), x)           # host vectors: the copy path leaves its sums in the work vectors
+        dev(T)
+        dev(N)
+        torch.cuda.synchronize()
+        for k, (g, w) in enumerate(zip(got, want)):
+            assert relerr(g.cpu().numpy(), w) < 1e-12, (own_streams, prob["kind"], k)
+        Yg = Yd.cpu().numpy()
+        for k in range(5):
+            assert relerr(Yg[:, k], oracle_mul(oracle, prob, T, np.ascontiguousarray(X[:, k]), np.zeros(n))) < 1e-12, k
+        assert relerr(yh, oracle_mul(oracle, prob, T, x, np.zeros(n))) < 1e-12
+        del A
 
 
 # ---- partitioned vectors behind the C ABI: bsm_mul_parts ------------------------------------------------------------
