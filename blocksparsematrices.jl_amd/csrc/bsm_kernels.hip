@@ -794,6 +794,43 @@ template <typename T> __device__ __forceinline__ void settle(T &v) {
     asm volatile("" : "+v"(v));
 }
 
+// ----------------------------------------------------------------------------------------
+// ComplexF64, 8 right-hand sides: the matrix pipe.  A complex product with 8 columns is a REAL product with 16:
+//     Y = B X,  X' = X as 16 real columns (Re, Im interleaved),  X'' = i X likewise   =>   Y (interleaved) = Re(B) X' + Im(B) X''
+// -- exactly the N = 16 of v_mfma_f64_16x16x4_f64, and both halves land in ONE accumulator.  (conj(B): X'' negated.)
+// The instruction runs at the vector FMA rate (tools/mfma_rate.hip: 47 vs 56 TFLOP/s), so in real arithmetic -- 8
+// of the 16 columns idle -- it buys nothing; here it replaces 64 v_fma_f64 wave-instructions per 16 bytes of
+// matrix and lane by 4 MFMAs per 64 lanes, and the K accumulators / x rows per lane (241 VGPRs = 2 waves per SIMD,
+// BEM x 8 at 6.1 single products) by 8 VGPRs per 16 x 16 output tile.
+//   lane = (ln = lane % 16, lk = lane / 16);  A operand: lane holds A[ln][lk], B operand: B[lk][ln],
+//   C / D: column ln, rows lk + 4 r (r = 0..3)                      (guide: cdna_hip_programming.md, f64 layout)
+// Forward half, per tile of 16 rows x 16 columns (4 loads of 16 bytes per lane: lane = row ln of the row block,
+// column 4 j + lk): A = Re / Im of the loaded element, B = X' / X'' of the staged x slice (LDS, [column][k] complex
+// = 16 doubles per column; X'' is X' with neighbouring lanes swapped and a sign: one DPP move), accumulator = the row block's
+// 16 x 16 sums for the whole panel.
+// Transposed half: the tile goes through LDS once ([column][row], stride 17 units) and comes back with lane =
+// (column ln, row 4 q + lk) -- as the B operand; A = X' / X'' of the panel's x ROWS (registers, loaded once per
+// panel), so the 16 x 16 sums of a column tile come out with the COLUMN on the lane (consecutive lanes = consecutive
+// y entries); they are complete after the panel's row blocks and leave as scalar atomics, 4 per lane.
+// ----------------------------------------------------------------------------------------
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+#ifndef BSM_MFMA_C128
+#define BSM_MFMA_C128 1
+#endif
+template <typename T, int K> constexpr bool kMfmaPath = BSM_MFMA_C128 && std::is_same<T, c128>::value && K == 8;
+// ComplexF32 likewise on v_mfma_f32_16x16x4_f32 (C / D: column ln, rows 4 lk + r -- the f32 map, not the f64 one).  A
+// 16-byte load holds TWO columns of a row (strip = 2 columns): one load feeds 4 MFMAs (2 columns x Re / Im), the k
+// index of an MFMA runs over the 4 strips of the load.  For the transposed sums to leave as contiguous runs (one
+// wave-instruction = Re and Im of 16 consecutive y entries for two k) the x rows enter the A operand with their 16
+// components in transposed order: lane ln holds component 4 (ln % 4) + ln / 4, so accumulator row 4 lk + r is
+// component 4 r + lk = (k = 2 r + lk / 2, Re / Im = lk % 2).
+#ifndef BSM_MFMA_C64
+#define BSM_MFMA_C64 1
+#endif
+typedef float v4f32 __attribute__((ext_vector_type(4)));
+template <typename T, int K> constexpr bool kMfmaPath32 = BSM_MFMA_C64 && std::is_same<T, c64>::value && K == 8;
+template <typename T, int K> constexpr bool kMfmaAny = kMfmaPath<T, K> || kMfmaPath32<T, K>;
+
 template <typename T, int L, int P, bool FWD, bool TRN, int K>
 __device__ __forceinline__ void run_panel_multi(const WaveD &wd, const uint4 *__restrict__ values,
                                                 const int *__restrict__ rows,
@@ -832,8 +869,58 @@ __device__ __forceinline__ void run_panel_multi(const WaveD &wd, const uint4 *__
     constexpr int PM = P + 1;  // strip stride in the LDS tile (16-byte units): conflict-free for both layouts
     static_assert(NS <= 64, "an iteration's strips must fit the wave");
     const int sp = lane % NS, rg = lane / NS;
-    T xrr[TRN ? L : 1][K];
-    if (TRN) {
+    // matrix-pipe path (above): row blocks of 16, the x rows of the panel as B operands, one accumulator per row block
+    constexpr bool MF = kMfmaPath<T, K>;
+    constexpr int MR = (P + 15) / 16;
+    const int ln = lane & 15, lk = lane >> 4;
+    double xr1[(MF && TRN) ? 4 * MR : 1];  // (X'' of a row is X' with neighbouring lanes swapped, and a sign)
+    v4f64 facc[MF ? MR : 1];
+    if constexpr (MF) {
+#pragma unroll
+        for (int rb = 0; rb < MR; ++rb) facc[rb] = v4f64{0.0, 0.0, 0.0, 0.0};
+        if (TRN) {
+#pragma unroll
+            for (int q = 0; q < 4 * MR; ++q) {
+                const int r = 4 * q + lk;
+                double re = 0.0, im = 0.0;
+                if (r < m) {
+                    const int ri = (wd.rbase >= 0) ? wd.rbase + r : rows[wd.row_off + r];
+                    const double *px = reinterpret_cast<const double *>(&x[ri + kc(ln >> 1) * ldx]);
+                    re = px[0];
+                    im = px[1];
+                }
+                // (alpha goes in here: the transposed sums leave the lanes as they come out of the accumulator)
+                xr1[q] = (ln & 1) ? alpha.re * im + alpha.im * re : alpha.re * re - alpha.im * im;
+            }
+        }
+    }
+    constexpr bool MF32 = kMfmaPath32<T, K>;
+    constexpr bool MFA = MF || MF32;
+    float fr1[(MF32 && TRN) ? 4 * MR : 1], fr2[(MF32 && TRN) ? 4 * MR : 1];
+    v4f32 facc32[MF32 ? MR : 1];
+    if constexpr (MF32) {
+#pragma unroll
+        for (int rb = 0; rb < MR; ++rb) facc32[rb] = v4f32{0.f, 0.f, 0.f, 0.f};
+        if (TRN) {
+            const int comp = 4 * (ln & 3) + (ln >> 2);  // the component this lane carries in the A operand (above)
+#pragma unroll
+            for (int q = 0; q < 4 * MR; ++q) {
+                const int r = 4 * q + lk;
+                float re = 0.f, im = 0.f;
+                if (r < m) {
+                    const int ri = (wd.rbase >= 0) ? wd.rbase + r : rows[wd.row_off + r];
+                    const c64 xv = x[ri + kc(comp >> 1) * ldx];
+                    re = alpha.re * xv.re - alpha.im * xv.im;  // (alpha goes in here)
+                    im = alpha.re * xv.im + alpha.im * xv.re;
+                }
+                fr1[q] = (comp & 1) ? im : re;                    // X'
+                fr2[q] = (comp & 1) ? re : -im;                   // X'' = i X
+                if (cjf) fr2[q] = -fr2[q];
+            }
+        }
+    }
+    T xrr[(TRN && !MFA) ? L : 1][K];
+    if (TRN && !MFA) {
 #pragma unroll
         for (int j = 0; j < L; ++j) {
             const int r = rg * L + j;
@@ -1048,13 +1135,14 @@ __device__ __forceinline__ void run_panel_multi(const WaveD &wd, const uint4 *__
                 emit();
             }
         }
-        for (int c0 = 0; !PIPE && c0 < ncols; c0 += XCH) {
+        // the x slice (forward half) and the y indices (transposed half) of the chunk of columns at c0
+        auto stage_columns = [&](int c0) {
             if (fwd_en || (BSM_MULTI_IX && trn_en)) {
 #pragma unroll
                 for (int q = 0; q < XCH / 64; ++q) {
                     const int c = q * 64 + lane;
                     const int w = c0 + c;
-                    if (w < ncols + NC) {
+                    if (MFA || w < ncols + NC) {  // (the matrix-pipe tiles read whole 16-column tiles of the slice)
                         bool ok = w < ncols, off = false;
                         const int xi = ok ? col_lookup(w, off) : 0;
                         // the chunk's y indices stay in LDS for the emission of its iterations (-1: the column takes no
@@ -1069,6 +1157,196 @@ __device__ __forceinline__ void run_panel_multi(const WaveD &wd, const uint4 *__
                     }
                 }
             }
+        };
+        if constexpr (MF) {
+            // one step = one row block (16 rows) of one column tile (16 columns): 4 loads of 16 bytes per lane, issued
+            // one step ahead of their use
+            const double *xsd = reinterpret_cast<const double *>(xs);
+            const int nrb = (m + 15) >> 4;
+            auto fetch = [&](c128(&b)[4], int t0, int rb) {
+                const int row = rb * 16 + ln;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int w = t0 + 4 * j + lk;
+                    if (row < m && w < ncols && !BSM_DBG(DBG_NO_MATRIX)) {
+                        const Vec16<T> q = load_stream16(&vb[(uint32_t)(w * m + row)]);
+                        b[j] = q.v[0];
+                    } else {
+                        b[j] = c128{0.0, 0.0};
+                    }
+                }
+            };
+            // Vector-memory operations retire in issue order and an atomic's round trip to the memory side is long: sums
+            // emitted right behind a tile would stand between the NEXT loads and their wait.  They are parked (4 sums, 4
+            // indices per lane) and leave one step later, right BEHIND the following step's loads -- whose wait then
+            // only has to let the 4 younger atomics pass.
+            // The transposed sums come out TRANSPOSED (operands swapped: A = the x rows, B = the tile), lane = (column
+            // ln, component n = lk + 4 r = Re / Im of k = n / 2): one wave-instruction adds Re and Im of 16 consecutive
+            // columns for two k -- two runs of 256 contiguous bytes, 8-10 cache lines.  What the memory-side atomics
+            // cost is the number of LINES a wave-instruction touches (measured on the BEM fixture, atomics alone:
+            // 12-16 lines 390 us, 16-20 lines 520 us).
+            double pd[4];
+            int pyi = -1;
+            bool pending = false;
+            auto emit = [&]() {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int n = lk + 4 * r;  // k = n / 2, Re / Im = n % 2 (alpha is in the x rows already)
+                    const double val = pd[r];
+                    if (pyi >= 0 && (n >> 1) < kact) {
+                        double *yp = reinterpret_cast<double *>(&y[pyi + (n >> 1) * ldy]) + (n & 1);
+                        if (flags & FLAG_RMW)
+                            *yp += val;
+                        else if (!BSM_DBG(DBG_NO_GLOBAL_ATOMICS))
+                            atomicAdd(yp, val);
+                    }
+                }
+                pending = false;
+            };
+            c128 nxt[4];
+            fetch(nxt, 0, 0);
+            for (int t0 = 0; t0 < ncols; t0 += 16) {
+                const int c0 = t0 & ~(XCH - 1);
+                if (t0 == c0) stage_columns(c0);
+                const int t_end = min(ncols, c0 + XCH);
+                v4f64 dt = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int rb = 0; rb < MR; ++rb) {
+                    if (rb >= nrb) break;  // (wave-uniform)
+                    c128 b[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) b[j] = nxt[j];
+                    if (rb + 1 < nrb)
+                        fetch(nxt, t0, rb + 1);
+                    else if (t0 + 16 < ncols)
+                        fetch(nxt, t0 + 16, 0);
+                    if (pending) emit();
+                    if (fwd_en && !BSM_DBG(DBG_NO_FWD_HALF)) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int wl = t0 - c0 + 4 * j + lk;  // column of the staged slice ([column][k] complex)
+                            const double x1 = xsd[wl * 16 + ln];
+                            double x2 = dppx<DPP_QUAD_XOR1>(x1);  // the other component of the same k: the neighbouring lane
+                            x2 = (((ln & 1) == 0) != cjf) ? -x2 : x2;
+                            facc[rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(b[j].re, x1, facc[rb], 0, 0, 0);
+                            facc[rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(b[j].im, x2, facc[rb], 0, 0, 0);
+                        }
+                    }
+                    if (trn_en && !BSM_DBG(DBG_NO_TRN_HALF)) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) tile[(4 * j + lk) * 17 + ln].v[0] = b[j];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const c128 u = tile[ln * 17 + 4 * q + lk].v[0];
+                            const double r1 = xr1[rb * 4 + q];
+                            double r2 = dppx<DPP_QUAD_XOR1>(r1);
+                            r2 = (((ln & 1) == 0) != cjf) ? -r2 : r2;
+                            dt = __builtin_amdgcn_mfma_f64_16x16x4f64(r1, u.re, dt, 0, 0, 0);
+                            dt = __builtin_amdgcn_mfma_f64_16x16x4f64(r2, u.im, dt, 0, 0, 0);
+                        }
+                    }
+                }
+                if (trn_en) {
+                    // lane (ln, lk) holds components lk + 4 r of column t0 + ln
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) pd[r] = dt[r];
+                    pyi = (t0 + ln < t_end) ? ixm[t0 + ln - c0] : -1;  // (read now: the next chunk's staging overwrites the list)
+                    pending = true;
+                }
+            }
+            if (pending) emit();
+        }
+        if constexpr (MF32) {
+            // one step = one row block (16 rows) of one column tile (16 columns = 8 strips): 2 loads of 16 bytes per
+            // lane (lane = row ln, strip 4 j + lk), issued one step ahead; everything else as in the ComplexF64 loop
+            const float *xsf = reinterpret_cast<const float *>(xs);
+            c64 *tile8 = reinterpret_cast<c64 *>(tile);
+            const int nrb = (m + 15) >> 4;
+            auto fetch = [&](Vec16<T>(&b)[2], int t0, int rb) {
+                const int row = rb * 16 + ln;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int sidx = (t0 >> 1) + 4 * j + lk;
+                    if (row < m && sidx < nstrips && !BSM_DBG(DBG_NO_MATRIX)) {
+                        b[j] = load_stream16(&vb[(uint32_t)(sidx * m + row)]);
+                    } else {
+                        b[j].v[0] = c64{0.f, 0.f};
+                        b[j].v[1] = c64{0.f, 0.f};
+                    }
+                }
+            };
+            float pd[4];
+            int pyi = -1;
+            bool pending = false;
+            auto emit = [&]() {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int kq = 2 * r + (lk >> 1);  // accumulator row 4 lk + r = component 4 r + lk
+                    if (pyi >= 0 && kq < kact) {
+                        float *yp = reinterpret_cast<float *>(&y[pyi + kq * ldy]) + (lk & 1);
+                        if (flags & FLAG_RMW)
+                            *yp += pd[r];
+                        else if (!BSM_DBG(DBG_NO_GLOBAL_ATOMICS))
+                            atomicAdd(yp, pd[r]);
+                    }
+                }
+                pending = false;
+            };
+            Vec16<T> nxt[2];
+            fetch(nxt, 0, 0);
+            for (int t0 = 0; t0 < ncols; t0 += 16) {
+                const int c0 = t0 & ~(XCH - 1);
+                if (t0 == c0) stage_columns(c0);
+                const int t_end = min(ncols, c0 + XCH);
+                v4f32 dt = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int rb = 0; rb < MR; ++rb) {
+                    if (rb >= nrb) break;  // (wave-uniform)
+                    Vec16<T> b[2];
+                    b[0] = nxt[0];
+                    b[1] = nxt[1];
+                    if (rb + 1 < nrb)
+                        fetch(nxt, t0, rb + 1);
+                    else if (t0 + 16 < ncols)
+                        fetch(nxt, t0 + 16, 0);
+                    if (pending) emit();
+                    if (fwd_en && !BSM_DBG(DBG_NO_FWD_HALF)) {
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+#pragma unroll
+                            for (int e = 0; e < 2; ++e) {
+                                const int wl = t0 - c0 + 2 * (4 * j + lk) + e;  // column of the staged slice
+                                const float x1 = xsf[wl * 16 + ln];
+                                float x2 = dppx<DPP_QUAD_XOR1>(x1);
+                                x2 = (((ln & 1) == 0) != cjf) ? -x2 : x2;
+                                facc32[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[j].v[e].re, x1, facc32[rb], 0, 0, 0);
+                                facc32[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[j].v[e].im, x2, facc32[rb], 0, 0, 0);
+                            }
+                    }
+                    if (trn_en && !BSM_DBG(DBG_NO_TRN_HALF)) {
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+#pragma unroll
+                            for (int e = 0; e < 2; ++e) tile8[(2 * (4 * j + lk) + e) * 17 + ln] = b[j].v[e];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const c64 u = tile8[ln * 17 + 4 * q + lk];
+                            dt = __builtin_amdgcn_mfma_f32_16x16x4f32(fr1[rb * 4 + q], u.re, dt, 0, 0, 0);
+                            dt = __builtin_amdgcn_mfma_f32_16x16x4f32(fr2[rb * 4 + q], u.im, dt, 0, 0, 0);
+                        }
+                    }
+                }
+                if (trn_en) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) pd[r] = dt[r];
+                    pyi = (t0 + ln < t_end) ? ixm[t0 + ln - c0] : -1;
+                    pending = true;
+                }
+            }
+            if (pending) emit();
+        }
+        for (int c0 = 0; !PIPE && !MFA && c0 < ncols; c0 += XCH) {
+            stage_columns(c0);
             const int s_end = min(nstrips, (c0 + XCH) / E);
             for (int s0 = c0 / E; s0 < s_end; s0 += G * L) {
                 // (issuing the next iteration's matrix loads before this iteration's arithmetic -- two register
@@ -1149,6 +1427,56 @@ __device__ __forceinline__ void run_panel_multi(const WaveD &wd, const uint4 *__
             }
         }
     }
+    if constexpr (MF32) {
+        if (FWD) {
+            // accumulators (column ln = component, rows 4 lk + r of a row block) -> lane = row, K complex sums
+            float *sl = reinterpret_cast<float *>(xs);
+#pragma unroll
+            for (int rb = 0; rb < MR; ++rb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = rb * 16 + 4 * lk + r;
+                    sl[row * 16 + (ln ^ (row & 15))] = facc32[rb][r];
+                }
+            const int sw = lane & 15;
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                T a = zero_of(T{});
+                if (lane < 16 * MR) {
+                    a.re = sl[lane * 16 + ((2 * k) ^ sw)];
+                    a.im = sl[lane * 16 + ((2 * k + 1) ^ sw)];
+                }
+                out[k] = a;
+            }
+        }
+        return;
+    }
+    if constexpr (MF) {
+        if (FWD) {
+            // accumulators (column ln, rows lk + 4 r of a row block) -> lane = row, K complex sums: through the dead x
+            // slice, 64 rows x 16 doubles, component n of row i at i * 16 + (n ^ ((i >> 1) & 15)) (both ways 2 lanes
+            // per bank pair at most)
+            double *sl = reinterpret_cast<double *>(xs);
+#pragma unroll
+            for (int rb = 0; rb < MR; ++rb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = rb * 16 + lk + 4 * r;
+                    sl[row * 16 + (ln ^ ((row >> 1) & 15))] = facc[rb][r];
+                }
+            const int sw = (lane >> 1) & 15;
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                T a = zero_of(T{});
+                if (lane < 16 * MR) {
+                    a.re = sl[lane * 16 + ((2 * k) ^ sw)];
+                    a.im = sl[lane * 16 + ((2 * k + 1) ^ sw)];
+                }
+                out[k] = a;
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         T a = acc[k];
@@ -1164,7 +1492,7 @@ __device__ __forceinline__ void run_panel_multi(const WaveD &wd, const uint4 *__
 // LDS admits 3; fused: 189 VGPRs = 2 per CU without the bound, 168 + 16 spilled dwords with it: C3 in fp32 x 8
 // 176 -> 159 us), 2 otherwise (the fp64 ones fit 3 by themselves)
 template <typename T, int L, bool FWD, bool TRN, int K>
-__global__ void __launch_bounds__(64 * kWavesPerWg, (kTilePipe<T, L, TRN, K> && sizeof(T) == 4 ? 3 : 2))
+__global__ void __launch_bounds__(64 * kWavesPerWg, ((kTilePipe<T, L, TRN, K> && sizeof(T) == 4) || kMfmaAny<T, K> ? 3 : 2))
     panel_kernel_multi(const WaveWork *__restrict__ waves, const uint4 *__restrict__ values,
                        const int *__restrict__ rows, const int *__restrict__ cols,
                        const T *__restrict__ x, long long ldx, T *__restrict__ y, long long ldy, T alpha,
@@ -1544,7 +1872,13 @@ static hipError_t launch_multi_typed(const DeviceImage &img, bool opT, bool conj
                                         strong_zero, stream, zrange);
         k += 8;
     }
-    if (e == hipSuccess && nrhs - k >= 5) {
+    // (ComplexF64: the 8-column pass runs on the matrix pipe -- a padded pass beats the 4-column register kernel
+    // from 3 columns on: BSM_MFMA_MIN_COLS)
+    static const int mf_min = [] {
+        const char *v = std::getenv("BSM_MFMA_MIN_COLS");
+        return v ? std::atoi(v) : 3;  // (BEM fixture x 4: 362 us padded against 486 us through the 4-column kernel)
+    }();
+    if (e == hipSuccess && nrhs - k >= (kMfmaAny<T, 8> ? mf_min : 5)) {
         const int rem = (int)(nrhs - k);
         e = launch_typed_multi<T, 4, 8>(img, opT, conj, xd + k * ldx, ldx, yd + k * ldy, ldy, alpha, beta,
                                         strong_zero, stream, zrange, rem);

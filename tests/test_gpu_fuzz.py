@@ -61,9 +61,11 @@ def test_random_operators_match_the_oracle(env, kind, dtype):
                 X = np.asfortranarray(np.stack([rand_vec(rng, xl, dtype) for _ in range(k)], axis=1))
                 Y0 = np.asfortranarray(np.stack([rand_vec(rng, yl, dtype) for _ in range(k)], axis=1))
                 Yd = torch.from_numpy(Y0.T.copy()).cuda().T  # column-major device matrix
-                bsm.mul(Yd, Aop, torch.from_numpy(X.T.copy()).cuda().T, -0.5, 1.25)
+                # (complex scalars for the complex types: the ComplexF64 8-column pass folds alpha into its x rows)
+                am, bm = (-0.5 + 0.75j, 1.25 - 0.5j) if dtype.kind == "c" else (-0.5, 1.25)
+                bsm.mul(Yd, Aop, torch.from_numpy(X.T.copy()).cuda().T, am, bm)
                 got = Yd.cpu().numpy()
                 for j in range(k):
-                    ref = oracle_mul(oracle, p, op, X[:, j].copy(), Y0[:, j].copy(), -0.5, 1.25, False)
+                    ref = oracle_mul(oracle, p, op, X[:, j].copy(), Y0[:, j].copy(), am, bm, False)
                     scale = max(np.max(np.abs(ref)), 1e-30)
                     assert np.max(np.abs(got[:, j] - ref)) / scale < TOL[dtype], (kind, dtype, case, acc, op, "multi", j)
