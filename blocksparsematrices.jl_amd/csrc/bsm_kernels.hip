@@ -836,7 +836,8 @@ __device__ __forceinline__ void run_panel_multi(const WaveD &wd, const uint4 *__
                                                 const int *__restrict__ rows,
                                                 const int *__restrict__ cols, const T *__restrict__ x,
                                                 long long ldx, T *__restrict__ y, long long ldy, T alpha,
-                                                int flags, int lane, T *xs, Vec16<T> *tile, int *ixm, T (&out)[K]) {
+                                                int flags, int lane, T *xs, Vec16<T> *tile, int *ixm, T (&out)[K],
+                                                bool &fwd_done) {
     constexpr int E = TT<T>::E;
     constexpr int G = 64 / P;
     constexpr int NC = G * L * E;
@@ -883,7 +884,7 @@ __device__ __forceinline__ void run_panel_multi(const WaveD &wd, const uint4 *__
             for (int q = 0; q < 4 * MR; ++q) {
                 const int r = 4 * q + lk;
                 double re = 0.0, im = 0.0;
-                if (r < m) {
+                if (r < m && !BSM_DBG(DBG_NO_XGATHER)) {
                     const int ri = (wd.rbase >= 0) ? wd.rbase + r : rows[wd.row_off + r];
                     const double *px = reinterpret_cast<const double *>(&x[ri + kc(ln >> 1) * ldx]);
                     re = px[0];
@@ -907,7 +908,7 @@ __device__ __forceinline__ void run_panel_multi(const WaveD &wd, const uint4 *__
             for (int q = 0; q < 4 * MR; ++q) {
                 const int r = 4 * q + lk;
                 float re = 0.f, im = 0.f;
-                if (r < m) {
+                if (r < m && !BSM_DBG(DBG_NO_XGATHER)) {
                     const int ri = (wd.rbase >= 0) ? wd.rbase + r : rows[wd.row_off + r];
                     const c64 xv = x[ri + kc(comp >> 1) * ldx];
                     re = alpha.re * xv.re - alpha.im * xv.im;  // (alpha goes in here)
@@ -1136,13 +1137,21 @@ __device__ __forceinline__ void run_panel_multi(const WaveD &wd, const uint4 *__
             }
         }
         // the x slice (forward half) and the y indices (transposed half) of the chunk of columns at c0
+        // (matrix-pipe path in accumulate mode: alpha goes into the slice, the forward sums leave from the accumulators)
+        const bool fold = MFA && !(flags & (FLAG_DIRECT | FLAG_RMW));
         auto stage_columns = [&](int c0) {
             if (fwd_en || (BSM_MULTI_IX && trn_en)) {
 #pragma unroll
                 for (int q = 0; q < XCH / 64; ++q) {
                     const int c = q * 64 + lane;
                     const int w = c0 + c;
-                    if (MFA || w < ncols + NC) {  // (the matrix-pipe tiles read whole 16-column tiles of the slice)
+                    if (BSM_DBG(DBG_NO_XGATHER)) {  // (timing probe: no column list, no x loads)
+                        if (BSM_MULTI_IX && TRN) ixm[c] = w < ncols ? w : -1;
+                        if (fwd_en) {
+#pragma unroll
+                            for (int k = 0; k < K; ++k) xs[c * K + k] = zero_of(T{});
+                        }
+                    } else if (MFA || w < ncols + NC) {  // (the matrix-pipe tiles read whole 16-column tiles of the slice)
                         bool ok = w < ncols, off = false;
                         const int xi = ok ? col_lookup(w, off) : 0;
                         // the chunk's y indices stay in LDS for the emission of its iterations (-1: the column takes no
@@ -1152,7 +1161,8 @@ __device__ __forceinline__ void run_panel_multi(const WaveD &wd, const uint4 *__
                         ok = ok && (!opT || off);
                         if (fwd_en) {
 #pragma unroll
-                            for (int k = 0; k < K; ++k) xs[c * K + k] = ok ? x[xi + kc(k) * ldx] : zero_of(T{});
+                            for (int k = 0; k < K; ++k)
+                                xs[c * K + k] = ok ? (fold ? mul(alpha, x[xi + kc(k) * ldx]) : x[xi + kc(k) * ldx]) : zero_of(T{});
                         }
                     }
                 }
@@ -1228,8 +1238,8 @@ __device__ __forceinline__ void run_panel_multi(const WaveD &wd, const uint4 *__
                             const double x1 = xsd[wl * 16 + ln];
                             double x2 = dppx<DPP_QUAD_XOR1>(x1);  // the other component of the same k: the neighbouring lane
                             x2 = (((ln & 1) == 0) != cjf) ? -x2 : x2;
-                            facc[rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(b[j].re, x1, facc[rb], 0, 0, 0);
-                            facc[rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(b[j].im, x2, facc[rb], 0, 0, 0);
+                            facc[rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, b[j].re, facc[rb], 0, 0, 0);
+                            facc[rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(x2, b[j].im, facc[rb], 0, 0, 0);
                         }
                     }
                     if (trn_en && !BSM_DBG(DBG_NO_TRN_HALF)) {
@@ -1261,6 +1271,7 @@ __device__ __forceinline__ void run_panel_multi(const WaveD &wd, const uint4 *__
             // lane (lane = row ln, strip 4 j + lk), issued one step ahead; everything else as in the ComplexF64 loop
             const float *xsf = reinterpret_cast<const float *>(xs);
             c64 *tile8 = reinterpret_cast<c64 *>(tile);
+            const int comp = 4 * (ln & 3) + (ln >> 2);
             const int nrb = (m + 15) >> 4;
             auto fetch = [&](Vec16<T>(&b)[2], int t0, int rb) {
                 const int row = rb * 16 + ln;
@@ -1316,11 +1327,11 @@ __device__ __forceinline__ void run_panel_multi(const WaveD &wd, const uint4 *__
 #pragma unroll
                             for (int e = 0; e < 2; ++e) {
                                 const int wl = t0 - c0 + 2 * (4 * j + lk) + e;  // column of the staged slice
-                                const float x1 = xsf[wl * 16 + ln];
-                                float x2 = dppx<DPP_QUAD_XOR1>(x1);
-                                x2 = (((ln & 1) == 0) != cjf) ? -x2 : x2;
-                                facc32[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[j].v[e].re, x1, facc32[rb], 0, 0, 0);
-                                facc32[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[j].v[e].im, x2, facc32[rb], 0, 0, 0);
+                                const float x1 = xsf[wl * 16 + comp];      // (components in the transposed order, as the x rows)
+                                float x2 = xsf[wl * 16 + (comp ^ 1)];
+                                x2 = (((comp & 1) == 0) != cjf) ? -x2 : x2;
+                                facc32[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(x1, b[j].v[e].re, facc32[rb], 0, 0, 0);
+                                facc32[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(x2, b[j].v[e].im, facc32[rb], 0, 0, 0);
                             }
                     }
                     if (trn_en && !BSM_DBG(DBG_NO_TRN_HALF)) {
@@ -1427,44 +1438,52 @@ __device__ __forceinline__ void run_panel_multi(const WaveD &wd, const uint4 *__
             }
         }
     }
-    if constexpr (MF32) {
-        if (FWD) {
-            // accumulators (column ln = component, rows 4 lk + r of a row block) -> lane = row, K complex sums
-            float *sl = reinterpret_cast<float *>(xs);
+    if constexpr (MFA) {
+        // The forward sums sit in the accumulators TRANSPOSED as well (A = the x slice, B = the tile): lane = (row ln of
+        // the row block, lk), register r = component  lk + 4 r (ComplexF64) / 4 r + lk (ComplexF32: the slice enters
+        // in transposed component order), i.e. Re and Im of two k for 16 consecutive rows per wave-instruction.
+        using R = typename std::conditional<MF, double, float>::type;
+        auto comp_of = [&](int r) { return MF ? lk + 4 * r : 4 * r + lk; };
+        if (FWD && !(flags & (FLAG_DIRECT | FLAG_RMW))) {
+            // atomic mode: every wave adds its own partial sums (alpha is in the slice already) -- contiguous runs
+            // again instead of Re and Im of one k per instruction, no slab, no combine (a group's waves add separately;
+            // coloured launches keep the combine: their plain read-modify-write is race-free between groups only)
+            if (wd.npieces > 0 && (!(flags & FLAG_OPT) || (wd.first.kind & kKindHasOff)) && !BSM_DBG(DBG_NO_FWD_OUT)) {
 #pragma unroll
-            for (int rb = 0; rb < MR; ++rb)
+                for (int rb = 0; rb < MR; ++rb) {
+                    const int row = rb * 16 + ln;
+                    if (rb * 16 >= m) break;
+                    int yi = -1;
+                    if (row < m) yi = (wd.rbase >= 0) ? wd.rbase + row : rows[wd.row_off + row];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = rb * 16 + 4 * lk + r;
-                    sl[row * 16 + (ln ^ (row & 15))] = facc32[rb][r];
+                    for (int r = 0; r < 4; ++r) {
+                        const int cq = comp_of(r);
+                        R val;
+                        if constexpr (MF) val = facc[rb][r]; else val = facc32[rb][r];
+                        if (yi >= 0 && (cq >> 1) < kact)
+                            atomicAdd(reinterpret_cast<R *>(&y[yi + (cq >> 1) * ldy]) + (cq & 1), val);
+                    }
                 }
-            const int sw = lane & 15;
-#pragma unroll
-            for (int k = 0; k < K; ++k) {
-                T a = zero_of(T{});
-                if (lane < 16 * MR) {
-                    a.re = sl[lane * 16 + ((2 * k) ^ sw)];
-                    a.im = sl[lane * 16 + ((2 * k + 1) ^ sw)];
-                }
-                out[k] = a;
             }
+            fwd_done = true;
+            return;
         }
-        return;
-    }
-    if constexpr (MF) {
         if (FWD) {
-            // accumulators (column ln, rows lk + 4 r of a row block) -> lane = row, K complex sums: through the dead x
-            // slice, 64 rows x 16 doubles, component n of row i at i * 16 + (n ^ ((i >> 1) & 15)) (both ways 2 lanes
-            // per bank pair at most)
-            double *sl = reinterpret_cast<double *>(xs);
+            // exclusive launches (plain stores, beta fused, groups combined in LDS by the caller): lane = row, K complex
+            // sums -- through the dead x slice, 64 rows x 16 components, component n of row i at i * 16 + (n ^ s(i))
+            R *sl = reinterpret_cast<R *>(xs);
+            auto swz = [&](int row) { return MF ? ((row >> 1) & 15) : (row & 15); };
 #pragma unroll
-            for (int rb = 0; rb < MR; ++rb)
+            for (int rb = 0; rb < MR; ++rb) {
+                const int row = rb * 16 + ln;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int row = rb * 16 + lk + 4 * r;
-                    sl[row * 16 + (ln ^ ((row >> 1) & 15))] = facc[rb][r];
+                    R val;
+                    if constexpr (MF) val = facc[rb][r]; else val = facc32[rb][r];
+                    sl[row * 16 + (comp_of(r) ^ swz(row))] = val;
                 }
-            const int sw = (lane >> 1) & 15;
+            }
+            const int sw = swz(lane);
 #pragma unroll
             for (int k = 0; k < K; ++k) {
                 T a = zero_of(T{});
@@ -1515,15 +1534,16 @@ __global__ void __launch_bounds__(64 * kWavesPerWg, ((kTilePipe<T, L, TRN, K> &&
     T u[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) u[k] = zero_of(T{});
+    bool fwd_done = false;  // the wave has added its forward sums to y itself (matrix-pipe path, accumulate mode)
     if (work == WORK_PANEL) {
         if (m <= 8)
-            run_panel_multi<T, L, 8, FWD, TRN, K>(wd, values, rows, cols, x, ldx, y, ldy, alpha, flags, lane, xs[wave], tl[wave], ixm[wave], u);
+            run_panel_multi<T, L, 8, FWD, TRN, K>(wd, values, rows, cols, x, ldx, y, ldy, alpha, flags, lane, xs[wave], tl[wave], ixm[wave], u, fwd_done);
         else if (m <= 16)
-            run_panel_multi<T, L, 16, FWD, TRN, K>(wd, values, rows, cols, x, ldx, y, ldy, alpha, flags, lane, xs[wave], tl[wave], ixm[wave], u);
+            run_panel_multi<T, L, 16, FWD, TRN, K>(wd, values, rows, cols, x, ldx, y, ldy, alpha, flags, lane, xs[wave], tl[wave], ixm[wave], u, fwd_done);
         else if (m <= 32)
-            run_panel_multi<T, L, 32, FWD, TRN, K>(wd, values, rows, cols, x, ldx, y, ldy, alpha, flags, lane, xs[wave], tl[wave], ixm[wave], u);
+            run_panel_multi<T, L, 32, FWD, TRN, K>(wd, values, rows, cols, x, ldx, y, ldy, alpha, flags, lane, xs[wave], tl[wave], ixm[wave], u, fwd_done);
         else
-            run_panel_multi<T, L, 64, FWD, TRN, K>(wd, values, rows, cols, x, ldx, y, ldy, alpha, flags, lane, xs[wave], tl[wave], ixm[wave], u);
+            run_panel_multi<T, L, 64, FWD, TRN, K>(wd, values, rows, cols, x, ldx, y, ldy, alpha, flags, lane, xs[wave], tl[wave], ixm[wave], u, fwd_done);
     }
     const bool direct = (flags & FLAG_DIRECT) != 0;
     const bool sz = (flags & FLAG_STRONG_ZERO) != 0;
@@ -1536,7 +1556,7 @@ __global__ void __launch_bounds__(64 * kWavesPerWg, ((kTilePipe<T, L, TRN, K> &&
             for (int k = 0; k < K; ++k) xs[wave][lane * K + k] = u[k];
             __syncthreads();
         }
-        if (work == WORK_PANEL && wd.lead) {
+        if (work == WORK_PANEL && wd.lead && !fwd_done && !BSM_DBG(DBG_NO_FWD_OUT)) {
             for (int w2 = 1; w2 < wd.grp; ++w2)
 #pragma unroll
                 for (int k = 0; k < K; ++k) u[k] = add(u[k], xs[wave + w2][lane * K + k]);

@@ -35,7 +35,9 @@ for k in range(K):
     X[:, k] = x * (k + 1)
 Y = torch.zeros((K, n), dtype=x.dtype, device="cuda").t()
 VAR = [("full", 0), ("no matrix loads", 64), ("no atomics", 1), ("no forward half", 128), ("no transposed half", 256),
-       ("no loads, no atomics", 65), ("loads + atomics only", 128 + 256), ("loads only", 128 + 256 + 1), ("nothing", 64 + 1 + 128 + 256)]
+       ("no loads, no atomics", 65), ("loads + atomics only", 128 + 256), ("loads only", 128 + 256 + 1), ("nothing", 64 + 1 + 128 + 256),
+       ("nothing, no x gather", 64 + 1 + 128 + 256 + 16), ("nothing, no forward output", 64 + 1 + 128 + 256 + 32),
+       ("nothing, no x gather, no forward output", 64 + 1 + 128 + 256 + 16 + 32), ("no x gather", 16), ("no forward output", 32)]
 for r in range(2):
     for nm, bits in VAR:
         os.environ["BSM_DEBUG_FLAGS"] = str(bits)
