@@ -879,7 +879,7 @@ def run_c2(args, bsm, torch, dist, np, rank, world, barrier, reduce_scalars):
         for tname, dtn, part, tol in BEM_TYPES:
             try:
                 bp, fx, n0 = bem_tiled_problem(torch, np, 400, dtn, part)
-                one, yb = leg(bsm, torch, bp, 50, multi_rhs=8 if tname in ("c128", "f64") else 0)
+                one, yb = leg(bsm, torch, bp, 50, multi_rhs=8 if tname in ("c128", "f64", "c64") else 0)
                 one["dtype"] = tname
                 # parity of the leg: tile 0 of y against the fixture's own product through an independent COO sum
                 ref = fixture_coo(np, fx, n0) @ bp["x"][:n0].cpu().numpy().astype(np.complex128 if np.dtype(dtn).kind == "c" else np.float64)

@@ -730,7 +730,7 @@ extern "C" int bsm_debug_set_trace(void *buf) {
 // full sweeps of A).  Same work distribution and layout as panel_kernel; every lane keeps K
 // accumulators, the staged x slice is [column][k] in LDS.
 // ========================================================================================
-template <typename T, int K> constexpr int x_chunk_cols_multi() {
+template <typename T, int K> constexpr int x_chunk_cols_multi_vec() {
     return (x_chunk_cols<T>() / K) > 64 * TT<T>::E ? (x_chunk_cols<T>() / K) : 64 * TT<T>::E;
 }
 // the tile-pipelined kernels (below) stage shorter slices: their LDS goes to the two matrix tiles.  A chunk
@@ -830,6 +830,11 @@ template <typename T, int K> constexpr bool kMfmaPath = BSM_MFMA_C128 && std::is
 typedef float v4f32 __attribute__((ext_vector_type(4)));
 template <typename T, int K> constexpr bool kMfmaPath32 = BSM_MFMA_C64 && std::is_same<T, c64>::value && K == 8;
 template <typename T, int K> constexpr bool kMfmaAny = kMfmaPath<T, K> || kMfmaPath32<T, K>;
+// columns per staged chunk: the matrix-pipe kernels take 64 (whole 16-column tiles; 64 x K elements is also the combine
+// slab of coloured / exclusive launches) -- ComplexF32: 4 KB per wave instead of 8, a fourth workgroup per CU
+template <typename T, int K> constexpr int x_chunk_cols_multi() {
+    return kMfmaAny<T, K> ? 64 : x_chunk_cols_multi_vec<T, K>();
+}
 
 template <typename T, int L, int P, bool FWD, bool TRN, int K>
 __device__ __forceinline__ void run_panel_multi(const WaveD &wd, const uint4 *__restrict__ values,
@@ -1511,7 +1516,7 @@ __device__ __forceinline__ void run_panel_multi(const WaveD &wd, const uint4 *__
 // LDS admits 3; fused: 189 VGPRs = 2 per CU without the bound, 168 + 16 spilled dwords with it: C3 in fp32 x 8
 // 176 -> 159 us), 2 otherwise (the fp64 ones fit 3 by themselves)
 template <typename T, int L, bool FWD, bool TRN, int K>
-__global__ void __launch_bounds__(64 * kWavesPerWg, ((kTilePipe<T, L, TRN, K> && sizeof(T) == 4) || kMfmaAny<T, K> ? 3 : 2))
+__global__ void __launch_bounds__(64 * kWavesPerWg, (kMfmaPath32<T, K> ? 4 : ((kTilePipe<T, L, TRN, K> && sizeof(T) == 4) || kMfmaAny<T, K> ? 3 : 2)))
     panel_kernel_multi(const WaveWork *__restrict__ waves, const uint4 *__restrict__ values,
                        const int *__restrict__ rows, const int *__restrict__ cols,
                        const T *__restrict__ x, long long ldx, T *__restrict__ y, long long ldy, T alpha,
@@ -1520,7 +1525,8 @@ __global__ void __launch_bounds__(64 * kWavesPerWg, ((kTilePipe<T, L, TRN, K> &&
     constexpr int XCH = PIPE ? x_chunk_cols_pipe<T, L>() : x_chunk_cols_multi<T, K>();
     constexpr int XS = XCH * K;  // >= 64*K: also holds the combine slab
     // 16-byte units: max over P of (64 / P) * L strips of P + 1 units; the pipelined kernels hold two tiles
-    constexpr int TILE = PIPE ? 2 * L * 64 : L * 72;
+    // (matrix-pipe kernels: one 16 x 16 tile of elements, column stride 17)
+    constexpr int TILE = PIPE ? 2 * L * 64 : (kMfmaAny<T, K> ? (16 * 17 * (int)sizeof(T) + 15) / 16 : L * 72);
     __shared__ __attribute__((aligned(16))) T xs[kWavesPerWg][FWD ? XS : 1];
     __shared__ Vec16<T> tl[kWavesPerWg][TRN ? TILE : 1];
     __shared__ int ixm[kWavesPerWg][(TRN && !PIPE && BSM_MULTI_IX) ? XCH : 1];  // y indices of the staged chunk (register path)
