@@ -817,6 +817,9 @@ typedef double v4f64 __attribute__((ext_vector_type(4)));
 #ifndef BSM_MFMA_C128
 #define BSM_MFMA_C128 1
 #endif
+#ifndef BSM_MFMA_C128_WGS  // resident workgroups per CU the ComplexF64 instance is compiled for (3: 168 VGPRs)
+#define BSM_MFMA_C128_WGS 3
+#endif
 template <typename T, int K> constexpr bool kMfmaPath = BSM_MFMA_C128 && std::is_same<T, c128>::value && K == 8;
 // ComplexF32 likewise on v_mfma_f32_16x16x4_f32 (C / D: column ln, rows 4 lk + r -- the f32 map, not the f64 one).  A
 // 16-byte load holds TWO columns of a row (strip = 2 columns): one load feeds 4 MFMAs (2 columns x Re / Im), the k
@@ -1516,7 +1519,7 @@ __device__ __forceinline__ void run_panel_multi(const WaveD &wd, const uint4 *__
 // LDS admits 3; fused: 189 VGPRs = 2 per CU without the bound, 168 + 16 spilled dwords with it: C3 in fp32 x 8
 // 176 -> 159 us), 2 otherwise (the fp64 ones fit 3 by themselves)
 template <typename T, int L, bool FWD, bool TRN, int K>
-__global__ void __launch_bounds__(64 * kWavesPerWg, (kMfmaPath32<T, K> ? 4 : ((kTilePipe<T, L, TRN, K> && sizeof(T) == 4) || kMfmaAny<T, K> ? 3 : 2)))
+__global__ void __launch_bounds__(64 * kWavesPerWg, (kMfmaPath32<T, K> ? 4 : ((kTilePipe<T, L, TRN, K> && sizeof(T) == 4) || (kMfmaAny<T, K> && BSM_MFMA_C128_WGS == 3) ? 3 : 2)))
     panel_kernel_multi(const WaveWork *__restrict__ waves, const uint4 *__restrict__ values,
                        const int *__restrict__ rows, const int *__restrict__ cols,
                        const T *__restrict__ x, long long ldx, T *__restrict__ y, long long ldy, T alpha,

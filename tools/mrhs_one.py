@@ -9,7 +9,22 @@ import numpy as np, torch, bsm_amd as bsm
 S = bsm.synthetic
 name, K = sys.argv[1], int(sys.argv[2])
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 10
-prob = {"c2": lambda: S.config2(on_device=True), "c3": lambda: S.config3(on_device=True),
+def bem(tiles, dtype, part):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from _common import fixture_problem
+    p = fixture_problem("cuboid", dtype, part)
+    n0 = p["size"][0]
+    tile = lambda lists: [l + k * n0 for k in range(tiles) for l in lists]
+    prob = dict(kind="symmetric", diagonals=p["diagonals"] * tiles, diagonalindices=tile(p["diagonalindices"]),
+                offdiagonals=p["offdiagonals"] * tiles, rowindices=tile(p["rowindices"]), colindices=tile(p["colindices"]),
+                size=(n0 * tiles, n0 * tiles))
+    xh = np.random.default_rng(0).standard_normal(n0 * tiles) + 1j * np.random.default_rng(1).standard_normal(n0 * tiles)
+    prob["x"] = torch.from_numpy(xh.astype(dtype)).cuda()
+    return prob
+
+
+prob = {"bem_c128": lambda: bem(400, np.complex128, "full"), "bem_c64": lambda: bem(400, np.complex64, "full"),
+        "c2": lambda: S.config2(on_device=True), "c3": lambda: S.config3(on_device=True),
         "c2x20": lambda: S.config2(n=2_000_000, nblocks=100_000, on_device=True),
         "c4s": lambda: S.config4(on_device=True, row_lo=0, row_hi=1953),
         "c5s": lambda: S.config5(n=625_000, on_device=True)}[name]()

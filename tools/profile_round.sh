@@ -22,6 +22,12 @@ rocprofv3 --output-format csv --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum TCC_
 # 3. MFMA counters on the C4 slice (128x128 fp32 blocks): expected 0
 say "MFMA counters, C4 slice"
 rocprofv3 --output-format csv --kernel-trace --pmc SQ_INSTS_VALU_MFMA_F32 SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_FMA_F32 -d $O/pmc_mfma -o p -- python3 $R/tools/kbench.py c4s 20 > /dev/null 2> $O/pmc_mfma.err
+# 3b. ... and on the products that DO run on the matrix pipe: 8 complex right-hand sides on the BEM fixture
+for cfg in bem_c128 bem_c64; do
+  say "MFMA counters, $cfg x 8"
+  rocprofv3 --output-format csv --kernel-trace --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU -d $O/mfma_${cfg} -o p -- python3 $R/tools/mrhs_one.py $cfg 8 10 > /dev/null 2> $O/mfma_${cfg}.err
+  rocprofv3 --output-format csv --kernel-trace --pmc TCC_EA0_ATOMIC_sum WRITE_SIZE FETCH_SIZE -d $O/mfma_${cfg}_mem -o p -- python3 $R/tools/mrhs_one.py $cfg 8 10 > /dev/null 2>> $O/mfma_${cfg}.err
+done
 # 4. the HBM-streaming legs: traffic, atomics, L2 hit rate, wave-state counters
 export ABB_REPS=8
 for cfg in c2x20 c3 c4s c5s bem_c128 bem_f64 bem_c64 bem_f32; do
@@ -48,6 +54,7 @@ python3 tools/pmc_summary.py mfma $O/r04_c4_mfma.json "panel_kernel<float" $O/pm
 { echo "C2 product (bench.py --pmc-child: 60 eager launches), rocprofv3 --pmc, per-dispatch means:"; python3 tools/pmc_table.py "panel_kernel<double, 8, true, false" $O/pmc_sq $O/pmc_tcc; } > $O/r04_c2_sq_tcc_counters.txt
 { for cfg in c2x20 c3 c4s c5s bem_c128 bem_f64 bem_c64 bem_f32; do echo "== $cfg (tools/abbench.py $cfg)"; python3 tools/pmc_table.py panel_kernel $O/leg_${cfg}_fetch $O/leg_${cfg}_write $O/leg_${cfg}_tcc $O/leg_${cfg}_sq; done
   if [ -f "$BEFORE" ]; then for cfg in bem_c128 bem_f64 bem_c64 bem_f32; do echo "== $cfg BEFORE (the library the round started from)"; python3 tools/pmc_table.py panel_kernel $O/before_${cfg}_write $O/before_${cfg}_tcc; done; fi; } > $O/r04_legs_counters.txt
+{ for cfg in bem_c128 bem_c64; do echo "== $cfg x 8 (tools/mrhs_one.py $cfg 8 10): the 8-column fused kernel on the matrix pipe, per-dispatch means"; python3 tools/pmc_table.py panel_kernel_multi $O/mfma_${cfg} $O/mfma_${cfg}_mem; done; } > $O/r04_multirhs_mfma_counters.txt
 { echo "C2 transposed product on the single image (tools/kbench.py c2 100 T):"; python3 tools/pmc_table.py "panel_kernel" $O/c2T_tcc; python3 tools/pmc_table.py "scale_kernel" $O/c2T_tcc; } > $O/r04_c2_transposed_counters.txt
 find $O/kt -name "*kernel_stats.csv" -exec cp {} $O/r04_c2_bench_default_kernel_stats.csv \;
 python3 tools/kt_summary.py $O/kt $O/r04_c2_bench_default_kernel_trace_by_grid.csv > /dev/null
@@ -76,10 +83,17 @@ python3 tools/abbench.py > $O/r04_abbench.txt 2> /dev/null
 python3 tools/kbench.py c2 500 T > $O/r04_c2_transposed.txt 2>&1 || true
 KB_TIMG=1 python3 tools/kbench.py c2 500 T >> $O/r04_c2_transposed.txt 2>&1 || true
 python3 tools/multirhs.py > $O/r04_multirhs.txt 2> /dev/null || true
+say "multi-device fan-out on virtual devices"
+{ for r in 1 2; do echo "-- default (parts on the caller's device share its stream: no ordering packets; work vectors kept zero by the finish kernels)"; python3 tools/distbench.py c3 2> /dev/null
+  echo "-- BSM_DIST_REZERO=0 (a w = 0 launch in front of every part's product, as in round 3)"; BSM_DIST_REZERO=0 python3 tools/distbench.py c3 2> /dev/null
+  echo "-- BSM_DIST_ONE_STREAM=0: every part on a stream of its own, ordered by flags (what parts on DISTINCT devices pay)"; BSM_DIST_ONE_STREAM=0 python3 tools/distbench.py c3 2> /dev/null
+  echo "-- BSM_DIST_ONE_STREAM=0 BSM_DIST_FLAGS=0: ... ordered by events"; BSM_DIST_ONE_STREAM=0 BSM_DIST_FLAGS=0 python3 tools/distbench.py c3 2> /dev/null; done; } > $O/r04_distbench.txt
+say "ablation of the matrix-pipe multi-RHS kernels"
+{ python3 tools/ablate_multi.py bem_c128 8 2> /dev/null | tail -14; python3 tools/ablate_multi.py bem_c64 8 2> /dev/null | tail -14; } > $O/r04_multirhs_mfma_ablation.txt
 say "ablations of the fused kernel on the tiled BEM fixture (experiment build)"
 { for t in c128 f64 c64 f32; do python3 tools/ablate.py 400 $t 3 2> /dev/null; done
   echo; echo "(tools/ablate.py on the experiment build, make -C blocksparsematrices.jl_amd/csrc exp: every variant drops one part of the fused kernel -- results are wrong by construction, only the times mean something; interleaved rounds in one process)"; } > $O/r04_bem_ablation.txt
 python3 tools/report.py $O/r04_report_all_configs.md > /dev/null 2>&1 || true
 find $O -name "*.csv" -size +2M -delete
-rm -rf $O/kt $O/pmc_* $O/leg_* $O/before_* $O/c2T_tcc
+rm -rf $O/kt $O/pmc_* $O/leg_* $O/before_* $O/c2T_tcc $O/mfma_bem_*
 ls -la $O
