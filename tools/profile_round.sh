@@ -23,10 +23,14 @@ rocprofv3 --output-format csv --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum TCC_
 say "MFMA counters, C4 slice"
 rocprofv3 --output-format csv --kernel-trace --pmc SQ_INSTS_VALU_MFMA_F32 SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_FMA_F32 -d $O/pmc_mfma -o p -- python3 $R/tools/kbench.py c4s 20 > /dev/null 2> $O/pmc_mfma.err
 # 3b. ... and on the products that DO run on the matrix pipe: 8 complex right-hand sides on the BEM fixture
+# (one memory counter per pass: FETCH_SIZE / WRITE_SIZE / the atomics do not fit one configuration)
 for cfg in bem_c128 bem_c64; do
   say "MFMA counters, $cfg x 8"
-  rocprofv3 --output-format csv --kernel-trace --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU -d $O/mfma_${cfg} -o p -- python3 $R/tools/mrhs_one.py $cfg 8 10 > /dev/null 2> $O/mfma_${cfg}.err
-  rocprofv3 --output-format csv --kernel-trace --pmc TCC_EA0_ATOMIC_sum WRITE_SIZE FETCH_SIZE -d $O/mfma_${cfg}_mem -o p -- python3 $R/tools/mrhs_one.py $cfg 8 10 > /dev/null 2>> $O/mfma_${cfg}.err
+  timeout -k 5 300 rocprofv3 --output-format csv --kernel-trace --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU -d $O/mfma_${cfg} -o p -- python3 $R/tools/mrhs_one.py $cfg 8 10 > /dev/null 2> $O/mfma_${cfg}.err
+  for c in TCC_EA0_ATOMIC_sum WRITE_SIZE FETCH_SIZE; do
+    say "  $cfg x 8 $c"
+    timeout -k 5 300 rocprofv3 --output-format csv --kernel-trace --pmc $c -d $O/mfma_${cfg}_$c -o p -- python3 $R/tools/mrhs_one.py $cfg 8 10 > /dev/null 2>> $O/mfma_${cfg}.err
+  done
 done
 # 4. the HBM-streaming legs: traffic, atomics, L2 hit rate, wave-state counters
 export ABB_REPS=8
@@ -54,7 +58,7 @@ python3 tools/pmc_summary.py mfma $O/r04_c4_mfma.json "panel_kernel<float" $O/pm
 { echo "C2 product (bench.py --pmc-child: 60 eager launches), rocprofv3 --pmc, per-dispatch means:"; python3 tools/pmc_table.py "panel_kernel<double, 8, true, false" $O/pmc_sq $O/pmc_tcc; } > $O/r04_c2_sq_tcc_counters.txt
 { for cfg in c2x20 c3 c4s c5s bem_c128 bem_f64 bem_c64 bem_f32; do echo "== $cfg (tools/abbench.py $cfg)"; python3 tools/pmc_table.py panel_kernel $O/leg_${cfg}_fetch $O/leg_${cfg}_write $O/leg_${cfg}_tcc $O/leg_${cfg}_sq; done
   if [ -f "$BEFORE" ]; then for cfg in bem_c128 bem_f64 bem_c64 bem_f32; do echo "== $cfg BEFORE (the library the round started from)"; python3 tools/pmc_table.py panel_kernel $O/before_${cfg}_write $O/before_${cfg}_tcc; done; fi; } > $O/r04_legs_counters.txt
-{ for cfg in bem_c128 bem_c64; do echo "== $cfg x 8 (tools/mrhs_one.py $cfg 8 10): the 8-column fused kernel on the matrix pipe, per-dispatch means"; python3 tools/pmc_table.py panel_kernel_multi $O/mfma_${cfg} $O/mfma_${cfg}_mem; done; } > $O/r04_multirhs_mfma_counters.txt
+{ for cfg in bem_c128 bem_c64; do echo "== $cfg x 8 (tools/mrhs_one.py $cfg 8 10): the 8-column fused kernel on the matrix pipe, per-dispatch means"; python3 tools/pmc_table.py panel_kernel_multi $O/mfma_${cfg} $O/mfma_${cfg}_TCC_EA0_ATOMIC_sum $O/mfma_${cfg}_WRITE_SIZE $O/mfma_${cfg}_FETCH_SIZE; done; } > $O/r04_multirhs_mfma_counters.txt
 { echo "C2 transposed product on the single image (tools/kbench.py c2 100 T):"; python3 tools/pmc_table.py "panel_kernel" $O/c2T_tcc; python3 tools/pmc_table.py "scale_kernel" $O/c2T_tcc; } > $O/r04_c2_transposed_counters.txt
 find $O/kt -name "*kernel_stats.csv" -exec cp {} $O/r04_c2_bench_default_kernel_stats.csv \;
 python3 tools/kt_summary.py $O/kt $O/r04_c2_bench_default_kernel_trace_by_grid.csv > /dev/null
