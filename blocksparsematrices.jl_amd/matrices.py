@@ -112,19 +112,31 @@ def _lds(blocks):
 
 def _host(b):
     """numpy view of a block wherever it lives (accessors used by sparse() / rowcolvals())"""
-    return b.cpu().numpy() if (torch is not None and isinstance(b, torch.Tensor)) else np.asarray(b)
+    return b.cpu().numpy() if (torch is not None and isinstance(b, torch.Tensor)) else _dense(b)
+
+
+def _dense(b):
+    """A block as a numpy array.  The reference takes any AbstractMatrix as a block and counts it as prod(size)
+    (`_nnz`, src/abstractblockmatrix.jl:65-71) -- sparse blocks included; here such a block (anything with
+    `.toarray()`, e.g. a scipy.sparse matrix) is densified ONCE, at construction: the packed image holds dense
+    panels anyway."""
+    if hasattr(b, "toarray") and not isinstance(b, np.ndarray):
+        b = b.toarray()
+    return np.asarray(b)
 
 
 def _blocks_dtype(*blocklists):
     dt = None
     for bl in blocklists:
         for b in bl:
-            d = np.asarray(b).dtype
+            d = _dense(b).dtype if hasattr(b, "toarray") and not isinstance(b, np.ndarray) else np.asarray(b).dtype
             dt = d if dt is None else np.promote_types(dt, d)
     if dt is None:
         dt = np.dtype(np.float64)
     if dt not in _DT:
         dt = np.promote_types(dt, np.float32) if dt.kind in "iub" else dt
+    if np.dtype(dt) == np.float16:  # (Julia would promote Float16 blocks with Float32 scalars the same way)
+        dt = np.dtype(np.float32)
     if np.dtype(dt) not in _DT:
         raise TypeError(f"unsupported block element type {dt}")
     return np.dtype(dt)
@@ -133,7 +145,7 @@ def _blocks_dtype(*blocklists):
 def _fblocks(blocks, dt):
     out = []
     for b in blocks:
-        a = np.asarray(b)
+        a = _dense(b)
         if a.ndim != 2:
             raise ValueError("every block must be a 2-D array")
         out.append(np.asfortranarray(a, dtype=dt))

@@ -93,18 +93,26 @@ handle(A) = lock(() -> get!(() -> _create(A), _handles, _key(A)), _lock)
 
 _ld(b) = Int64(max(stride(b, 2), size(b, 1), 1))   # leading dimension; >= 1 also for 0-row blocks
 
+# A block the C ABI can take: element type T, column-major with unit row stride.  The reference admits any
+# AbstractMatrix as a block and counts it as prod(size) (_nnz, src/abstractblockmatrix.jl:65-71): sparse blocks,
+# adjoints, views with a row stride are densified ONCE here, at handle creation.
+_cblock(::Type{T}, b::StridedMatrix{T}) where {T} = stride(b, 1) == 1 ? b : Matrix{T}(b)
+_cblock(::Type{T}, b::AbstractMatrix) where {T} = Matrix{T}(b)
+_cblocks(::Type{T}, bs) where {T} = [_cblock(T, b) for b in bs]
+
 # replaces the analysis done by the constructor src/vbcrs.jl:78-122 + the loop :266-288
 function _create(A::VariableBlockCompressedRowStorage{T}) where {T}
     nb = length(A.blocks)
     m = Int64[size(b, 1) for b in A.blocks]; n = Int64[size(b, 2) for b in A.blocks]
     rowstart = Int64[A.rowindices[searchsortedlast(A.rowptr, i)] for i in 1:nb]
     colstart = Int64.(A.colindices)
-    ptrs = Ptr{Cvoid}[pointer(b) for b in A.blocks]
+    bl = _cblocks(T, A.blocks)
+    ptrs = Ptr{Cvoid}[pointer(b) for b in bl]
     out = Ref{Ptr{Cvoid}}(C_NULL)
-    GC.@preserve A _check(ccall((:bsm_vbcrs_create, libbsm), Cint,
+    GC.@preserve A bl _check(ccall((:bsm_vbcrs_create, libbsm), Cint,
         (Cint, Int64, Int64, Int64, Ptr{Ptr{Cvoid}}, Ptr{Int64}, Ptr{Int64}, Ptr{Int64},
          Ptr{Int64}, Ptr{Int64}, Ref{BsmOptions}, Ref{Ptr{Cvoid}}),
-        _DTYPE[T], size(A, 1), size(A, 2), nb, ptrs, m, n, _ld.(A.blocks), rowstart, colstart,
+        _DTYPE[T], size(A, 1), size(A, 2), nb, ptrs, m, n, _ld.(bl), rowstart, colstart,
         _options(A.scheduler), out))
     return Handle(out[])
 end
@@ -114,12 +122,13 @@ function _create(A::BlockSparseMatrix{T}) where {T}
     nb = length(A.blocks)
     m = Int64[size(b, 1) for b in A.blocks]; n = Int64[size(b, 2) for b in A.blocks]
     ri = [Vector{Int64}(r) for r in A.rowindices]; ci = [Vector{Int64}(c) for c in A.colindices]
+    bl = _cblocks(T, A.blocks)
     out = Ref{Ptr{Cvoid}}(C_NULL)
-    GC.@preserve A ri ci _check(ccall((:bsm_blocksparse_create, libbsm), Cint,
+    GC.@preserve A bl ri ci _check(ccall((:bsm_blocksparse_create, libbsm), Cint,
         (Cint, Int64, Int64, Int64, Ptr{Ptr{Cvoid}}, Ptr{Int64}, Ptr{Int64}, Ptr{Int64},
          Ptr{Ptr{Int64}}, Ptr{Ptr{Int64}}, Ref{BsmOptions}, Ref{Ptr{Cvoid}}),
-        _DTYPE[T], size(A, 1), size(A, 2), nb, Ptr{Cvoid}[pointer(b) for b in A.blocks], m, n,
-        _ld.(A.blocks), pointer.(ri), pointer.(ci), _options(A.scheduler), out))
+        _DTYPE[T], size(A, 1), size(A, 2), nb, Ptr{Cvoid}[pointer(b) for b in bl], m, n,
+        _ld.(bl), pointer.(ri), pointer.(ci), _options(A.scheduler), out))
     return Handle(out[])
 end
 
@@ -129,14 +138,15 @@ function _create(A::SymmetricBlockMatrix{T}) where {T}
     m = Int64[size(b, 1) for b in A.offdiagonals]; n = Int64[size(b, 2) for b in A.offdiagonals]
     di = [Vector{Int64}(d) for d in A.diagonalindices]
     ri = [Vector{Int64}(r) for r in A.rowindices]; ci = [Vector{Int64}(c) for c in A.colindices]
+    dg = _cblocks(T, A.diagonals); og = _cblocks(T, A.offdiagonals)
     out = Ref{Ptr{Cvoid}}(C_NULL)
-    GC.@preserve A di ri ci _check(ccall((:bsm_symmetric_create, libbsm), Cint,
+    GC.@preserve A dg og di ri ci _check(ccall((:bsm_symmetric_create, libbsm), Cint,
         (Cint, Int64, Int64, Int64, Ptr{Ptr{Cvoid}}, Ptr{Int64}, Ptr{Int64}, Ptr{Ptr{Int64}},
          Int64, Ptr{Ptr{Cvoid}}, Ptr{Int64}, Ptr{Int64}, Ptr{Int64}, Ptr{Ptr{Int64}},
          Ptr{Ptr{Int64}}, Ref{BsmOptions}, Ref{Ptr{Cvoid}}),
-        _DTYPE[T], size(A, 1), size(A, 2), length(ds), Ptr{Cvoid}[pointer(b) for b in A.diagonals],
-        ds, _ld.(A.diagonals), pointer.(di), length(m), Ptr{Cvoid}[pointer(b) for b in A.offdiagonals],
-        m, n, _ld.(A.offdiagonals), pointer.(ri), pointer.(ci), _options(A.scheduler), out))
+        _DTYPE[T], size(A, 1), size(A, 2), length(ds), Ptr{Cvoid}[pointer(b) for b in dg],
+        ds, _ld.(dg), pointer.(di), length(m), Ptr{Cvoid}[pointer(b) for b in og],
+        m, n, _ld.(og), pointer.(ri), pointer.(ci), _options(A.scheduler), out))
     return Handle(out[])
 end
 

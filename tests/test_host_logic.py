@@ -252,6 +252,35 @@ def test_image_config1_blocksparse(bsm, oracle):
     _check_image(bsm, oracle, p, A, np.float64)
 
 
+def test_blocks_of_any_matrix_type_and_indices_of_any_integer_type(bsm, oracle):
+    """The reference takes any AbstractMatrix as a block (counted as prod(size): src/abstractblockmatrix.jl:65-71)
+    and any P <: Integer as an index.  The mirror densifies a sparse block once at construction, takes row-major
+    arrays, views with strides, np.matrix, Float16 and integer blocks (promoted like Julia would with Float32 /
+    Float64 scalars) and Int32 / UInt16 indices -- the packed image and `sparse(A)` are those of the dense blocks."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(12)
+    dense = [rng.standard_normal((9, 7)), rng.standard_normal((5, 11)), rng.standard_normal((6, 6)), rng.standard_normal((4, 3))]
+    big = rng.standard_normal((20, 30))
+    dense[1] = big[2:7, 3:25:2].copy()
+    mixed = [sp.csr_matrix(dense[0]), big[2:7, 3:25:2], np.matrix(dense[2]), sp.csc_matrix(dense[3])]
+    rows = [np.arange(1, 10, dtype=np.int32), np.arange(20, 25, dtype=np.uint16), np.arange(30, 36), np.arange(40, 44, dtype=np.int32)]
+    cols = [np.arange(3, 10, dtype=np.int32), np.arange(12, 23, dtype=np.int64), np.arange(30, 36, dtype=np.uint16), np.arange(1, 4)]
+    ref = bsm.BlockSparseMatrix(dense, [r.astype(np.int64) for r in rows], [c.astype(np.int64) for c in cols], (50, 40), device=NODEV)
+    A = bsm.BlockSparseMatrix(mixed, rows, cols, (50, 40), device=NODEV)
+    assert A.dtype == np.float64 and bsm.nnz(A) == bsm.nnz(ref) == sum(d.size for d in dense)
+    assert abs(bsm.sparse(A) - bsm.sparse(ref)).max() == 0
+    p = dict(kind="blocksparse", blocks=[np.asfortranarray(d) for d in dense], rowindices=[r.astype(np.int64) for r in rows],
+             colindices=[c.astype(np.int64) for c in cols], size=(50, 40))
+    _check_image(bsm, oracle, p, A, np.float64)
+    # element types: Float16 -> Float32, Int32 -> Float64, a complex block promotes the whole matrix
+    h = bsm.BlockSparseMatrix([d.astype(np.float16) for d in dense], rows, cols, (50, 40), device=NODEV)
+    assert h.dtype == np.float32
+    i = bsm.VariableBlockCompressedRowStorage([np.arange(12, dtype=np.int32).reshape(3, 4)], [2], [5], (10, 10), device=NODEV)
+    assert i.dtype == np.float64 and bsm.sparse(i)[3, 6] == 10  # row-major input: 0-based entry (2, 2) of the block = 2 * 4 + 2
+    c = bsm.BlockSparseMatrix([dense[0], sp.csr_matrix(dense[1] * (1 + 2j))], rows[:2], cols[:2], (50, 40), device=NODEV)
+    assert c.dtype == np.complex128
+
+
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_image_config2_vbcrs_small(bsm, oracle, dtype):
     p = bsm.synthetic.config2(n=4000, nblocks=400, dtype=dtype)
