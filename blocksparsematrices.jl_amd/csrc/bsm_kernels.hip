@@ -741,7 +741,7 @@ template <> constexpr bool kRealType<double> = true;
 // which multi-RHS kernels run the tile pipeline: the transposed / fused 8- and 4-column ones in real arithmetic
 // with 4 loads per lane (the complex 8-column ones are at the register limit as they are: c64 fused 242 -> 256
 // VGPRs + scratch with it; the ComplexF64 4-column one gains nothing over its register path: 487 vs 490 us)
-template <typename T, int L, bool TRN, int K> constexpr bool kTilePipe = TRN && L == 4 && kRealType<T> && K >= 4;
+template <typename T, int L, bool TRN, int K> constexpr bool kTilePipe = TRN && L == 4 && kRealType<T> && K >= 4 && K <= 8;
 template <typename T, int L> constexpr int x_chunk_cols_pipe() {
     return 8 * L * TT<T>::E > 64 ? 8 * L * TT<T>::E : 64;
 }
@@ -832,7 +832,16 @@ template <typename T, int K> constexpr bool kMfmaPath = BSM_MFMA_C128 && std::is
 #endif
 typedef float v4f32 __attribute__((ext_vector_type(4)));
 template <typename T, int K> constexpr bool kMfmaPath32 = BSM_MFMA_C64 && std::is_same<T, c64>::value && K == 8;
-template <typename T, int K> constexpr bool kMfmaAny = kMfmaPath<T, K> || kMfmaPath32<T, K>;
+// Real arithmetic: N = 16 is 16 right-hand sides.  The K = 16 instances (bsm_mul_multi: batches of 16, remainders of 9-15
+// padded) run the same loop with ONE MFMA per operand (no X''): Float64 = two columns per 16-byte load and the f64
+// accumulator map, Float32 = four columns per load and the f32 map with the components in transposed order.
+#ifndef BSM_MFMA_REAL
+#define BSM_MFMA_REAL 1
+#endif
+template <typename T, int K> constexpr bool kMfmaReal = BSM_MFMA_REAL && kRealType<T> && K == 16;
+template <typename T, int K> constexpr bool kMfmaAny = kMfmaPath<T, K> || kMfmaPath32<T, K> || kMfmaReal<T, K>;
+__device__ __forceinline__ v4f64 mfma16(double a, double b, v4f64 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ v4f32 mfma16(float a, float b, v4f32 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 // columns per staged chunk: the matrix-pipe kernels take 64 (whole 16-column tiles; 64 x K elements is also the combine
 // slab of coloured / exclusive launches) -- ComplexF32: 4 KB per wave instead of 8, a fourth workgroup per CU
 template <typename T, int K> constexpr int x_chunk_cols_multi() {
@@ -851,7 +860,7 @@ __device__ __forceinline__ void run_panel_multi(const WaveD &wd, const uint4 *__
     constexpr int NC = G * L * E;
     constexpr bool PIPE = kTilePipe<T, L, TRN, K>;  // matrix tiles prefetched into LDS (below)
     constexpr int XCH = PIPE ? x_chunk_cols_pipe<T, L>() : x_chunk_cols_multi<T, K>();
-    static_assert(XCH % NC == 0, "x chunk must hold whole iterations");
+    static_assert(kMfmaAny<T, K> || XCH % NC == 0, "x chunk must hold whole iterations");
     const bool opT = (flags & FLAG_OPT) != 0;
     const bool cjf = (flags & FLAG_CONJ) != 0;
     const int kact = ((flags >> FLAG_KACT_SHIFT) & 15) ? ((flags >> FLAG_KACT_SHIFT) & 15) : K;
@@ -883,7 +892,9 @@ __device__ __forceinline__ void run_panel_multi(const WaveD &wd, const uint4 *__
     constexpr int MR = (P + 15) / 16;
     const int ln = lane & 15, lk = lane >> 4;
     double xr1[(MF && TRN) ? 4 * MR : 1];  // (X'' of a row is X' with neighbouring lanes swapped, and a sign)
-    v4f64 facc[MF ? MR : 1];
+    constexpr bool MFR = kMfmaReal<T, K>;
+    constexpr bool MFR64 = MFR && sizeof(T) == 8, MFR32 = MFR && sizeof(T) == 4;
+    v4f64 facc[(MF || MFR64) ? MR : 1];
     if constexpr (MF) {
 #pragma unroll
         for (int rb = 0; rb < MR; ++rb) facc[rb] = v4f64{0.0, 0.0, 0.0, 0.0};
@@ -904,9 +915,32 @@ __device__ __forceinline__ void run_panel_multi(const WaveD &wd, const uint4 *__
         }
     }
     constexpr bool MF32 = kMfmaPath32<T, K>;
-    constexpr bool MFA = MF || MF32;
+    constexpr bool MFA = MF || MF32 || MFR;
     float fr1[(MF32 && TRN) ? 4 * MR : 1], fr2[(MF32 && TRN) ? 4 * MR : 1];
-    v4f32 facc32[MF32 ? MR : 1];
+    v4f32 facc32[(MF32 || MFR32) ? MR : 1];
+    // real types, K = 16: the panel's x rows (alpha folded in) as A operands of the transposed half; the lane carries
+    // component (= right-hand side) compA: ln for the f64 accumulator map, the transposed order for the f32 one
+    const int compA = MFR32 ? 4 * (ln & 3) + (ln >> 2) : ln;
+    T rr[(MFR && TRN) ? 4 * MR : 1];
+    if constexpr (MFR) {
+#pragma unroll
+        for (int rb = 0; rb < MR; ++rb) {
+            if constexpr (MFR64) facc[rb] = v4f64{0.0, 0.0, 0.0, 0.0};
+            if constexpr (MFR32) facc32[rb] = v4f32{0.f, 0.f, 0.f, 0.f};
+        }
+        if (TRN) {
+#pragma unroll
+            for (int q = 0; q < 4 * MR; ++q) {
+                const int r = 4 * q + lk;
+                T v = zero_of(T{});
+                if (r < m && !BSM_DBG(DBG_NO_XGATHER)) {
+                    const int ri = (wd.rbase >= 0) ? wd.rbase + r : rows[wd.row_off + r];
+                    v = mul(alpha, x[ri + kc(compA) * ldx]);
+                }
+                rr[q] = v;
+            }
+        }
+    }
     if constexpr (MF32) {
 #pragma unroll
         for (int rb = 0; rb < MR; ++rb) facc32[rb] = v4f32{0.f, 0.f, 0.f, 0.f};
@@ -1147,6 +1181,9 @@ __device__ __forceinline__ void run_panel_multi(const WaveD &wd, const uint4 *__
         // the x slice (forward half) and the y indices (transposed half) of the chunk of columns at c0
         // (matrix-pipe path in accumulate mode: alpha goes into the slice, the forward sums leave from the accumulators)
         const bool fold = MFA && !(flags & (FLAG_DIRECT | FLAG_RMW));
+        // (the lane that stages a column writes its K entries 64 / 128 bytes apart from its neighbours': 16- / 32-way bank
+        // conflicts per store -- an XOR swizzle of the slot (k ^ column index within the bank row) was measured: +-0, the
+        // staging is bound by the K x 64 scattered line requests of the gather, not by the LDS)
         auto stage_columns = [&](int c0) {
             if (fwd_en || (BSM_MULTI_IX && trn_en)) {
 #pragma unroll
@@ -1335,7 +1372,7 @@ __device__ __forceinline__ void run_panel_multi(const WaveD &wd, const uint4 *__
 #pragma unroll
                             for (int e = 0; e < 2; ++e) {
                                 const int wl = t0 - c0 + 2 * (4 * j + lk) + e;  // column of the staged slice
-                                const float x1 = xsf[wl * 16 + comp];      // (components in the transposed order, as the x rows)
+                                const float x1 = xsf[wl * 16 + comp];  // (components in the transposed order, as the x rows)
                                 float x2 = xsf[wl * 16 + (comp ^ 1)];
                                 x2 = (((comp & 1) == 0) != cjf) ? -x2 : x2;
                                 facc32[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(x1, b[j].v[e].re, facc32[rb], 0, 0, 0);
@@ -1353,6 +1390,91 @@ __device__ __forceinline__ void run_panel_multi(const WaveD &wd, const uint4 *__
                             dt = __builtin_amdgcn_mfma_f32_16x16x4f32(fr1[rb * 4 + q], u.re, dt, 0, 0, 0);
                             dt = __builtin_amdgcn_mfma_f32_16x16x4f32(fr2[rb * 4 + q], u.im, dt, 0, 0, 0);
                         }
+                    }
+                }
+                if (trn_en) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) pd[r] = dt[r];
+                    pyi = (t0 + ln < t_end) ? ixm[t0 + ln - c0] : -1;
+                    pending = true;
+                }
+            }
+            if (pending) emit();
+        }
+        if constexpr (MFR) {
+            // one step = one row block (16 rows) of one column tile (16 columns = 16 / E strips): 16 / (4 E) loads of
+            // 16 bytes per lane (lane = row ln, strip 4 j + lk), issued one step ahead; E MFMAs per load and half
+            using V4 = typename std::conditional<MFR64, v4f64, v4f32>::type;
+            constexpr int NLD = 4 / E;  // loads per lane and step: 2 (Float64), 1 (Float32)
+            T *tileT = reinterpret_cast<T *>(tile);
+            const int nrb = (m + 15) >> 4;
+            auto fetch = [&](Vec16<T>(&b)[NLD], int t0, int rb) {
+                const int row = rb * 16 + ln;
+#pragma unroll
+                for (int j = 0; j < NLD; ++j) {
+                    const int sidx = t0 / E + 4 * j + lk;
+                    if (row < m && sidx < nstrips && !BSM_DBG(DBG_NO_MATRIX)) {
+                        b[j] = load_stream16(&vb[(uint32_t)(sidx * m + row)]);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < E; ++e) b[j].v[e] = zero_of(T{});
+                    }
+                }
+            };
+            auto comp_of = [&](int r) { return MFR64 ? lk + 4 * r : 4 * r + lk; };  // accumulator row -> right-hand side
+            T pd[4];
+            int pyi = -1;
+            bool pending = false;
+            auto emit = [&]() {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int kq = comp_of(r);
+                    if (pyi >= 0 && kq < kact) {
+                        T *yp = &y[pyi + kq * ldy];
+                        if (flags & FLAG_RMW)
+                            *yp += pd[r];
+                        else if (!BSM_DBG(DBG_NO_GLOBAL_ATOMICS))
+                            atomicAdd(yp, pd[r]);
+                    }
+                }
+                pending = false;
+            };
+            Vec16<T> nxt[NLD];
+            fetch(nxt, 0, 0);
+            for (int t0 = 0; t0 < ncols; t0 += 16) {
+                const int c0 = t0 & ~(XCH - 1);
+                if (t0 == c0) stage_columns(c0);
+                const int t_end = min(ncols, c0 + XCH);
+                V4 dt = {0, 0, 0, 0};
+#pragma unroll
+                for (int rb = 0; rb < MR; ++rb) {
+                    if (rb >= nrb) break;  // (wave-uniform)
+                    Vec16<T> b[NLD];
+#pragma unroll
+                    for (int j = 0; j < NLD; ++j) b[j] = nxt[j];
+                    if (rb + 1 < nrb)
+                        fetch(nxt, t0, rb + 1);
+                    else if (t0 + 16 < ncols)
+                        fetch(nxt, t0 + 16, 0);
+                    if (pending) emit();
+                    if (fwd_en && !BSM_DBG(DBG_NO_FWD_HALF)) {
+#pragma unroll
+                        for (int j = 0; j < NLD; ++j)
+#pragma unroll
+                            for (int e = 0; e < E; ++e) {
+                                const int wl = t0 - c0 + E * (4 * j + lk) + e;  // column of the staged slice
+                                const T x1 = xs[wl * 16 + compA];
+                                if constexpr (MFR64) facc[rb] = mfma16(x1, b[j].v[e], facc[rb]);
+                                if constexpr (MFR32) facc32[rb] = mfma16(x1, b[j].v[e], facc32[rb]);
+                            }
+                    }
+                    if (trn_en && !BSM_DBG(DBG_NO_TRN_HALF)) {
+#pragma unroll
+                        for (int j = 0; j < NLD; ++j)
+#pragma unroll
+                            for (int e = 0; e < E; ++e) tileT[(E * (4 * j + lk) + e) * 17 + ln] = b[j].v[e];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) dt = mfma16(rr[rb * 4 + q], tileT[ln * 17 + 4 * q + lk], dt);
                     }
                 }
                 if (trn_en) {
@@ -1450,8 +1572,11 @@ __device__ __forceinline__ void run_panel_multi(const WaveD &wd, const uint4 *__
         // The forward sums sit in the accumulators TRANSPOSED as well (A = the x slice, B = the tile): lane = (row ln of
         // the row block, lk), register r = component  lk + 4 r (ComplexF64) / 4 r + lk (ComplexF32: the slice enters
         // in transposed component order), i.e. Re and Im of two k for 16 consecutive rows per wave-instruction.
-        using R = typename std::conditional<MF, double, float>::type;
-        auto comp_of = [&](int r) { return MF ? lk + 4 * r : 4 * r + lk; };
+        // (real types, K = 16: a component is a right-hand side)
+        using R = typename std::conditional<MF || MFR64, double, float>::type;
+        constexpr bool M64 = MF || MFR64;  // the f64 accumulator map
+        constexpr int CS = MFR ? 0 : 1;    // component -> k: comp >> CS; Re / Im: comp & CS
+        auto comp_of = [&](int r) { return M64 ? lk + 4 * r : 4 * r + lk; };
         if (FWD && !(flags & (FLAG_DIRECT | FLAG_RMW))) {
             // atomic mode: every wave adds its own partial sums (alpha is in the slice already) -- contiguous runs
             // again instead of Re and Im of one k per instruction, no slab, no combine (a group's waves add separately;
@@ -1467,9 +1592,9 @@ __device__ __forceinline__ void run_panel_multi(const WaveD &wd, const uint4 *__
                     for (int r = 0; r < 4; ++r) {
                         const int cq = comp_of(r);
                         R val;
-                        if constexpr (MF) val = facc[rb][r]; else val = facc32[rb][r];
-                        if (yi >= 0 && (cq >> 1) < kact)
-                            atomicAdd(reinterpret_cast<R *>(&y[yi + (cq >> 1) * ldy]) + (cq & 1), val);
+                        if constexpr (M64) val = facc[rb][r]; else val = facc32[rb][r];
+                        if (yi >= 0 && (cq >> CS) < kact)
+                            atomicAdd(reinterpret_cast<R *>(&y[yi + (cq >> CS) * ldy]) + (cq & CS), val);
                     }
                 }
             }
@@ -1480,14 +1605,14 @@ __device__ __forceinline__ void run_panel_multi(const WaveD &wd, const uint4 *__
             // exclusive launches (plain stores, beta fused, groups combined in LDS by the caller): lane = row, K complex
             // sums -- through the dead x slice, 64 rows x 16 components, component n of row i at i * 16 + (n ^ s(i))
             R *sl = reinterpret_cast<R *>(xs);
-            auto swz = [&](int row) { return MF ? ((row >> 1) & 15) : (row & 15); };
+            auto swz = [&](int row) { return M64 ? ((row >> 1) & 15) : (row & 15); };
 #pragma unroll
             for (int rb = 0; rb < MR; ++rb) {
                 const int row = rb * 16 + ln;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     R val;
-                    if constexpr (MF) val = facc[rb][r]; else val = facc32[rb][r];
+                    if constexpr (M64) val = facc[rb][r]; else val = facc32[rb][r];
                     sl[row * 16 + (comp_of(r) ^ swz(row))] = val;
                 }
             }
@@ -1496,8 +1621,12 @@ __device__ __forceinline__ void run_panel_multi(const WaveD &wd, const uint4 *__
             for (int k = 0; k < K; ++k) {
                 T a = zero_of(T{});
                 if (lane < 16 * MR) {
-                    a.re = sl[lane * 16 + ((2 * k) ^ sw)];
-                    a.im = sl[lane * 16 + ((2 * k + 1) ^ sw)];
+                    if constexpr (MFR) {
+                        a = sl[lane * 16 + (k ^ sw)];
+                    } else {
+                        a.re = sl[lane * 16 + ((2 * k) ^ sw)];
+                        a.im = sl[lane * 16 + ((2 * k + 1) ^ sw)];
+                    }
                 }
                 out[k] = a;
             }
@@ -1519,7 +1648,7 @@ __device__ __forceinline__ void run_panel_multi(const WaveD &wd, const uint4 *__
 // LDS admits 3; fused: 189 VGPRs = 2 per CU without the bound, 168 + 16 spilled dwords with it: C3 in fp32 x 8
 // 176 -> 159 us), 2 otherwise (the fp64 ones fit 3 by themselves)
 template <typename T, int L, bool FWD, bool TRN, int K>
-__global__ void __launch_bounds__(64 * kWavesPerWg, (kMfmaPath32<T, K> ? 4 : ((kTilePipe<T, L, TRN, K> && sizeof(T) == 4) || (kMfmaAny<T, K> && BSM_MFMA_C128_WGS == 3) ? 3 : 2)))
+__global__ void __launch_bounds__(64 * kWavesPerWg, ((kMfmaPath32<T, K> || (kMfmaReal<T, K> && sizeof(T) == 4)) ? 4 : ((kTilePipe<T, L, TRN, K> && sizeof(T) == 4) || (kMfmaAny<T, K> && BSM_MFMA_C128_WGS == 3) ? 3 : 2)))
     panel_kernel_multi(const WaveWork *__restrict__ waves, const uint4 *__restrict__ values,
                        const int *__restrict__ rows, const int *__restrict__ cols,
                        const T *__restrict__ x, long long ldx, T *__restrict__ y, long long ldy, T alpha,
@@ -1896,6 +2025,27 @@ static hipError_t launch_multi_typed(const DeviceImage &img, bool opT, bool conj
     // slots repeat the last column and are never written): a pass costs 1.2-1.8 (8) / 1.1-1.4 (4) single products
     // on the large operators, 3.9 / 3.0 on the BEM fixture -- never more than the 4 + singles it replaces; two
     // columns stay two single products (a 4-column pass over 3-28-row panels costs three).
+    // real types, 9 columns and more: batches of 16 on the matrix pipe (N = 16 of v_mfma_*_16x16x4: kMfmaReal), a
+    // remainder of 9-15 as one padded pass (C3 x 16: 374 us against 2 x 264, C4 slice 442 against 2 x 364; x 9: one
+    // padded pass against an 8-column pass + a single product).  Short scattered panels (the BEM fixture: mean group
+    // height below 32) gain nothing below 15 columns: their passes are bound by the x gather and the atomics, which
+    // grow with the padded width (fp64 x 16: 615 us against 2 x 320).  BSM_MFMA_REAL_MIN_COLS overrides (17: off).
+    if constexpr (kMfmaReal<T, 16>) {
+        static const int mr_env = [] {
+            const char *v = std::getenv("BSM_MFMA_REAL_MIN_COLS");
+            return v ? std::atoi(v) : 0;
+        }();
+        const int mr_min = mr_env ? mr_env : (img.mean_rows < 32.f ? 15 : 9);
+        while (e == hipSuccess && nrhs - k >= 16 && mr_min <= 16) {
+            e = launch_typed_multi<T, 4, 16>(img, opT, conj, xd + k * ldx, ldx, yd + k * ldy, ldy, alpha, beta, strong_zero, stream, zrange);
+            k += 16;
+        }
+        if (e == hipSuccess && nrhs - k >= mr_min && nrhs - k < 16) {
+            const int rem = (int)(nrhs - k);
+            e = launch_typed_multi<T, 4, 16>(img, opT, conj, xd + k * ldx, ldx, yd + k * ldy, ldy, alpha, beta, strong_zero, stream, zrange, rem);
+            k += rem;
+        }
+    }
     while (e == hipSuccess && nrhs - k >= 8) {
         e = launch_typed_multi<T, 4, 8>(img, opT, conj, xd + k * ldx, ldx, yd + k * ldy, ldy, alpha, beta,
                                         strong_zero, stream, zrange);

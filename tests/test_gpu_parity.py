@@ -347,6 +347,24 @@ def test_multi_rhs_symmetric_and_blocksparse_fixture(torch_cuda, bsm, oracle, ke
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_multi_rhs_real_sixteen_column_passes_on_the_matrix_pipe(torch_cuda, bsm, oracle, dtype):
+    """Real element types with 9 and more right-hand sides: batches of 16 (and padded remainders) run on
+    v_mfma_*_16x16x4 (csrc/bsm_kernels.hip: kMfmaReal) -- fused symmetric (atomic and coloured launches), exclusive
+    VBCRS (plain stores, beta fused, groups combined in LDS), BlockSparseMatrix, the reference's fixture (short
+    scattered panels: from 15 columns on), ops N / T, numeric and strong-zero beta, every column against the oracle."""
+    r = bsm.synthetic.config3(nseg=40, dtype=dtype)
+    _check_multi(torch_cuda, bsm, oracle, r, bsm.synthetic.build(r), dtype, nrhs_list=(16, 11, 35), ops=[N, T])
+    _check_multi(torch_cuda, bsm, oracle, r, bsm.synthetic.build(r, accumulate="colored"), dtype, nrhs_list=(16,), ops=[N])
+    v = bsm.synthetic.config2(n=12000, nblocks=600, dtype=dtype)
+    _check_multi(torch_cuda, bsm, oracle, v, bsm.synthetic.build(v), dtype, nrhs_list=(16, 9), ops=[N, T])
+    _check_multi(torch_cuda, bsm, oracle, v, bsm.synthetic.build(v, transpose_image=True), dtype, nrhs_list=(13,), ops=[T])
+    f = fixture_problem("cuboid", dtype, "real")
+    _check_multi(torch_cuda, bsm, oracle, f, bsm.synthetic.build(f), dtype, nrhs_list=(16, 15, 17), ops=[N])
+    q = fixture_as_blocksparse("cuboid", dtype, "real")
+    _check_multi(torch_cuda, bsm, oracle, q, bsm.synthetic.build(q), dtype, nrhs_list=(16,), ops=[N, T])
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_multi_rhs_real_fused_and_transposed_tile_pipeline(torch_cuda, bsm, oracle, dtype):
     """The 8-column fused / transposed kernels in real arithmetic prefetch their matrix tiles into LDS
     (global_load_lds, counted vmcnt, deferred atomics): every strip height (8 / 16 / 32 / 64 rows, heights that

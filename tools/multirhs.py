@@ -65,7 +65,7 @@ for name in names:
     reps = 100 if st["alg_bytes"] < 200e6 else 15
     t1 = timed(plan, reps)
     line = f"{name:9s} 1 rhs {t1:8.1f} us ({st['alg_bytes']/t1/1e3:5.0f} GB/s)"
-    for K in (4, 8):
+    for K in (4, 8, 16):
         X = torch.empty((K, n), dtype=x.dtype, device="cuda").t()  # column-major n x K
         for k in range(K):
             X[:, k] = x * (k + 1)
