@@ -289,8 +289,10 @@ int bsm_host_unregister(void *ptr);
 
 /* Y = alpha * op(A) * X + beta * Y for nrhs right-hand sides -- `A * X` / `mul!(Y, A, X, a, b)`
  * with matrices.  LinearMaps loops the columns of X through _unsafe_mul! (nrhs full sweeps of A);
- * here A is streamed ONCE per batch of up to 8 columns (a remainder of 2-7 columns is one padded
- * pass; nothing outside the nrhs columns of X and Y is read or written).  X is size(op(A),2) x nrhs
+ * here A is streamed ONCE per batch of up to 8 columns (16 for Float32 / Float64 matrices from 9 columns on; a
+ * remainder is one padded pass; nothing outside the nrhs columns of X and Y is read or written).  The 8-column
+ * passes of the complex types and the 16-column passes of the real ones run on the matrix pipe (8 complex
+ * columns = 16 real ones = N of v_mfma_{f64,f32}_16x16x4).  X is size(op(A),2) x nrhs
  * and Y is size(op(A),1) x nrhs, both column-major with leading dimensions ldx / ldy (elements).
  * Every other argument as in bsm_mul; each column gives what nrhs = 1 semantics prescribe (same
  * alpha, beta, strong zero). */
