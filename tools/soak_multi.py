@@ -19,20 +19,28 @@ def bem(tiles, dtype, part):
     prob = dict(kind="symmetric", diagonals=p["diagonals"] * tiles, diagonalindices=tile(p["diagonalindices"]),
                 offdiagonals=p["offdiagonals"] * tiles, rowindices=tile(p["rowindices"]), colindices=tile(p["colindices"]),
                 size=(n0 * tiles, n0 * tiles))
-    prob["x"] = torch.from_numpy(np.random.default_rng(0).standard_normal(n0 * tiles).astype(dtype)).cuda()
+    xh = np.random.default_rng(0).standard_normal(n0 * tiles)
+    if np.dtype(dtype).kind == "c":
+        xh = xh + 1j * np.random.default_rng(1).standard_normal(n0 * tiles)
+    prob["x"] = torch.from_numpy(xh.astype(dtype)).cuda()
     return prob
 
 
 CASES = {"c3": lambda: S.config3(on_device=True), "c5s": lambda: S.config5(n=625_000, on_device=True),
-         "bem_f64": lambda: bem(200, np.float64, "real"), "c3_f32": lambda: S.config3(on_device=True, dtype=np.float32)}
+         "bem_f64": lambda: bem(200, np.float64, "real"), "c3_f32": lambda: S.config3(on_device=True, dtype=np.float32),
+         # the matrix-pipe kernels: 8 complex columns (and padded 3-7), 16 real ones (and padded 9-15)
+         "bem_c128": lambda: bem(200, np.complex128, "full"), "bem_c64": lambda: bem(200, np.complex64, "full")}
+only = [a for a in sys.argv[2:]]
+if only:
+    CASES = {k: v for k, v in CASES.items() if k in only}
 bad = 0
 for name, make in CASES.items():
     prob = make()
     A = S.build(prob)
     x = prob["x"]
     n = x.shape[0]
-    tol = 1e-12 if x.dtype == torch.float64 else 2e-5
-    for K in (8, 5, 4, 3):
+    tol = 1e-12 if x.dtype in (torch.float64, torch.complex128) else 2e-5
+    for K in ((8, 5, 4, 3) if x.dtype.is_complex else (16, 11, 8, 5, 4, 3)):
         g = torch.Generator(device="cuda").manual_seed(K)
         X = torch.randn((K, n), dtype=x.dtype, device="cuda", generator=g).t()
         ref = torch.zeros((K, n), dtype=x.dtype, device="cuda").t()
