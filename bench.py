@@ -243,6 +243,8 @@ def leg(bsm, torch, prob, reps, multi_rhs=0, **kw):
         torch.cuda.synchronize()
         out["multi_rhs"] = {"nrhs": K, "us": round(tk * 1e6, 2), "single_products": round(tk / t, 3),
                             "relerr_vs_single_products": worst}
+        if x.dtype.is_complex and K == 8:  # (csrc/bsm_kernels.hip: kMfmaPath / kMfmaPath32; counters: profiles/r04_multirhs_mfma_counters.txt)
+            out["multi_rhs"]["pipe"] = "matrix pipe: 8 complex columns = N = 16 of v_mfma_%s_16x16x4" % ("f64" if x.dtype == torch.complex128 else "f32")
         del X, Y
     del plan, A
     return out, y
