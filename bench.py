@@ -224,8 +224,9 @@ def leg(bsm, torch, prob, reps, multi_rhs=0, **kw):
         out["graph_frac_of_hbm_peak"] = round(st["alg_bytes"] / tg / 1e9 / HBM_PEAK_GBPS, 4)
     if st.get("win_emissions"):  # fused symmetric launch: share of the y contributions that leave a CU as global atomics
         out["y_contributions_as_atomics"] = round((st["win_emissions"] - st["win_inside"] + st["win_flushed"]) / st["win_emissions"], 3)
-    if multi_rhs:
-        K, n = int(multi_rhs), x.shape[0]
+    for K in ([multi_rhs] if isinstance(multi_rhs, int) else list(multi_rhs)) if multi_rhs else []:
+        key = "multi_rhs" if K == 8 else f"multi_rhs_{K}"
+        n = x.shape[0]
         X = torch.empty((K, n), dtype=x.dtype, device="cuda").t()  # column-major n x K
         for k in range(K):
             X[:, k] = x * (k + 1) / K
@@ -241,10 +242,12 @@ def leg(bsm, torch, prob, reps, multi_rhs=0, **kw):
             worst = max(worst, float((Y[:, k] - y).abs().max() / y.abs().max()))
         plan()  # (y back to the single product of x)
         torch.cuda.synchronize()
-        out["multi_rhs"] = {"nrhs": K, "us": round(tk * 1e6, 2), "single_products": round(tk / t, 3),
-                            "relerr_vs_single_products": worst}
+        out[key] = {"nrhs": K, "us": round(tk * 1e6, 2), "single_products": round(tk / t, 3),
+                    "relerr_vs_single_products": worst}
         if x.dtype.is_complex and K == 8:  # (csrc/bsm_kernels.hip: kMfmaPath / kMfmaPath32; counters: profiles/r04_multirhs_mfma_counters.txt)
-            out["multi_rhs"]["pipe"] = "matrix pipe: 8 complex columns = N = 16 of v_mfma_%s_16x16x4" % ("f64" if x.dtype == torch.complex128 else "f32")
+            out[key]["pipe"] = "matrix pipe: 8 complex columns = N = 16 of v_mfma_%s_16x16x4" % ("f64" if x.dtype == torch.complex128 else "f32")
+        if not x.dtype.is_complex and K == 16:  # (kMfmaReal)
+            out[key]["pipe"] = "matrix pipe: 16 real columns = N = 16 of v_mfma_%s_16x16x4" % ("f64" if x.dtype == torch.float64 else "f32")
         del X, Y
     del plan, A
     return out, y
@@ -868,7 +871,7 @@ def run_c2(args, bsm, torch, dist, np, rank, world, barrier, reduce_scalars):
         try:  # (additional figures must never cost the headline line)
             extra["hbm_vbcrs_fp64"], _ = leg(bsm, torch, S.config2(n=2_000_000, nblocks=100_000, on_device=True), 50)
             extra["hbm_vbcrs_fp64"]["workload"] = "C2-shaped VBCRS 2M x 2M, 100 000 fp64 blocks 8-64 (20 x C2), forward mul!"
-            extra["c3_fused"], _ = leg(bsm, torch, S.config3(on_device=True), 50, multi_rhs=8)
+            extra["c3_fused"], _ = leg(bsm, torch, S.config3(on_device=True), 50, multi_rhs=(8, 16))
             extra["c3_fused"]["workload"] = "C3: SymmetricBlockMatrix 200k x 200k, 64x64 fp64 blocks, half-bandwidth 8, fused A + A^T mul!"
         except Exception as e:  # pragma: no cover
             extra["legs_error"] = repr(e)
