@@ -595,9 +595,8 @@ static int dist_mul_fused(DistState &D, int op, int K, const std::vector<VecSour
             if (mine) taken = true;
         }
     }
-    // flags pay where streams wait for each other (a write-value packet costs ~2 us more than an event record that
-    // nobody waits for: a product whose parts all work on ONE stream -- partitioned vectors driven from one stream of
-    // one virtual device -- keeps events: tools/distbench.py, 2 parts 202 vs 188 us)
+    // flags pay where streams wait for each other; a product whose parts all work on ONE stream orders nothing at all
+    // (below)
     bool several_streams = false;
     for (int p = 1; p < P; p++) several_streams = several_streams || run[p] != run[0] || D.parts[p]->device != D.parts[0]->device;
     // everything on ONE stream of one device -- the parts and the caller's vectors (one part, or partitioned vectors
