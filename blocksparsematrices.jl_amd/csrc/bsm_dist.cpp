@@ -804,7 +804,7 @@ static int dist_mul_fused(DistState &D, int op, int K, const std::vector<VecSour
     return BSM_OK;
 }
 
-// K <= 8 right-hand sides in one fan-out (K = 1: bsm_mul).  X / Y: column k at x + k * ldx / y + k * ldy
+// K <= 16 right-hand sides in one fan-out (K = 1: bsm_mul).  X / Y: column k at x + k * ldx / y + k * ldy
 // elements.  The part buffers hold column k at k * vlen elements.
 static int dist_mul_copies(bsm_matrix_s *A, int op, int K, const void *x, long long ldx, void *y, long long ldy,
                            const void *alpha, const void *beta, int beta_strong_zero, int memspace, hipStream_t stream) {
@@ -1140,11 +1140,16 @@ int dist_mul(bsm_matrix_s *A, int op, const void *x, void *y, const void *alpha,
 int dist_mul_multi(bsm_matrix_s *A, int op, long long nrhs, const void *X, long long ldx, void *Y, long long ldy,
                    const void *alpha, const void *beta, int beta_strong_zero, int memspace, hipStream_t stream) {
     const size_t es = (size_t)A->dist->es;
-    for (long long k = 0; k < nrhs; k += 8) {
-        const int kb = (int)std::min<long long>(8, nrhs - k);
+    // batches of 8 columns per fan-out; Float32 / Float64 operators take 9 and more columns 16 at a time (the parts'
+    // 16-column matrix-pipe passes, bsm_kernels.hip: kMfmaReal)
+    const bool real = A->dist->dtype == 0 || A->dist->dtype == 1;
+    for (long long k = 0; k < nrhs;) {
+        const long long left = nrhs - k;
+        const int kb = (int)((real && left >= 9) ? std::min<long long>(16, left) : std::min<long long>(8, left));
         int rc = dist_mul_k(A, op, kb, (const char *)X + (size_t)k * ldx * es, ldx, (char *)Y + (size_t)k * ldy * es, ldy,
                             alpha, beta, beta_strong_zero, memspace, stream);
         if (rc != BSM_OK) return rc;
+        k += kb;
     }
     return BSM_OK;
 }

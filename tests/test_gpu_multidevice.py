@@ -206,8 +206,9 @@ def test_concurrent_products_on_one_multi_device_handle(torch_cuda, bsm, oracle)
     assert not errs, errs[:3]
 
 
+@pytest.mark.parametrize("K", [11, 20])
 @pytest.mark.parametrize("kind", ["symmetric", "vbcrs", "fixture"])
-def test_multi_rhs_through_the_multi_device_handle(torch_cuda, bsm, oracle, kind):
+def test_multi_rhs_through_the_multi_device_handle(torch_cuda, bsm, oracle, kind, K):
     """mul!(Y, A, X, a, b) with matrices on a handle spread over three parts: every device streams its
     part once per batch of <= 8 columns, the halo and the delivery carry the batch's columns; 11 columns =
     a batch of 8 + one of 3; padded leading dimensions; host and device memory; each column against the
@@ -223,7 +224,7 @@ def test_multi_rhs_through_the_multi_device_handle(torch_cuda, bsm, oracle, kind
     dt = np.dtype(A.dtype)
     n = prob["size"][0]
     rng = np.random.default_rng(21)
-    K, ld = 11, n + 5
+    ld = n + 5  # (K = 20 on a real operator: a fan-out of 16 columns -- the parts' matrix-pipe passes -- and one of 4)
     Xp = np.zeros((ld, K), dtype=dt, order="F")
     Yp = np.zeros((ld, K), dtype=dt, order="F")
     Xp[:n] = rng.standard_normal((n, K)) + (1j * rng.standard_normal((n, K)) if dt.kind == "c" else 0)
