@@ -70,6 +70,15 @@ def counter_file(path, build, kernel=None, alg_bytes=None):
     return d, None
 
 
+def profiler_in_environment(env):
+    """names what says that this process was started under rocprofv3 / rocprofiler (its preloaded tool library or its
+    control variables), or None"""
+    for k, v in env.items():
+        if k.startswith(("ROCPROFILER_", "ROCPROF_", "ROCP_")) or (k in ("LD_PRELOAD", "HSA_TOOLS_LIB") and "rocprof" in v.lower()):
+            return k
+    return None
+
+
 def live_traffic(kernel_sub, alg_bytes):
     """HBM traffic of the C2 product measured NOW: two rocprofv3 passes (FETCH_SIZE, WRITE_SIZE -- one counter per
     pass, --kernel-trace only, MI355X_MICROARCH.md) over a child process that runs this script's C2 launches
@@ -84,6 +93,9 @@ def live_traffic(kernel_sub, alg_bytes):
     exe = shutil.which("rocprofv3")
     if exe is None:
         return None, "rocprofv3 is not on this box"
+    why = profiler_in_environment(os.environ)
+    if why:  # this very process runs under a profiler: a child would inherit its preload and nest profilers
+        return None, "not taken: bench.py itself runs under a profiler (%s)" % why
     means = {}
     env = dict(os.environ, TMPDIR="/tmp")
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -314,6 +326,25 @@ def self_launch(args):
     return (rc or 3) if '"value_invalid": true' in line else 0
 
 
+def init_one_rank(backend, torch, dev_index):
+    """torch.distributed with ONE rank (the loopback rehearsal): own rendezvous on 127.0.0.1"""
+    import datetime
+    import socket
+    import torch.distributed as dist
+    if dist.is_initialized():
+        return dist
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if "MASTER_PORT" not in os.environ:
+        sk = socket.socket()
+        sk.bind(("127.0.0.1", 0))
+        os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+        sk.close()
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    kw = {"device_id": torch.device("cuda", dev_index)} if backend == "nccl" else {}
+    dist.init_process_group(backend, rank=0, world_size=1, timeout=datetime.timedelta(minutes=5), **kw)
+    return dist
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -334,6 +365,10 @@ def main():
                     "(the round-2 step) instead of the overlapped one")
     ap.add_argument("--no-live-pmc", action="store_true", help="take roofline.traffic from the stamped file under profiles/ "
                     "instead of two rocprofv3 passes of this run")
+    ap.add_argument("--loopback", action="store_true", help="N = 1, --workload c5: initialise the backend (nccl = RCCL) with ONE rank and run "
+                    "the N > 1 step for real -- the rank owns all but the first and last 8 diagonal segments, a phantom neighbour (this "
+                    "same process) the rest, so the x halo and the partial-y halo travel through grouped self send / recv beside the "
+                    "interior launch (distributed.RowPartitioned(loopback=...)): the only way a one-GPU box executes RCCL")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.pmc_child:
@@ -366,6 +401,10 @@ def main():
     # never met real multi-GPU hardware before the driver's run), every rank switches to it together
     # and the JSON line says so -- a slow measured line instead of none.
     comm = {"group": None, "dev": "cuda", "name": args.backend, "fallback": None}
+    if world == 1 and args.loopback:
+        dist = init_one_rank(args.backend, torch, dev_index)
+        if args.backend != "nccl":
+            comm["dev"] = "cpu"
     if world > 1:
         import datetime
         import torch.distributed as dist
@@ -419,6 +458,7 @@ def run_partitioned(args, bsm, torch, dist, np, rank, world, barrier, reduce_sca
     from bsm_amd import distributed as D
     S = bsm.synthetic
     comm = reduce_scalars.comm
+    loopback = bool(getattr(args, "loopback", False)) and world == 1
 
     def c5_share():
         n = int(5_000_000 * args.scale)
@@ -434,6 +474,12 @@ def run_partitioned(args, bsm, torch, dist, np, rank, world, barrier, reduce_sca
         segs = np.nonzero(part == rank)[0]
         lo, hi = (int(segs[0]), int(segs[-1]) + 1) if len(segs) else (0, 0)
         prob = S.config5(n=n, on_device=True, seg_lo=lo, seg_hi=hi)
+        if loopback:
+            # one rank plays a MIDDLE rank of a node: it owns all but the first and last `edge` segments, the phantom
+            # neighbour (this process) the rows of those -- their blocks are this rank's boundary blocks
+            edge = min(8, max(nseg // 4, 1))
+            lb_own = (int(start[edge]) + 1, int(start[nseg - edge]))
+            return prob, lb_own, True, "C5: SymmetricBlockMatrix %dx%d, segments U{16..256}, off-diagonal (I,J) J=I-1..I-4, fp64" % (n, n), (lambda: prob)
 
         def verification():
             # everything that contributes to this rank's rows, built WITHOUT any exchange: the rank's own
@@ -452,6 +498,9 @@ def run_partitioned(args, bsm, torch, dist, np, rank, world, barrier, reduce_sca
         lo, hi = rank * ngrid // world, (rank + 1) * ngrid // world  # uniform blocks: equal row counts == equal bytes
         prob = S.config4(ngrid=ngrid, on_device=True, row_lo=lo, row_hi=hi)
         own = (lo * 128 + 1, hi * 128)
+        if loopback:
+            edge = min(8, max(ngrid // 4, 1))
+            own = (edge * 128 + 1, (ngrid - edge) * 128)
         return prob, own, False, "C4: VBCRS %dx%d, %d 128x128 fp32 blocks (16 per block row)" % (ngrid * 128, ngrid * 128, ngrid * 16), (lambda: prob)
 
     def run(share, steps, warmup, overlap):
@@ -464,13 +513,16 @@ def run_partitioned(args, bsm, torch, dist, np, rank, world, barrier, reduce_sca
         if overlap:
             # interior blocks (read x[own], write y[own]) and boundary blocks as two handles: the exchanges
             # and the boundary product run on a side stream beside the interior launch
-            P = D.build_overlapped(prob, own, group=comm["group"], symmetric=sym, xmode="halo" if sym else "allgather")
+            P = D.build_overlapped(prob, own, group=comm["group"], symmetric=sym, xmode="halo" if sym else "allgather",
+                                   loopback=own if loopback else None)
             handles = [h for h in (P.interior, P.local) if h is not None]
         else:
             touched = D._touched(own, prob["colindices"]) if sym else own
+            if loopback:  # the rank holds every block; rows outside `own` are the phantom's
+                touched = (1, n)
             A = D.build_local(prob, touched)
             P = D.RowPartitioned(A, own, touched, group=comm["group"], gather=False, symmetric=sym,
-                                 xneed=touched if sym else None)
+                                 xneed=touched if sym else None, loopback=own if loopback else None)
             handles = [A] if A is not None else []
         t_setup = time.perf_counter() - t0
         if not handles:
@@ -527,7 +579,8 @@ def run_partitioned(args, bsm, torch, dist, np, rank, world, barrier, reduce_sca
             step()
         barrier()
         elapsed = time.perf_counter() - t0
-        y_step = y[own[0] - 1:own[1]].clone()
+        chk = (1, n) if loopback else own  # loopback: the phantom's rows are this process's too -- every row is checked
+        y_step = y[chk[0] - 1:chk[1]].clone()
         # the local kernels alone (HIP events on the stream they are launched on), for the roofline object
         yk = torch.zeros_like(y)
         plans = [bsm.MulPlan(yk, h, x) for h in handles]
@@ -551,7 +604,7 @@ def run_partitioned(args, bsm, torch, dist, np, rank, world, barrier, reduce_sca
         Aver = S.build(verification())
         yv = torch.full((n,), float("nan"), dtype=x.dtype, device="cuda")
         bsm.mul(yv, Aver, x_full)
-        ref = yv[own[0] - 1:own[1]]
+        ref = yv[chk[0] - 1:chk[1]]
         scale = float(ref.abs().max().item())
         diff = float((y_step - ref).abs().max().item())
         rel = diff / scale if scale > 0 else float("nan")
@@ -632,6 +685,13 @@ def run_partitioned(args, bsm, torch, dist, np, rank, world, barrier, reduce_sca
         "roofline": roofline,
     }
     notes = [t for t in (args.note, r5.get("note")) if t]
+    if loopback:
+        out["config"]["loopback"] = {
+            "what": "ONE rank over the %s backend playing a middle rank of a node: it owns rows %d..%d (all but the first and last 8 "
+                    "diagonal segments), a phantom neighbour -- this same process -- the rest; the x halo and the partial-y halo of "
+                    "the boundary blocks travel through grouped self send / recv (batch_isend_irecv on device tensors) on the side "
+                    "stream beside the interior launch; every row of y is checked against an ordinary single-handle product" % (backend, r5["own"][0], r5["own"][1]),
+            "librccl_loaded": bool([ln for ln in open("/proc/self/maps") if "librccl" in ln])}
     if world > 1 and args.scale == 1.0:
         # the same operator on ONE GPU (profiles/r04_c5_n1.json: `bench.py --gpus 1 --workload c5` on an MI355X box of this
         # pool, stamped with the build of the kernels): what this line's value has to be divided by for a speed-up --
@@ -915,6 +975,30 @@ def run_c2(args, bsm, torch, dist, np, rank, world, barrier, reduce_scalars):
                                                       "committed copy of this figure as config.n1_same_workload"}
         except Exception as e:  # pragma: no cover
             extra["c5_n1"] = {"error": repr(e)}
+        torch.cuda.empty_cache()
+        # the same step with the exchanges REALLY running over RCCL: one rank, loopback (see --loopback).  What the halo
+        # exchange of a middle rank costs beside the interior launch on this box; the first and only execution of the
+        # nccl branches of distributed.py a one-GPU box allows.
+        try:
+            d1 = init_one_rank("nccl", torch, torch.cuda.current_device())
+            a5.loopback = True
+            cm = {"group": None, "dev": "cuda", "name": "nccl", "fallback": None}
+
+            def bar1():
+                d1.barrier()
+                torch.cuda.synchronize()
+
+            def red1(elapsed, nbytes):
+                return elapsed, float(nbytes)
+            red1.comm = cm
+            o6 = run_partitioned(a5, bsm, torch, d1, np, 0, 1, bar1, red1)
+            extra["c5_n1_rccl_loopback"] = {"value": o6["value"], "unit": "GB/s", "ms_per_step": o6["ms_per_step"], "steps": 20,
+                                            "exchange_us": o6["config"]["exchange_us"], "local_kernel_us_max": o6["config"]["local_kernel_us_max"],
+                                            "parity_relerr": o6["config"]["parity_relerr"], "backend": o6["config"]["backend"],
+                                            "loopback": o6["config"]["loopback"]}
+            d1.destroy_process_group()
+        except Exception as e:  # pragma: no cover
+            extra["c5_n1_rccl_loopback"] = {"error": repr(e)}
         torch.cuda.empty_cache()
     mf, why_mf = counter_file(MFMA_FILE, build)
     if rank == 0:

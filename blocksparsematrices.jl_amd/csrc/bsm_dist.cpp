@@ -8,6 +8,7 @@
 // device travel -- as direct peer-to-peer copies over the xGMI links followed by a local add.
 // One host thread issues everything; every step is asynchronous and ordered by events.
 #include <algorithm>
+#include <atomic>
 #include <complex>
 #include <condition_variable>
 #include <cstdlib>
@@ -457,21 +458,26 @@ int dist_create(bsm_matrix_s *A, bsm_ctx_s *ctx, int mtype, int dtype, int64_t n
     }
     D.all_peer = ctx->peer_ok;  // enabled for every pair when the context was created (bsm_ctx_create)
     if (const char *v = std::getenv("BSM_DIST_COPIES")) D.all_peer = D.all_peer && std::atoi(v) == 0;  // tests: force the copy path
-    if (const char *v = std::getenv("BSM_DIST_REZERO")) D.rezero = std::atoi(v) != 0;
     if (const char *v = std::getenv("BSM_DIST_ONE_STREAM")) D.one_stream = std::atoi(v) != 0;
     {
-        // flags: on by default where they have been exercised -- every part on ONE physical device (virtual devices); on
-        // distinct devices (a flag polled by another GPU's command processor has never run on this pool) only on request
+        // flags and zero-keeping: on by default where they have been exercised -- every part on ONE physical device
+        // (virtual devices).  On distinct devices a flag is polled by another GPU's command processor and the finish
+        // kernels write their zeros into a PEER's work vector over xGMI (visible to the owner's next atomic
+        // accumulation only if those remote writes have reached its L2 at the event boundary): neither has ever run
+        // on this pool, so both are opt-in there (BSM_DIST_FLAGS=1 / BSM_DIST_REZERO=1) until one 2-GPU parity run of
+        // test_work_vectors_stay_zero_* / test_flag_and_event_ordering_* has passed on real devices.
         bool one_device = true;
         for (int d : ctx->devices) one_device = one_device && d == ctx->devices[0];
-        int can = 0;
+        D.rezero = one_device;
+        if (const char *v = std::getenv("BSM_DIST_REZERO")) D.rezero = std::atoi(v) != 0;
+        int can = 1;
         for (int d : ctx->devices) {
             int c = 0;
             if (hipDeviceGetAttribute(&c, hipDeviceAttributeCanUseStreamWaitValue, d) != hipSuccess) {
                 (void)hipGetLastError();
                 c = 0;
             }
-            can = (d == ctx->devices[0]) ? c : (can && c);
+            can = can && c;  // EVERY device of the context must be able to run the wait packets
         }
         D.use_flags = one_device && can;
         if (const char *v = std::getenv("BSM_DIST_FLAGS")) D.use_flags = std::atoi(v) != 0 && can;
@@ -562,9 +568,54 @@ struct VecDest {
     int ready_flag = -1;
 };
 
+static int dist_mul_fused_issue(DistState &D, int op, int K, const std::vector<VecSource> &src, long long ldx,
+                                const std::vector<VecDest> &dst, long long ldy, const void *alpha, const void *beta,
+                                int beta_strong_zero);
+
+// test hook (unexported in the header, like bsm_debug_move_image_array): the n-th fused fan-out from now fails between
+// its two phases, the way a launch error would (tests/test_gpu_multidevice.py: the product after it must not hang)
+static std::atomic<int> g_fail_countdown{-1};
+extern "C" void bsm_debug_dist_fail_after(int n) { g_fail_countdown.store(n); }
+static bool injected_failure() {
+    int c = g_fail_countdown.load();
+    if (c < 0) return false;
+    return g_fail_countdown.fetch_sub(1) == 0;
+}
+
+// The fan-out, and what is left behind when it fails half-way.  Events degrade by themselves (an event that was never
+// recorded counts as complete); sequence counters do not: the failed product has consumed a number, wait packets for it
+// may already be queued, and the write packets that would release them were never issued -- the next product's
+// previous() would wait for flag >= seq forever and the drain of a mode change would block the host.  So on any error
+// the host writes the product's number into every counter (coherent pinned memory: the queued waits fall through),
+// drains the devices and leaves the handle as after create: no ordering form remembered, no delivery to wait for, work
+// vectors "unknown" (the next fused product clears them once).
 static int dist_mul_fused(DistState &D, int op, int K, const std::vector<VecSource> &src, long long ldx,
                           const std::vector<VecDest> &dst, long long ldy, const void *alpha, const void *beta,
                           int beta_strong_zero) {
+    const int rc = dist_mul_fused_issue(D, op, K, src, ldx, dst, ldy, alpha, beta, beta_strong_zero);
+    if (rc == BSM_OK) return rc;
+    const int P = (int)D.parts.size();
+    if (D.flags) {
+        volatile uint64_t *F = D.flags;
+        for (int i = 0; i < 3 * P + 1; i++)
+            if (F[i] < D.seq) F[i] = D.seq;
+        __sync_synchronize();
+    }
+    for (int p = 0; p < P; p++) {
+        DeviceGuard g;
+        if (g.enter(D.parts[p]->device) == hipSuccess) (void)hipDeviceSynchronize();
+        (void)hipGetLastError();
+        D.parts[p]->w_clean = false;
+    }
+    D.last_mode = -1;
+    D.last_single_stream = nullptr;
+    D.produced = false;
+    return rc;
+}
+
+static int dist_mul_fused_issue(DistState &D, int op, int K, const std::vector<VecSource> &src, long long ldx,
+                                const std::vector<VecDest> &dst, long long ldy, const void *alpha, const void *beta,
+                                int beta_strong_zero) {
     const int P = (int)D.parts.size();
     const bool along = (op == BSM_OP_N) || D.symmetric;
     const Plan &pl = along ? D.plan_n : D.plan_t;
@@ -783,6 +834,7 @@ static int dist_mul_fused(DistState &D, int op, int K, const std::vector<VecSour
     };
     for (int ph = 0; ph < 2; ph++) {
         int rc = BSM_OK;
+        if (ph == 1 && injected_failure()) return hip_fail(hipErrorUnknown, "injected failure between the phases of a fan-out");
         if (D.workers)
             rc = D.workers->run([&](int p) { return phase(ph, p, false); });
         else
@@ -981,6 +1033,7 @@ static int dist_mul_copies(bsm_matrix_s *A, int op, int K, const void *x, long l
     };
     for (int ph = 0; ph < 2; ph++) {
         int rc = BSM_OK;
+        if (ph == 1 && injected_failure()) return hip_fail(hipErrorUnknown, "injected failure between the phases of a fan-out");
         if (D.workers)
             rc = D.workers->run([&](int p) { return phase(ph, p, false); });
         else

@@ -230,7 +230,7 @@ def split_interior(local, own):
     return interior, boundary, btouched, bxneed
 
 
-def build_overlapped(local, own, group=None, symmetric=None, xmode="auto", **kw):
+def build_overlapped(local, own, group=None, symmetric=None, xmode="auto", loopback=None, **kw):
     """RowPartitioned for the partitioned-vector forward product with the exchange OVERLAPPED with the
     interior rows (mul_overlapped): two handles per rank -- interior blocks with own = the rank's
     rows, boundary blocks with own = the rows they touch.  xmode: "halo" (the x entries the boundary
@@ -244,7 +244,7 @@ def build_overlapped(local, own, group=None, symmetric=None, xmode="auto", **kw)
         extra = max(0, own[0] - bxneed[0]) + max(0, bxneed[1] - own[1]) if bxneed[1] >= bxneed[0] else 0
         xmode = "halo" if extra <= max(own[1] - own[0] + 1, 0) else "allgather"
     P = RowPartitioned(A_bnd, own, btouched, group=group, gather=False, symmetric=sym,
-                       xneed=(bxneed if xmode == "halo" else None), interior=A_int)
+                       xneed=(bxneed if xmode == "halo" else None), interior=A_int, loopback=loopback)
     P.xmode = xmode
     return P
 
@@ -262,8 +262,26 @@ class RowPartitioned:
     its beta pass covers exactly the rows it touches), or None for a rank without blocks."""
 
     def __init__(self, local, own, touched=None, group=None, gather=False, axis=0, symmetric=None, xneed=None,
-                 interior=None):
+                 interior=None, loopback=None):
         self.local = local
+        # LOOPBACK rehearsal (one rank, any backend -- meant for "nccl" on the single GPU of a test box, where RCCL
+        # refuses two ranks per device): every collective and point-to-point branch of this class runs against the
+        # rank ITSELF instead of being skipped at world == 1.
+        #   loopback=True     the world == 1 short cuts are off: all_gather_into_tensor / reduce_scatter_tensor /
+        #                     all_reduce really run (one rank), and what they deliver is what ends up in y (the
+        #                     source slice is poisoned with NaN in between);
+        #   loopback=(lo, hi) additionally the rank plays TWO roles: itself, owning rows lo..hi only (`own` must be
+        #                     that range), and a block-less phantom neighbour owning every other row.  x entries
+        #                     outside lo..hi and partial-y segments outside lo..hi then travel through grouped self
+        #                     send / recv (batch_isend_irecv on device tensors: ncclSend / ncclRecv to the own rank
+        #                     inside one group are legal) exactly like the halo between two ranks; the source of
+        #                     every transfer is poisoned or zeroed behind the send, so a transfer that did not
+        #                     happen, or one that was overtaken by the kernels around it, shows in the result.
+        self.loopback = bool(loopback)
+        self._phantom = None
+        if isinstance(loopback, (tuple, list)):
+            if (int(loopback[0]), int(loopback[1])) != (int(own[0]), int(own[1])):
+                raise ValueError("loopback=(lo, hi) must be the `own` range of the rank's own role")
         # mul_overlapped only: handle of the rank's INTERIOR blocks (own = the rank's rows); `local` then
         # holds the boundary blocks and `touched` the rows THEY write (see split_interior)
         self.interior = interior
@@ -280,6 +298,10 @@ class RowPartitioned:
         self.symmetric = isinstance(local, M.SymmetricBlockMatrix) if symmetric is None else symmetric
         self.rank = dist.get_rank(group) if dist is not None and dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist is not None and dist.is_initialized() else 1
+        if self.loopback:
+            if self.world != 1:
+                raise ValueError("loopback is a one-rank rehearsal")
+            self._phantom = isinstance(loopback, (tuple, list))
         self._ranges = None
         self._plan = None   # halo exchange of products along the partition (buffers included)
         self._work = None
@@ -298,15 +320,27 @@ class RowPartitioned:
             xn = self.xneed if self.xneed is not None else (0, -1)
             mine = torch.tensor([self.own[0], self.own[1], self.touched[0], self.touched[1], xn[0], xn[1]],
                                 dtype=torch.int64)
-            if self.world > 1:
+            if self.world > 1 or self.loopback:
                 out = [torch.zeros(6, dtype=torch.int64, device=device) for _ in range(self.world)]
                 dist.all_gather(out, mine.to(device), group=self.group)
                 full = [tuple(int(v) for v in t.cpu()) for t in out]
             else:
                 full = [tuple(int(v) for v in mine)]
+            if self._phantom:
+                # logical ranks of the loopback rehearsal: 0 = this rank's own role, 1 / 2 = the phantom neighbour's
+                # rows below / above it (no blocks: they touch nothing and read nothing); all three are this process
+                lo, hi = self.own
+                big = 1 << 62
+                full = [full[0], (1, lo - 1, 1, lo - 1, 1, 0), (hi + 1, big, hi + 1, big, 1, 0)]
+                if self.xneed is None:
+                    full[0] = full[0][:4] + (1, big)  # "reads everything": every x entry outside own comes from the phantom
             self._ranges = [t[:4] for t in full]
             self._xneeds = [t[4:] for t in full]
         return self._ranges
+
+    def _peer(self, r):
+        """physical rank behind logical rank r (loopback: every logical rank is this process)"""
+        return self.rank if self._phantom else r
 
     def fetch_x(self, x):
         """x arrives PARTITIONED like y (every rank holds x[own] only, the rest of the full-length
@@ -314,7 +348,7 @@ class RowPartitioned:
         symmetric operators: own range + a halo) that is one batched point-to-point exchange with the
         owners, received straight into x; without, the all-gather of the x slices."""
         ranges = self._exchange_ranges(x.device)
-        if self.world == 1:
+        if self.world == 1 and not self.loopback:
             return x
         own_ranges = [(rl, rh) for rl, rh, _, _ in ranges]
         if any(xn == (0, -1) for xn in self._xneeds):  # somebody reads everything: all-gather (collective)
@@ -322,21 +356,29 @@ class RowPartitioned:
         if self._xplan is None or self._xplan[0] is not x:
             olo, ohi = self.own
             nlo, nhi = self._xneeds[self.rank]
-            sends, recvs = [], []
+            sends, recvs, staged = [], [], []
             for r, (rlo, rhi) in enumerate(own_ranges):
                 if r == self.rank:
                     continue
                 a, b = max(self._xneeds[r][0], olo), min(self._xneeds[r][1], ohi)  # what rank r reads of mine
                 if a <= b:
                     sends.append((r, x[a - 1:b]))
-                a, b = max(nlo, rlo), min(nhi, rhi)  # what I read of rank r's
+                a, b = max(nlo, rlo), min(nhi, min(rhi, x.shape[0]))  # what I read of rank r's
                 if a <= b:
                     recvs.append((r, x[a - 1:b]))
-            ops = [dist.P2POp(dist.isend, v, r, group=self.group) for r, v in sends]
-            ops += [dist.P2POp(dist.irecv, v, r, group=self.group) for r, v in recvs]
-            self._xplan = (x, ops)  # the descriptors point at fixed views of x: built once
+                    if self._phantom:
+                        # the phantom owner's half of the transfer: its entries leave from a buffer of their own, and
+                        # the place they are received into holds NaN until they have arrived
+                        staged.append((torch.empty_like(x[a - 1:b]), x[a - 1:b]))
+                        sends.append((r, staged[-1][0]))
+            ops = [dist.P2POp(dist.isend, v, self._peer(r), group=self.group) for r, v in sends]
+            ops += [dist.P2POp(dist.irecv, v, self._peer(r), group=self.group) for r, v in recvs]
+            self._xplan = (x, ops, staged)  # the descriptors point at fixed views of x: built once
         ops = self._xplan[1]
         if ops:
+            for src, view in self._xplan[2]:
+                src.copy_(view)
+                view.fill_(float("nan"))
             self._host_mediated_fence(x)
             for req in dist.batch_isend_irecv(ops):
                 req.wait()
@@ -365,10 +407,37 @@ class RowPartitioned:
                 a, b = max(rtlo, olo), min(rthi, ohi)  # rank r's contributions to my rows
                 if a <= b:
                     recvs.append((r, a, b, torch.empty(b - a + 1, dtype=w.dtype, device=w.device)))
-            ops = [dist.P2POp(dist.isend, v, r, group=self.group) for r, v in sends]
-            ops += [dist.P2POp(dist.irecv, buf, r, group=self.group) for r, _, _, buf in recvs]
+            if self._phantom:
+                # the phantom owners' half: they receive what this rank produced for their rows (and add it, below)
+                n = w.shape[0]
+                sends = [(r, v) for r, v in sends if v.shape[0] > 0]
+                for r, v in sends:
+                    a = int(v.storage_offset() - w.storage_offset()) + 1
+                    recvs.append((r, a, a + v.shape[0] - 1, torch.empty_like(v)))
+                assert all(b <= n for _, _, b, _ in recvs)
+            ops = [dist.P2POp(dist.isend, v, self._peer(r), group=self.group) for r, v in sends]
+            ops += [dist.P2POp(dist.irecv, buf, self._peer(r), group=self.group) for r, _, _, buf in recvs]
             self._plan = (ops, recvs)  # the descriptors point at fixed views / buffers: built once
         return self._plan
+
+    def _phantom_rows(self, y, beta):
+        """loopback=(lo, hi): the phantom neighbour's own part of a product -- it has no blocks, so its rows (everything
+        outside lo..hi) are just scaled by beta; what this rank produced for them is added from the receive buffers"""
+        lo, hi = self.own
+        n = y.shape[0]
+        if lo > 1:
+            self._combine(y, slice(0, lo - 1), 0, beta)
+        if hi < n:
+            self._combine(y, slice(hi, n), 0, beta)
+
+    def _exchange(self, ops, recvs, t):
+        """one batched point-to-point exchange; loopback: receive buffers hold NaN until their transfer has arrived"""
+        if self._phantom:
+            for _, _, _, buf in recvs:
+                buf.fill_(float("nan"))
+        self._host_mediated_fence(t)
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
 
     def _host_mediated_fence(self, t):
         """RCCL orders its transfers against the compute stream by itself.  `gloo` (the CPU rehearsal
@@ -420,6 +489,8 @@ class RowPartitioned:
                 lm(y, x, alpha, beta)  # rows outside `own` are left untouched by the handle
             elif ohi >= olo:
                 self._combine(y, slice(olo - 1, ohi), 0, beta)
+            if self._phantom:
+                self._phantom_rows(y, beta)
         else:
             w = self._workvec(y)
             if lm is not None:
@@ -428,15 +499,15 @@ class RowPartitioned:
                 w[olo - 1:ohi] = 0
             ops, recvs = self._halo_plan(w, ranges)
             if halo and ops:
-                self._host_mediated_fence(w)
-                for req in dist.batch_isend_irecv(ops):
-                    req.wait()
+                self._exchange(ops, recvs, w)
             if ohi >= olo:
                 own_slice = slice(olo - 1, ohi)
                 self._combine(y, own_slice, w[own_slice], beta)
+            if self._phantom:
+                self._phantom_rows(y, beta)
             for _, a, b, buf in recvs:
                 y[a - 1:b] += buf
-        if self.gather and self.world > 1:
+        if self.gather and (self.world > 1 or self.loopback):
             self._allgather(y, [(rl, rh) for rl, rh, _, _ in ranges])
         return y
 
@@ -496,15 +567,15 @@ class RowPartitioned:
                 M.mul(w, self.local, x, alpha, False)  # strong zero over the rows the boundary blocks touch
             ops, recvs = self._halo_plan(w, ranges)
             if halo and ops:
-                self._host_mediated_fence(w)
-                for req in dist.batch_isend_irecv(ops):
-                    req.wait()
+                self._exchange(ops, recvs, w)
         if cuda:
             main.wait_stream(side)
         if own_slice is not None and thi >= tlo:
             a, b = max(olo, tlo), min(ohi, thi)
             if a <= b:
                 y[a - 1:b] += w[a - 1:b]
+        if self._phantom:
+            self._phantom_rows(y, beta)
         for _, a, b, buf in recvs:
             y[a - 1:b] += buf
         return y
@@ -518,7 +589,7 @@ class RowPartitioned:
             lm(w, x, alpha, False)
         else:
             w.zero_()
-        if self.world == 1:
+        if self.world == 1 and not self.loopback:
             self._combine(y, slice(0, n), w, beta)
             return y
         if self.gather:
@@ -531,6 +602,8 @@ class RowPartitioned:
             self._pad = torch.zeros(chunk * self.world, dtype=y.dtype, device=y.device)
             self._rsout = torch.empty(chunk, dtype=y.dtype, device=y.device)
         self._pad[:n] = w
+        if self.loopback:
+            self._rsout.fill_(float("nan"))  # what ends up in y is what the collective delivered
         self._host_mediated_fence(w)
         dist.reduce_scatter_tensor(self._rsout, self._pad, group=self.group)
         lo, hi = self.out_range(n)
@@ -541,6 +614,8 @@ class RowPartitioned:
     def _allgather(self, y, own_ranges):
         # one all-gather of the (padded) own slices instead of one broadcast per rank: a single
         # collective whose per-peer messages (~n/N entries) use all xGMI links at once
+        if self.loopback:
+            own_ranges = own_ranges[:1]  # (the phantom roles hold their rows in this very y)
         maxlen = max(max(rh - rl + 1, 0) for rl, rh in own_ranges)
         if maxlen == 0:
             return y
@@ -551,9 +626,11 @@ class RowPartitioned:
         olo, ohi = self.own
         if ohi >= olo:
             self._sbuf[:ohi - olo + 1] = y[olo - 1:ohi]
+            if self.loopback:
+                y[olo - 1:ohi] = float("nan")  # comes back through the collective, or shows
         self._host_mediated_fence(y)
         dist.all_gather_into_tensor(self._gbuf, self._sbuf, group=self.group)
         for r, (rlo, rhi) in enumerate(own_ranges):
-            if r != self.rank and rhi >= rlo:
+            if (r != self.rank or self.loopback) and rhi >= rlo:
                 y[rlo - 1:rhi] = self._gbuf[r * maxlen:r * maxlen + (rhi - rlo + 1)]
         return y

@@ -121,10 +121,12 @@ typedef struct {
  * blocksparsematrices.jl_amd/_lib.py: BsmOptions, BsmPartInfo, BsmStats; tests/test_c_abi_from_c.py asserts the
  * same numbers against the ctypes mirror): a field added or moved here fails the build instead of drifting silently
  * away from a binding that cannot be compiled against this header. */
-#ifdef __cplusplus
+#if defined(__cplusplus) && __cplusplus >= 201103L
 #define BSM_LAYOUT_ASSERT(cond, msg) static_assert(cond, msg)
-#else
+#elif !defined(__cplusplus) && defined(__STDC_VERSION__) && __STDC_VERSION__ >= 201112L
 #define BSM_LAYOUT_ASSERT(cond, msg) _Static_assert(cond, msg)
+#else /* C99 / pre-C++11 consumers of the C ABI: the header still compiles, the checks are the library build's */
+#define BSM_LAYOUT_ASSERT(cond, msg) struct bsm_layout_assert_unused_
 #endif
 BSM_LAYOUT_ASSERT(sizeof(bsm_options) == 72, "bsm_options is 72 bytes");
 BSM_LAYOUT_ASSERT(offsetof(bsm_options, device) == 4 && offsetof(bsm_options, scheduler) == 8 &&

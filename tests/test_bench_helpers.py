@@ -79,6 +79,20 @@ def test_live_traffic_falls_back_when_the_profiler_is_absent(monkeypatch):
     assert d is None and "rocprofv3" in why
 
 
+def test_live_traffic_is_skipped_under_a_profiler(monkeypatch):
+    """bench.py started under rocprofv3 (its preload / control variables in the environment) must not start profiler
+    children of its own: they would inherit the preload and nest profilers"""
+    import shutil
+    import bench
+    monkeypatch.setattr(shutil, "which", lambda name: "/opt/rocm/bin/rocprofv3")
+    for k, v in (("ROCPROFILER_LIBRARY_CTOR", "1"), ("ROCP_TOOL_LIBRARIES", "x"), ("LD_PRELOAD", "/opt/rocm/lib/librocprofiler-sdk-tool.so")):
+        monkeypatch.setenv(k, v)
+        d, why = bench.live_traffic("panel_kernel<double, 8, true, false", 54553920)
+        assert d is None and "profiler" in why and k in why
+        monkeypatch.delenv(k)
+    assert bench.profiler_in_environment({"LD_PRELOAD": "/usr/lib/libjemalloc.so", "PATH": "/opt/rocm/bin"}) is None
+
+
 def test_fixture_coo_of_the_bench_is_the_reference_operator():
     """bench.fixture_coo (the parity reference of the BEM legs) against the test suite's own COO product, per element type"""
     import numpy as np

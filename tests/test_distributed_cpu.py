@@ -230,3 +230,19 @@ def test_partition_is_a_partition():
         local, own = D.split_vbcrs(cp, r, 3, axis=1)
         for cs, b in zip(local["colstart"], local["blocks"]):
             assert own[0] <= cs and cs + b.shape[1] - 1 <= own[1]
+
+
+def test_one_rank_loopback_rehearsal_logic():
+    """`RowPartitioned(loopback=...)`: every collective / point-to-point branch against the rank itself (tests/_loopback.py).
+    Here on the CPU over gloo (self send / recv replaced by an in-process copy: gloo has no pair to the own rank) with the
+    image interpreter as local product -- the logic of what `-m gpu` runs over RCCL on the one GPU of the test box."""
+    import _loopback
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_loopback.run, args=("gloo", _free_port(), q))
+    p.start()
+    status, res, extra = q.get(timeout=400)
+    p.join(timeout=120)
+    assert status == "ok", res
+    assert len(res) >= 20 and all(e < 1e-12 for _, e in res), res
+    assert p.exitcode == 0

@@ -175,3 +175,26 @@ def test_bench_launches_its_own_ranks_and_reports_parity():
     c4 = d["extra"]["c4"]
     assert c4["parity_relerr"] <= 1e-5 and c4["overlap"] is True
     assert "value_invalid" not in d
+
+
+def test_rccl_executes_every_collective_branch_on_one_rank():
+    """The `nccl` (= RCCL) backend really runs: world size 1 on cuda:0, in a fresh child process, with
+    `RowPartitioned(loopback=...)` driving (a) all_gather_into_tensor of y and of the x slices, (b) reduce_scatter_tensor /
+    all_reduce of the across-partition transpose, (c) the symmetric / index-list / VBCRS halo plans through grouped self
+    send / recv (`batch_isend_irecv` on device tensors), (d) `mul_overlapped` with the exchange on its side stream --
+    every result against the CPU oracle (tests/_loopback.py).  RCCL refuses two ranks on one device, so this is the only
+    form in which the one-GPU box can execute the branches the 8-GPU run depends on."""
+    import torch.multiprocessing as mp
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _loopback
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_loopback.run, args=("nccl", _free_port(), q))
+    p.start()
+    status, res, extra = q.get(timeout=500)
+    p.join(timeout=120)
+    assert status == "ok", res
+    assert len(res) >= 20 and all(e < 1e-12 for _, e in res), res
+    assert extra["backend"] == "nccl" and extra["librccl"], extra   # librccl.so is mapped into the process that ran them
+    assert extra["libbsmrocm"], extra
+    assert p.exitcode == 0

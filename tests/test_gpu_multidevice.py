@@ -333,6 +333,43 @@ def test_flag_and_event_ordering_of_the_fan_out(torch_cuda, bsm, oracle, monkeyp
     assert relerr(yd[1].cpu().numpy(), refs[0]) < 1e-12
 
 
+@pytest.mark.parametrize("mode", ["1", "0"])
+def test_a_fan_out_that_fails_half_way_leaves_a_usable_handle(torch_cuda, bsm, oracle, monkeypatch, mode):
+    """A fused fan-out that fails between its two phases (injected: bsm_debug_dist_fail_after) has consumed a sequence
+    number whose write packets were never issued.  The library releases every counter from the host, drains the devices
+    and forgets the ordering form (csrc/bsm_dist.cpp: dist_mul_fused): the failing call reports an error, and the
+    products after it neither hang on `flag >= seq` nor accumulate into a half-written work vector."""
+    import ctypes as C
+    from bsm_amd import _lib as L
+    torch = torch_cuda
+    monkeypatch.setenv("BSM_DIST_FLAGS", mode)
+    monkeypatch.setenv("BSM_DIST_ONE_STREAM", "0")  # parts on streams of their own: ordering packets between them
+    prob = bsm.synthetic.config5(n=30_000, lo=16, hi=96, halfband=3)
+    n = prob["size"][0]
+    A = bsm.synthetic.build(prob, devices=[0, 0, 0])
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal(n)
+    ref = oracle_mul(oracle, prob, N, x, np.zeros(n))
+    xd = torch.from_numpy(x).cuda()
+    yd = torch.full((n,), float("nan"), dtype=torch.float64, device="cuda")
+    bsm.mul(yd, A, xd)
+    bsm.mul(yd, A, xd)
+    hook = L.lib().bsm_debug_dist_fail_after
+    hook.argtypes, hook.restype = [C.c_int], None
+    hook(0)  # the next fused fan-out fails after its products have been issued
+    with pytest.raises(Exception):
+        bsm.mul(yd, A, xd)
+    for _ in range(3):  # must neither hang nor be wrong
+        yd.fill_(float("nan"))
+        bsm.mul(yd, A, xd)
+    torch.cuda.synchronize()
+    assert relerr(yd.cpu().numpy(), ref) < 1e-12
+    z = torch.from_numpy(x.copy()).cuda()
+    bsm.mul(z, A, yd, 0.5, -2.0)
+    torch.cuda.synchronize()
+    assert relerr(z.cpu().numpy(), oracle_mul(oracle, prob, N, ref, x.copy(), 0.5, -2.0, False)) < 1e-12
+
+
 @pytest.mark.parametrize("own_streams", ["0", "1"])
 def test_work_vectors_stay_zero_across_directions_batches_and_paths(torch_cuda, bsm, oracle, monkeypatch, own_streams):
     """The finish kernels write zeros behind what they read, so a product accumulates into its part's work vector
