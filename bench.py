@@ -340,7 +340,10 @@ def init_one_rank(backend, torch, dev_index):
         os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
         sk.close()
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    kw = {"device_id": torch.device("cuda", dev_index)} if backend == "nccl" else {}
+    kw = {}
+    if backend == "nccl":
+        from bsm_amd import distributed as D
+        kw = {"device_id": torch.device("cuda", dev_index), "pg_options": D.nccl_options()}
     dist.init_process_group(backend, rank=0, world_size=1, timeout=datetime.timedelta(minutes=5), **kw)
     return dist
 
@@ -409,7 +412,8 @@ def main():
         import datetime
         import torch.distributed as dist
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index),
+            from bsm_amd import distributed as D
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index), pg_options=D.nccl_options(),
                                     timeout=datetime.timedelta(minutes=5))
         else:
             dist.init_process_group(args.backend)
@@ -504,6 +508,23 @@ def run_partitioned(args, bsm, torch, dist, np, rank, world, barrier, reduce_sca
         return prob, own, False, "C4: VBCRS %dx%d, %d 128x128 fp32 blocks (16 per block row)" % (ngrid * 128, ngrid * 128, ngrid * 16), (lambda: prob)
 
     def run(share, steps, warmup, overlap):
+        # the rank's products run on a stream whose CU mask leaves one CU per XCD to RCCL's send / recv kernels (they
+        # find no free CU beside a launch that fills the chip and would finish when the launch does: DESIGN.md 5b)
+        reserve = int(os.environ.get("BSM_RESERVE_CUS", "8")) if (overlap and dist is not None and comm["name"] == "nccl") else 0
+        if reserve:
+            torch.cuda.synchronize()
+            prev_stream = torch.cuda.current_stream()
+            torch.cuda.set_stream(D.compute_stream(reserve=reserve))
+        try:
+            r = run_on_current_stream(share, steps, warmup, overlap)
+        finally:
+            if reserve:
+                torch.cuda.synchronize()
+                torch.cuda.set_stream(prev_stream)
+        r["reserved_cus"] = reserve
+        return r
+
+    def run_on_current_stream(share, steps, warmup, overlap):
         t0 = time.perf_counter()
         prob, own, sym, desc, verification = share()
         n = prob["size"][0]
@@ -675,7 +696,7 @@ def run_partitioned(args, bsm, torch, dist, np, rank, world, barrier, reduce_sca
                    "partition": "diagonal segments by stored bytes (bsm_partition_rows)",
                    "collectives": "ncclSend/ncclRecv (x halo, partial-y halo)" if comm["name"] == "nccl" else comm["name"],
                    "backend": backend, "ranks": ranks_seen, "devices": comm.get("devices"),
-                   "overlap": r5["overlap"],
+                   "overlap": r5["overlap"], "reserved_cus": r5.get("reserved_cus", 0),
                    "parity_relerr": r5["parity"], "parity_tol": tol,
                    "parity_check": "every rank: its y slice of the last timed step vs an exchange-free product of all blocks "
                                    "reaching its rows with the full x (max |dy| / max |y|, max over ranks)",

@@ -112,6 +112,11 @@ def lib():
         getattr(L, name).restype = C.c_int
     L.bsm_rowcolvals.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, _I64P, C.c_int, C.c_void_p]
     L.bsm_rowcolvals.restype = C.c_int
+    L.bsm_stream_create_reserved.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+    L.bsm_stream_destroy.argtypes = [C.c_void_p]
+    L.bsm_stream_create_reserved.restype = L.bsm_stream_destroy.restype = C.c_int
+    L.bsm_vec_add_segments.argtypes = [C.c_int, C.c_void_p, C.c_int32, _I64P, _PP, _I64P, C.c_void_p]
+    L.bsm_vec_add_segments.restype = C.c_int
     L.bsm_host_register.argtypes = [C.c_void_p, C.c_int64]
     L.bsm_host_unregister.argtypes = [C.c_void_p]
     L.bsm_host_register.restype = L.bsm_host_unregister.restype = C.c_int

@@ -887,6 +887,71 @@ extern "C" int bsm_host_unregister(void *ptr) {
     return BSM_OK;
 }
 
+// A compute stream that leaves CUs to the collective layer.  Measured with the one-rank RCCL loopback of the C5 step
+// (tools/loopback_trace.py, profiles/r05_loopback_*.txt): beside a product launch that fills every CU, RCCL's send /
+// recv kernel (one large workgroup per channel) found no CU with enough free registers and LDS at once -- 8 us alone,
+// 470 us beside the interior launch, i.e. the "overlapped" exchange finished when the product did.  With the product
+// on a stream whose CU mask leaves one CU per XCD free the exchange runs beside it (87-137 us, hidden) and the step
+// shrinks from 698 to 656 us at 1 % cost for the product.  Mask bit i is CU i / 8 of XCD i % 8 on this part: clearing
+// bits in groups of 8 keeps the XCDs equal -- masks that do not (4 CUs of one XCD: 917 instead of 615 us) slow every
+// launch, which is why `reserved_cus` is rounded up to a multiple of 8.
+extern "C" int bsm_stream_create_reserved(int device, int reserved_cus, void **stream) {
+    if (!stream || reserved_cus < 0) return fail(BSM_ERR_INVALID, "bad argument");
+    DeviceGuard g;
+    hipError_t e = g.enter(device);
+    if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
+    int ncu = 0;
+    e = hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device);
+    if (e != hipSuccess) return hip_fail(e, "hipDeviceGetAttribute");
+    const int r = std::min((reserved_cus + 7) / 8 * 8, std::max(ncu - 8, 0));
+    hipStream_t st = nullptr;
+    if (r == 0) {
+        e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+    } else {
+        std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);
+        for (int i = r; i < ncu; i++) mask[(size_t)i / 32] |= 1u << (i % 32);
+        e = hipExtStreamCreateWithCUMask(&st, (uint32_t)mask.size(), mask.data());
+    }
+    if (e != hipSuccess) return hip_fail(e, "stream creation");
+    *stream = (void *)st;
+    return BSM_OK;
+}
+
+extern "C" int bsm_stream_destroy(void *stream) {
+    if (!stream) return BSM_OK;
+    hipError_t e = hipStreamDestroy((hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail(e, "hipStreamDestroy");
+    return BSM_OK;
+}
+
+extern "C" int bsm_vec_add_segments(int dtype, void *y, int32_t nseg, const int64_t *offset, const void *const *src,
+                                    const int64_t *len, void *stream) {
+    if (dtype < 0 || dtype > 3) return fail(BSM_ERR_INVALID, "bad dtype");
+    if (nseg < 0 || (nseg > 0 && (!y || !offset || !src || !len))) return fail(BSM_ERR_INVALID, "null argument");
+    // disjoint segments only: the launch adds without atomics
+    for (int32_t a = 0; a < nseg; a++) {
+        if (offset[a] < 0 || len[a] < 0 || (len[a] > 0 && !src[a])) return fail(BSM_ERR_INVALID, "bad segment");
+        for (int32_t b = a + 1; b < nseg; b++)
+            if (len[a] > 0 && len[b] > 0 && offset[a] < offset[b] + len[b] && offset[b] < offset[a] + len[a])
+                return fail(BSM_ERR_INVALID, "segments overlap");
+    }
+    for (int32_t s0 = 0; s0 < nseg; s0 += kMaxVecPieces) {
+        VecPieces pc;
+        int np = 0;
+        for (int32_t c = s0; c < nseg && np < kMaxVecPieces; c++) {
+            if (len[c] == 0) continue;
+            pc.base[np] = src[c];
+            pc.lo[np] = offset[c];
+            pc.hi[np] = offset[c] + len[c];
+            pc.strided[np] = 0;
+            np++;
+        }
+        hipError_t e = launch_vec_add_segments(dtype, y, pc, np, (hipStream_t)stream);
+        if (e != hipSuccess) return hip_fail(e, "segment add launch");
+    }
+    return BSM_OK;
+}
+
 extern "C" int bsm_part_info(bsm_matrix_t A, int32_t part, bsm_part_info_t *out) {
     if (!A || !out) return fail(BSM_ERR_INVALID, "null argument");
     if (!A->dist) return fail(BSM_ERR_INVALID, "not a multi-device handle");

@@ -63,6 +63,9 @@ hipError_t launch_vec_finish(int dtype, void *y, long long ldy, void *w, long lo
                              long long lo, long long hi, const void *beta, int strong_zero, int accumulate_only, int rezero, int K,
                              hipStream_t stream);
 
+// y[lo_c + i] += base_c[i] for npieces <= kMaxVecPieces disjoint segments [lo_c, hi_c) of y, one launch
+hipError_t launch_vec_add_segments(int dtype, void *y, const VecPieces &pc, int npieces, hipStream_t stream);
+
 // nrhs right-hand sides: X (ldx) and Y (ldy) column-major; A is streamed once per batch of <= 8.
 hipError_t launch_mul_multi(const DeviceImage &img, bool opT, bool conj, long long nrhs, const void *x,
                             long long ldx, void *y, long long ldy, const void *alpha, const void *beta,

@@ -2228,6 +2228,38 @@ hipError_t launch_vec_finish(int dtype, void *y, long long ldy, void *w, long lo
     return hipErrorInvalidValue;
 }
 
+// y[lo_c + i] += src_c[i], i < hi_c - lo_c, for up to kMaxVecPieces DISJOINT segments in one launch (blockIdx.y = segment):
+// the delivery of a row-partitioned product in the process-per-GPU layer (distributed.py: own rows of the boundary
+// blocks' sums + every received partial-y segment) -- one launch behind the join instead of one per segment.
+// Here pc.base[c] is the segment's own first element (not a virtual base), lo / hi its range in y.
+template <typename T>
+__global__ void __launch_bounds__(256) vec_add_segments_kernel(T *__restrict__ y, VecPieces pc) {
+    const int c = blockIdx.y;
+    const T *__restrict__ src = reinterpret_cast<const T *>(pc.base[c]);
+    const long long lo = pc.lo[c], n = pc.hi[c] - lo;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        y[lo + i] = add(y[lo + i], src[i]);
+}
+template <typename T>
+static hipError_t add_segments_typed(void *y, const VecPieces &pc, int npieces, hipStream_t stream) {
+    long long longest = 0;
+    for (int c = 0; c < npieces; ++c) longest = longest > pc.hi[c] - pc.lo[c] ? longest : pc.hi[c] - pc.lo[c];
+    if (npieces <= 0 || longest <= 0) return hipSuccess;
+    long long nblk = (longest + 255) / 256;
+    if (nblk > 1024) nblk = 1024;
+    hipLaunchKernelGGL((vec_add_segments_kernel<T>), dim3((unsigned)nblk, (unsigned)npieces), dim3(256), 0, stream, (T *)y, pc);
+    return hipGetLastError();
+}
+hipError_t launch_vec_add_segments(int dtype, void *y, const VecPieces &pc, int npieces, hipStream_t stream) {
+    switch (dtype) {
+        case 0: return add_segments_typed<float>(y, pc, npieces, stream);
+        case 1: return add_segments_typed<double>(y, pc, npieces, stream);
+        case 2: return add_segments_typed<c64>(y, pc, npieces, stream);
+        case 3: return add_segments_typed<c128>(y, pc, npieces, stream);
+    }
+    return hipErrorInvalidValue;
+}
+
 template <typename T>
 static hipError_t vec_launch(int which, void *dst, const void *src, long long n, const void *beta_p, hipStream_t stream) {
     if (n <= 0) return hipSuccess;

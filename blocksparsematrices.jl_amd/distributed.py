@@ -40,6 +40,44 @@ except Exception:  # pragma: no cover
 from . import matrices as M
 
 
+def nccl_options():
+    """`pg_options` for `init_process_group("nccl", ...)`: the collective layer's internal stream as a HIGH-PRIORITY
+    stream.  The runtime deals ordinary streams onto a handful of hardware queues per device; in the kernel trace of the
+    RCCL loopback step (profiles/r05_loopback_timeline.txt) RCCL's stream shared the main stream's queue, so the
+    partial-y send / recv kernel waited for the whole interior launch it was meant to run beside.  Priority streams get
+    queues of their own.  None when this torch build has no such option."""
+    try:
+        opts = dist.ProcessGroupNCCL.Options()
+        opts.is_high_priority_stream = True
+        return opts
+    except Exception:  # pragma: no cover
+        return None
+
+
+_compute_streams = {}
+
+
+def compute_stream(device=None, reserve=None):
+    """The stream a rank's products should run on when `mul_overlapped` exchanges beside them: a torch ExternalStream over
+    `bsm_stream_create_reserved` whose CU mask leaves `reserve` CUs (default: BSM_RESERVE_CUS or 8 = one per XCD) to RCCL's
+    kernels.  Without it the send / recv kernels find no free CU beside the interior launch and the exchange ends when
+    the launch does (profiles/r05_loopback_*.txt: C5 share of one rank of eight, step 698 -> 656 us).  Use as
+    `with torch.cuda.stream(D.compute_stream()): ...` around the solver loop.  One stream per (device, reserve), kept for
+    the life of the process."""
+    import ctypes as C
+    import os
+    from . import _lib as L
+    dev = torch.cuda.current_device() if device is None else int(device)
+    if reserve is None:
+        reserve = int(os.environ.get("BSM_RESERVE_CUS", "8"))
+    key = (dev, int(reserve))
+    if key not in _compute_streams:
+        st = C.c_void_p()
+        L.check(L.lib().bsm_stream_create_reserved(dev, int(reserve), C.byref(st)))
+        _compute_streams[key] = torch.cuda.ExternalStream(st.value, device=torch.device("cuda", dev))
+    return _compute_streams[key]
+
+
 def balanced_cuts(weights, nparts):
     """Cut len(weights) consecutive units into nparts contiguous ranges of ~equal total weight.
     Returns nparts+1 boundaries (unit indices).  (Same rule as bsm_partition_rows.)"""
@@ -307,6 +345,7 @@ class RowPartitioned:
         self._work = None
         self._gbuf = self._sbuf = self._pad = self._rsout = None
         self._ops = {}
+        self._segadd = None
 
     def out_range(self, n, rank=None):
         """Output rows (1-based, inclusive) rank `rank` holds after a product ACROSS the partition."""
@@ -543,7 +582,11 @@ class RowPartitioned:
         if cuda:
             main = torch.cuda.current_stream(y.device)
             if self._side is None:
-                self._side = torch.cuda.Stream(device=y.device)
+                # a HIGH-PRIORITY stream: the runtime deals ordinary streams onto a handful of hardware queues per device
+                # and the side stream landed on the main stream's own queue (kernel trace of the RCCL loopback step,
+                # profiles/r05_loopback_timeline.txt: the interior launch sat behind the side stream's wait for the x
+                # halo, nothing overlapped); priority streams get queues of their own
+                self._side = torch.cuda.Stream(device=y.device, priority=-1)
             side = self._side
             side.wait_stream(main)
             side_ctx = torch.cuda.stream(side)
@@ -570,15 +613,34 @@ class RowPartitioned:
                 self._exchange(ops, recvs, w)
         if cuda:
             main.wait_stream(side)
+        if self._phantom:
+            self._phantom_rows(y, beta)
+        # y[own] += the boundary blocks' sums for own rows + every received segment: ONE multi-tensor launch (each separate
+        # add is a ~5 us launch on the critical path behind the join -- with 8 ranks the interior launch is ~0.57 ms)
+        dst, src = [], []
         if own_slice is not None and thi >= tlo:
             a, b = max(olo, tlo), min(ohi, thi)
             if a <= b:
-                y[a - 1:b] += w[a - 1:b]
-        if self._phantom:
-            self._phantom_rows(y, beta)
+                dst.append(y[a - 1:b])
+                src.append(w[a - 1:b])
         for _, a, b, buf in recvs:
-            y[a - 1:b] += buf
+            dst.append(y[a - 1:b])
+            src.append(buf)
+        if len(dst) == 1 or not cuda or any(self._overlap(p, q) for i, p in enumerate(dst) for q in dst[i + 1:]):
+            for d_, s_ in zip(dst, src):  # (two segments for the same rows must not race inside one launch)
+                d_ += s_
+        elif dst:
+            # (torch._foreach_add_ was tried first: its multi-tensor kernel took 38 us for three short segments)
+            if self._segadd is None or not self._segadd.matches(y, dst, src):
+                self._segadd = M.SegmentAdd(y, dst, src)
+            self._segadd()
         return y
+
+    @staticmethod
+    def _overlap(p, q):
+        a0, a1 = p.storage_offset(), p.storage_offset() + p.shape[0]
+        b0, b1 = q.storage_offset(), q.storage_offset() + q.shape[0]
+        return a0 < b1 and b0 < a1
 
     def _mul_across(self, y, x, alpha, beta, lm):
         """Every rank holds a full-length partial result: reduce-scatter onto equal chunks (or one

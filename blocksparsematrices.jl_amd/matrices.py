@@ -772,6 +772,41 @@ class MulPlan:
             L.check(rc)
 
 
+class SegmentAdd:
+    """Pre-marshalled `y[a_s : a_s + len_s] += src_s` over DISJOINT segments of one device vector, ONE launch on the
+    current torch stream (bsm_vec_add_segments): the delivery step of distributed.RowPartitioned -- the own rows of the
+    boundary blocks' sums + every received partial-y segment.  dsts: views of y, srcs: tensors of the same lengths."""
+
+    def __init__(self, y, dsts, srcs):
+        dt = {torch.float32: 0, torch.float64: 1, torch.complex64: 2, torch.complex128: 3}[y.dtype]
+        es = y.element_size()
+        n = len(dsts)
+        for d, s_ in zip(dsts, srcs):
+            if d.dtype != y.dtype or s_.dtype != y.dtype or d.shape != s_.shape or d.dim() != 1 or \
+                    not d.is_contiguous() or not s_.is_contiguous() or d.device != y.device or s_.device != y.device:
+                raise ValueError("segments must be contiguous 1-D tensors of y's type on y's device")
+        self._off = (C.c_int64 * n)(*[(d.data_ptr() - y.data_ptr()) // es for d in dsts])
+        self._len = (C.c_int64 * n)(*[d.shape[0] for d in dsts])
+        self._src = (C.c_void_p * n)(*[s_.data_ptr() for s_ in srcs])
+        if any(o < 0 or o + l_ > y.numel() for o, l_ in zip(self._off, self._len)):
+            raise ValueError("a segment lies outside y")
+        self._keep = (y, dsts, srcs)
+        self._fn = L.lib().bsm_vec_add_segments
+        self._args = [C.c_int(dt), C.c_void_p(y.data_ptr()), C.c_int32(n), self._off, self._src, self._len]
+        self._dev = y.device
+
+    def matches(self, y, dsts, srcs):
+        ky, kd, ks = self._keep
+        return ky.data_ptr() == y.data_ptr() and len(kd) == len(dsts) and \
+            all(a.data_ptr() == b.data_ptr() and a.shape == b.shape for a, b in zip(kd, dsts)) and \
+            all(a.data_ptr() == b.data_ptr() for a, b in zip(ks, srcs))
+
+    def __call__(self):
+        rc = self._fn(*self._args, C.c_void_p(torch.cuda.current_stream(self._dev).cuda_stream))
+        if rc:
+            L.check(rc)
+
+
 def _apply(A, x):
     """A * x: allocates y like LinearMaps does (similar(x, ...), uninitialised) then mul!."""
     m, _ = size(A)

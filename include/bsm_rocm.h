@@ -280,6 +280,24 @@ int bsm_mul(bsm_matrix_t A, int op, const void *x, void *y, const void *alpha,
 int bsm_mul_parts(bsm_matrix_t A, int op, const void *const *x_parts, void *const *y_parts, const void *alpha,
                   const void *beta, int beta_strong_zero, void *const *streams);
 
+/* A HIP stream for the products of a rank that exchanges vector segments with its neighbours WHILE it multiplies (one
+ * process per GPU, RCCL): its CU mask leaves `reserved_cus` compute units -- rounded up to a multiple of 8, one per XCD
+ * -- to the collective layer's kernels.  Beside a product launch that fills every CU those kernels otherwise wait for
+ * the launch to drain (measured: DESIGN.md section 5b).  0 = an ordinary non-blocking stream.  Pass the stream to
+ * bsm_mul / bsm_mul_multi like any other (`stream` argument); the reference has no counterpart (shared-memory tasks,
+ * src/symmetricblockmatrix.jl:395-432). */
+int bsm_stream_create_reserved(int device, int reserved_cus, void **stream);
+int bsm_stream_destroy(void *stream);
+
+/* y[offset[s] + i] += src[s][i], i < len[s], for nseg DISJOINT segments of a device vector y, in ONE launch on
+ * `stream` (dtype as in the *_create calls; offsets 0-based, in elements).  The delivery step of a row-partitioned
+ * product in a process-per-GPU layer above this ABI (blocksparsematrices.jl_amd/distributed.py: the own rows of the
+ * boundary blocks' sums + every partial-y segment received from a neighbour -- the y segments other tasks of the
+ * reference's fan-out would have added in shared memory, src/symmetricblockmatrix.jl:407-418): one launch behind
+ * the join of the exchange instead of one per segment.  Overlapping segments are refused (BSM_ERR_INVALID). */
+int bsm_vec_add_segments(int dtype, void *y, int32_t nseg, const int64_t *offset, const void *const *src,
+                         const int64_t *len, void *stream);
+
 /* Page-locks a HOST vector the caller keeps using as x or y of BSM_MEM_HOST products (a Julia
  * Vector{T} that lives through a solver loop): bsm_mul then moves it by DMA straight from / to the
  * caller's memory instead of copying it through the library's pinned mirrors (C2-sized product:

@@ -42,7 +42,9 @@ def run(backend, port, q):
         gpu = backend == "nccl"
         if gpu:
             torch.cuda.set_device(0)
-            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+            sys.path.insert(0, ROOT)
+            from bsm_amd import distributed as D0
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0), pg_options=D0.nccl_options())
         else:
             dist.init_process_group("gloo", rank=0, world_size=1)
 
@@ -169,11 +171,14 @@ def run(backend, port, q):
                 P = D.RowPartitioned(Ab, own, bt, gather=False, symmetric=issym, xneed=(bx if xmode == "halo" else None),
                                      interior=Ai, loopback=own)
                 idle = (lambda yy, xx, a, b: P._combine(yy, slice(own[0] - 1, own[1]), 0, b))
+                import contextlib
                 for alpha, beta in combos:
-                    for rep in range(3):
-                        y = torch.from_numpy(y0.copy()).to(dev)
-                        P.mul_overlapped(y, x, alpha, beta, local_mul=image_mul(Ab, bt),
-                                         interior_mul=(image_mul(Ai, own) if Ai is not None else idle) if not gpu else None)
+                    # GPU: on the compute stream whose CU mask leaves one CU per XCD to RCCL (distributed.compute_stream)
+                    with (torch.cuda.stream(D.compute_stream()) if gpu else contextlib.nullcontext()):
+                        for rep in range(3):
+                            y = torch.from_numpy(y0.copy()).to(dev)
+                            P.mul_overlapped(y, x, alpha, beta, local_mul=image_mul(Ab, bt),
+                                             interior_mul=(image_mul(Ai, own) if Ai is not None else idle) if not gpu else None)
                     sync()
                     out.append(("%s overlapped step, x %s %s" % (kind, xmode, beta), relerr(y.cpu().numpy(), ref_of(prob, N, y0, alpha, beta))))
                 assert torch.equal(x.cpu(), torch.from_numpy(prob["x"]))

@@ -198,3 +198,45 @@ def test_rccl_executes_every_collective_branch_on_one_rank():
     assert extra["backend"] == "nccl" and extra["librccl"], extra   # librccl.so is mapped into the process that ran them
     assert extra["libbsmrocm"], extra
     assert p.exitcode == 0
+
+
+def test_segment_add_and_reserved_cu_stream():
+    """The two C-ABI helpers of the process-per-GPU layer: bsm_vec_add_segments (delivery of the partial-y segments in one
+    launch; overlapping segments refused) and bsm_stream_create_reserved (a compute stream whose CU mask leaves CUs to
+    RCCL's kernels) -- a product on that stream against the oracle."""
+    import torch
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import bsm_amd as bsm
+    from bsm_amd import distributed as D
+    from bsm_amd import matrices as M
+    from _common import N, oracle_mul, relerr
+    from oracle import load_oracle
+    for dt in (torch.float64, torch.float32, torch.complex128, torch.complex64):
+        g = torch.Generator(device="cpu").manual_seed(3)
+        y = torch.randn(1000, dtype=dt, generator=g).cuda()
+        ref = y.clone()
+        srcs = [torch.randn(n, dtype=dt, generator=g).cuda() for n in (17, 300, 1, 64)]
+        offs = (0, 100, 500, 936)
+        dsts = [y[o:o + s_.shape[0]] for o, s_ in zip(offs, srcs)]
+        add = M.SegmentAdd(y, dsts, srcs)
+        add()
+        add()
+        for o, s_ in zip(offs, srcs):
+            ref[o:o + s_.shape[0]] += 2 * s_
+        torch.cuda.synchronize()
+        assert torch.allclose(y, ref, rtol=1e-6, atol=0)
+    with pytest.raises(Exception):
+        M.SegmentAdd(y, [y[0:10], y[5:15]], [srcs[1][:10], srcs[1][:10]])()
+    st = D.compute_stream()
+    assert st is D.compute_stream()  # cached
+    prob = bsm.synthetic.config3(nseg=40)
+    A = bsm.synthetic.build(prob)
+    x = torch.from_numpy(prob["x"]).cuda()
+    yd = torch.full((prob["size"][0],), float("nan"), dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    with torch.cuda.stream(st):
+        for _ in range(3):
+            bsm.mul(yd, A, x)
+    st.synchronize()
+    assert relerr(yd.cpu().numpy(), oracle_mul(load_oracle(), prob, N, prob["x"], np.zeros(prob["size"][0]))) < 1e-12
