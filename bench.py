@@ -44,6 +44,7 @@ HBM_PEAK_GBPS = 8000.0  # MI355X spec (MI355X_MICROARCH.md); measured-copy ceili
 PMC_FILE = os.path.join(ROOT, "profiles", "r04_c2_pmc.json")  # written by tools/pmc_summary.py, stamped with the build id
 MFMA_FILE = os.path.join(ROOT, "profiles", "r04_c4_mfma.json")
 C5N1_FILE = os.path.join(ROOT, "profiles", "r04_c5_n1.json")  # the N > 1 workload on ONE GPU (tools/profile_round.sh)
+SETUP_STEPS = 30    # N > 1 / --workload c5: untimed steps of a freshly built operator before the W warm-up steps (config.setup_steps)
 MIN_TIMED_S = 5e-3  # a timed region shorter than this is repeated (config.replays) so that host synchronisation stays below 1 %
 
 
@@ -592,6 +593,11 @@ def run_partitioned(args, bsm, torch, dist, np, rank, world, barrier, reduce_sca
                 P.group = comm["group"]
                 P._plan = P._xplan = P._ranges = None
 
+        # set-up: a freshly built operator runs its first tens of launches 5-8 % slower (clocks, TLBs: DESIGN.md section 4;
+        # per-step times of the first 30 steps in profiles/r05_loopback_first_steps.txt) -- SETUP_STEPS untimed steps of the
+        # same kind first, as the single-GPU legs do with 30 launches; then the W warm-up steps and EXACTLY K timed ones
+        for _ in range(SETUP_STEPS):
+            step()
         for _ in range(warmup):
             step()
         barrier()
@@ -696,7 +702,7 @@ def run_partitioned(args, bsm, torch, dist, np, rank, world, barrier, reduce_sca
                    "partition": "diagonal segments by stored bytes (bsm_partition_rows)",
                    "collectives": "ncclSend/ncclRecv (x halo, partial-y halo)" if comm["name"] == "nccl" else comm["name"],
                    "backend": backend, "ranks": ranks_seen, "devices": comm.get("devices"),
-                   "overlap": r5["overlap"], "reserved_cus": r5.get("reserved_cus", 0),
+                   "overlap": r5["overlap"], "reserved_cus": r5.get("reserved_cus", 0), "setup_steps": SETUP_STEPS,
                    "parity_relerr": r5["parity"], "parity_tol": tol,
                    "parity_check": "every rank: its y slice of the last timed step vs an exchange-free product of all blocks "
                                    "reaching its rows with the full x (max |dy| / max |y|, max over ranks)",

@@ -47,9 +47,17 @@ if reserve:
     torch.cuda.synchronize()
     torch.cuda.set_stream(ext)
     print("compute stream with %d of %d CUs, reserved bits stride %d" % (ncu - reserve, ncu, stride), flush=True)
-for _ in range(10):
-    P.mul_overlapped(y, x)
+# per-step device time of the FIRST steps (events between the steps, no host sync): how many steps until steady state
+evs = [torch.cuda.Event(enable_timing=True) for _ in range(31)]
 torch.cuda.synchronize()
+t0 = time.perf_counter()
+for i in range(30):
+    evs[i].record()
+    P.mul_overlapped(y, x)
+evs[30].record()
+torch.cuda.synchronize()
+print("first 30 steps: wall %.1f us per step; device us per step: %s" % ((time.perf_counter() - t0) / 30 * 1e6,
+      " ".join("%.0f" % (evs[i].elapsed_time(evs[i + 1]) * 1e3) for i in range(30))), flush=True)
 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 reps = 50
 t0 = time.perf_counter()
