@@ -44,6 +44,7 @@ HBM_PEAK_GBPS = 8000.0  # MI355X spec (MI355X_MICROARCH.md); measured-copy ceili
 PMC_FILE = os.path.join(ROOT, "profiles", "r04_c2_pmc.json")  # written by tools/pmc_summary.py, stamped with the build id
 MFMA_FILE = os.path.join(ROOT, "profiles", "r04_c4_mfma.json")
 C5N1_FILE = os.path.join(ROOT, "profiles", "r04_c5_n1.json")  # the N > 1 workload on ONE GPU (tools/profile_round.sh)
+ORACLE_SAMPLES = 48  # sampled block rows per rank of the full-size oracle check of the partitioned workloads
 SETUP_STEPS = 30    # N > 1 / --workload c5: untimed steps of a freshly built operator before the W warm-up steps (config.setup_steps)
 MIN_TIMED_S = 5e-3  # a timed region shorter than this is repeated (config.replays) so that host synchronisation stays below 1 %
 
@@ -373,6 +374,7 @@ def main():
                     "the N > 1 step for real -- the rank owns all but the first and last 8 diagonal segments, a phantom neighbour (this "
                     "same process) the rest, so the x halo and the partial-y halo travel through grouped self send / recv beside the "
                     "interior launch (distributed.RowPartitioned(loopback=...)): the only way a one-GPU box executes RCCL")
+    ap.add_argument("--no-oracle-check", action="store_true", help="--workload c5 / N > 1: skip the sampled-row oracle check of the last timed step")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.pmc_child:
@@ -484,7 +486,8 @@ def run_partitioned(args, bsm, torch, dist, np, rank, world, barrier, reduce_sca
             # neighbour (this process) the rows of those -- their blocks are this rank's boundary blocks
             edge = min(8, max(nseg // 4, 1))
             lb_own = (int(start[edge]) + 1, int(start[nseg - edge]))
-            return prob, lb_own, True, "C5: SymmetricBlockMatrix %dx%d, segments U{16..256}, off-diagonal (I,J) J=I-1..I-4, fp64" % (n, n), (lambda: prob)
+            return prob, lb_own, True, "C5: SymmetricBlockMatrix %dx%d, segments U{16..256}, off-diagonal (I,J) J=I-1..I-4, fp64" % (n, n), (lambda: prob), \
+                (lambda: S.config5_sample(S.sample_ids(ORACLE_SAMPLES, nseg), n=n)[:2])
 
         def verification():
             # everything that contributes to this rank's rows, built WITHOUT any exchange: the rank's own
@@ -496,7 +499,9 @@ def run_partitioned(args, bsm, torch, dist, np, rank, world, barrier, reduce_sca
                 for k in ("diagonals", "diagonalindices", "offdiagonals", "rowindices", "colindices"):
                     ver[k] = list(prob[k]) + list(ext[k])
             return ver
-        return prob, own[rank], True, "C5: SymmetricBlockMatrix %dx%d, segments U{16..256}, off-diagonal (I,J) J=I-1..I-4, fp64" % (n, n), verification
+        # the rank's rows against the ORACLE on sampled diagonal segments (blocks regenerated on the host, bit-identical)
+        sampler = (lambda: S.config5_sample(S.sample_ids(ORACLE_SAMPLES, nseg, lo=lo, hi=hi), n=n)[:2]) if hi > lo else None
+        return prob, own[rank], True, "C5: SymmetricBlockMatrix %dx%d, segments U{16..256}, off-diagonal (I,J) J=I-1..I-4, fp64" % (n, n), verification, sampler
 
     def c4_share():
         ngrid = max(world, int(15625 * args.scale))
@@ -506,7 +511,8 @@ def run_partitioned(args, bsm, torch, dist, np, rank, world, barrier, reduce_sca
         if loopback:
             edge = min(8, max(ngrid // 4, 1))
             own = (edge * 128 + 1, (ngrid - edge) * 128)
-        return prob, own, False, "C4: VBCRS %dx%d, %d 128x128 fp32 blocks (16 per block row)" % (ngrid * 128, ngrid * 128, ngrid * 16), (lambda: prob)
+        sampler = (lambda: S.config4_sample(S.sample_ids(ORACLE_SAMPLES, ngrid, lo=lo, hi=hi), ngrid=ngrid)[:2]) if hi > lo else None
+        return prob, own, False, "C4: VBCRS %dx%d, %d 128x128 fp32 blocks (16 per block row)" % (ngrid * 128, ngrid * 128, ngrid * 16), (lambda: prob), sampler
 
     def run(share, steps, warmup, overlap):
         # the rank's products run on a stream whose CU mask leaves one CU per XCD to RCCL's send / recv kernels (they
@@ -527,7 +533,7 @@ def run_partitioned(args, bsm, torch, dist, np, rank, world, barrier, reduce_sca
 
     def run_on_current_stream(share, steps, warmup, overlap):
         t0 = time.perf_counter()
-        prob, own, sym, desc, verification = share()
+        prob, own, sym, desc, verification, sampler = share()
         n = prob["size"][0]
         x = prob["x"]
         es = x.element_size()
@@ -639,7 +645,38 @@ def run_partitioned(args, bsm, torch, dist, np, rank, world, barrier, reduce_sca
             rel = float("inf")
         del Aver, yv
         pmax, _ = reduce_scalars(rel, 0)
-        return dict(desc=desc, elapsed=elapsed, total_bytes=total, kdur=kmax, rank_alg=rank_bytes + 2 * n * es // world,
+        # ... and against the CPU ORACLE (the checker, after every timed figure is final): the operator is generated in HBM
+        # bit-identically to the numpy streams, so the host regenerates only the blocks reaching ORACLE_SAMPLES sampled block
+        # rows of this rank, runs the reference loop restatement on that sub-problem with the full x, and this rank's y of
+        # the last timed step is compared on those rows (max |dy| / max |y| over them; max over ranks)
+        osamp = float("nan")
+        if sampler is not None and not getattr(args, "no_oracle_check", False):
+            from oracle import load_oracle
+            orc = None
+            if rank == 0:  # rank 0 first: builds oracle/libbsm_oracle.so if the tree has none
+                try:
+                    orc = load_oracle()
+                except Exception as e:  # pragma: no cover
+                    print("[bench] the oracle could not be loaded: %r" % (e,), file=sys.stderr, flush=True)
+            if dist is not None and world > 1:
+                dist.barrier(group=comm["fallback"] if comm["fallback"] is not None else comm["group"])
+            try:
+                if orc is None:
+                    orc = load_oracle(build=False)
+                sys.path.insert(0, os.path.join(ROOT, "tests"))
+                from _common import N as OPN, oracle_mul, sampled_relerr
+                sub, ranges = sampler()
+                yref = oracle_mul(orc, sub, OPN, sub["x"], np.zeros(n, sub["x"].dtype))
+                yfull = np.full(n, np.nan, sub["x"].dtype)
+                yfull[chk[0] - 1:chk[1]] = y_step.cpu().numpy()
+                osamp = sampled_relerr(yfull, yref, ranges)
+                del yfull, yref, sub
+            except Exception as e:  # pragma: no cover
+                print("[bench] sampled oracle check failed to run: %r" % (e,), file=sys.stderr, flush=True)
+            osamp_max, _ = reduce_scalars(osamp if osamp == osamp else float("inf"), 0)
+        else:
+            osamp_max = None
+        return dict(oracle_sampled=osamp_max, desc=desc, elapsed=elapsed, total_bytes=total, kdur=kmax, rank_alg=rank_bytes + 2 * n * es // world,
                     setup_s=t_setup, parity=pmax, n=n, own=own, overlap=overlap,
                     exchange_us=(elapsed / steps - kmax) * 1e6)
 
@@ -670,6 +707,7 @@ def run_partitioned(args, bsm, torch, dist, np, rank, world, barrier, reduce_sca
                        "local_kernel_us_max": round(r4["kdur"] * 1e6, 1),
                        "exchange_us": round(r4["exchange_us"], 1),
                        "parity_relerr": r4["parity"], "parity_tol": 1e-5, "overlap": r4["overlap"],
+                       "parity_vs_oracle_sampled": r4["oracle_sampled"],
                        "frac_of_hbm_peak": round(r4["total_bytes"] * steps / r4["elapsed"] / 1e9 / (HBM_PEAK_GBPS * world), 4),
                        "setup_s": round(r4["setup_s"], 2)}
       except Exception as e:  # pragma: no cover
@@ -706,6 +744,10 @@ def run_partitioned(args, bsm, torch, dist, np, rank, world, barrier, reduce_sca
                    "parity_relerr": r5["parity"], "parity_tol": tol,
                    "parity_check": "every rank: its y slice of the last timed step vs an exchange-free product of all blocks "
                                    "reaching its rows with the full x (max |dy| / max |y|, max over ranks)",
+                   "parity_vs_oracle_sampled": r5["oracle_sampled"],
+                   "parity_vs_oracle_sampled_check": "every rank: its y of the last timed step vs oracle/bsm_oracle.c (orc_sym_mul, the reference's "
+                                                     "three sweeps) on %d sampled diagonal segments of its rows -- the blocks reaching them regenerated "
+                                                     "on the host from the same SplitMix64 streams (synthetic.config5_sample); max over ranks" % ORACLE_SAMPLES,
                    "exchange_us": round(r5["exchange_us"], 1),
                    "local_kernel_us_max": round(r5["kdur"] * 1e6, 1),
                    "frac_of_hbm_peak": round(value / (HBM_PEAK_GBPS * world), 4)},
@@ -742,6 +784,9 @@ def run_partitioned(args, bsm, torch, dist, np, rank, world, barrier, reduce_sca
         if "c4" in extra and "note" in locals().get("r4", {}):
             extra["c4"]["note"] = r4["note"]
         out["extra"] = extra
+    if r5["oracle_sampled"] is not None and not (r5["oracle_sampled"] <= tol):
+        out["config"]["oracle_check_failed"] = True
+        out["value_invalid"] = True
     if not (r5["parity"] <= tol):
         # a wrong y must not pass as a measurement: the line is printed for diagnosis, flagged, and the run fails
         out["config"]["parity_failed"] = True
@@ -997,7 +1042,8 @@ def run_c2(args, bsm, torch, dist, np, rank, world, barrier, reduce_scalars):
             o5 = run_partitioned(a5, bsm, torch, None, np, 0, 1, barrier, reduce_scalars)
             extra["c5_n1"] = {"workload": o5["config"]["workload"], "value": o5["value"], "unit": "GB/s", "ms_per_step": o5["ms_per_step"],
                               "steps": 20, "exchange_us": o5["config"]["exchange_us"], "local_kernel_us_max": o5["config"]["local_kernel_us_max"],
-                              "parity_relerr": o5["config"]["parity_relerr"], "frac_of_hbm_peak": o5["config"]["frac_of_hbm_peak"],
+                              "parity_relerr": o5["config"]["parity_relerr"], "parity_vs_oracle_sampled": o5["config"]["parity_vs_oracle_sampled"],
+                              "frac_of_hbm_peak": o5["config"]["frac_of_hbm_peak"],
                               "build": build, "note": "what `python bench.py --gpus 1 --workload c5` prints; N > 1 lines carry the "
                                                       "committed copy of this figure as config.n1_same_workload"}
         except Exception as e:  # pragma: no cover
@@ -1021,7 +1067,8 @@ def run_c2(args, bsm, torch, dist, np, rank, world, barrier, reduce_scalars):
             o6 = run_partitioned(a5, bsm, torch, d1, np, 0, 1, bar1, red1)
             extra["c5_n1_rccl_loopback"] = {"value": o6["value"], "unit": "GB/s", "ms_per_step": o6["ms_per_step"], "steps": 20,
                                             "exchange_us": o6["config"]["exchange_us"], "local_kernel_us_max": o6["config"]["local_kernel_us_max"],
-                                            "parity_relerr": o6["config"]["parity_relerr"], "backend": o6["config"]["backend"],
+                                            "parity_relerr": o6["config"]["parity_relerr"], "parity_vs_oracle_sampled": o6["config"]["parity_vs_oracle_sampled"],
+                                            "backend": o6["config"]["backend"],
                                             "loopback": o6["config"]["loopback"]}
             d1.destroy_process_group()
         except Exception as e:  # pragma: no cover

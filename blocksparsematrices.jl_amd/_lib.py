@@ -54,7 +54,8 @@ EXPORTS = ["bsm_options_default", "bsm_vbcrs_create", "bsm_vbcrs_create_from_sym
            "bsm_partition_rows", "bsm_part_info", "bsm_host_register", "bsm_host_unregister", "bsm_rowcolvals",
            "bsm_blocksparse_create",
            "bsm_symmetric_create", "bsm_mul", "bsm_mul_multi", "bsm_mul_parts", "bsm_get_bookkeeping", "bsm_get_image", "bsm_stats",
-           "bsm_color", "bsm_destroy", "bsm_last_error", "bsm_version"]
+           "bsm_color", "bsm_destroy", "bsm_last_error", "bsm_version",
+           "bsm_vec_add_segments", "bsm_stream_create_reserved", "bsm_stream_destroy"]
 
 
 # include/bsm_synth.h (bench / test utility: synthetic operators generated in HBM)

@@ -212,6 +212,40 @@ def config3(nseg=3125, bs=64, halfband=8, dtype=np.float64, seed=0xB5A3, on_devi
                 rowindices=ridx, colindices=cidx, size=(n, n), x=vector(seed, n, dtype))
 
 
+def _config4_cols(seed, I, ngrid, per_row):
+    """block columns of block row I of C4: the diagonal one, then distinct uniform draws"""
+    colsI = [I]
+    u = draws(seed, I * 4 * per_row, 4 * per_row)
+    k = 0
+    while len(colsI) < min(per_row, ngrid):
+        J = int(u[k % len(u)] % np.uint64(ngrid)) if k < len(u) else (colsI[-1] + 1) % ngrid
+        k += 1
+        if J not in colsI:
+            colsI.append(J)
+    return colsI
+
+
+def config4_sample(block_rows=(), block_cols=(), ngrid=15625, bs=128, per_row=16, dtype=np.float32, seed=0xB5A4):
+    """HOST sub-problem of C4 for a sampled-row check at full size: exactly the blocks of the given block rows (every
+    contribution to those rows of A x) and the blocks of the given block columns (every contribution to those rows of
+    A^T x), bit-identical to what config4(on_device=True) generates in HBM.  Returns (problem, row ranges, column
+    ranges) with 1-based inclusive ranges of the sampled rows / columns; problem["x"] is the full x."""
+    n = ngrid * bs
+    want_r, want_c = set(int(i) for i in block_rows), set(int(j) for j in block_cols)
+    blocks, rowstart, colstart, seen = [], [], [], set()
+    for I in (range(ngrid) if want_c else sorted(want_r)):
+        colsI = _config4_cols(seed, I, ngrid, per_row)
+        for t, J in enumerate(colsI):
+            if (I in want_r or J in want_c) and (I, t) not in seen:
+                seen.add((I, t))
+                blocks.append(block_values(seed, I * per_row + t, bs, bs, dtype))
+                rowstart.append(I * bs + 1)
+                colstart.append(J * bs + 1)
+    prob = dict(kind="vbcrs", blocks=blocks, rowstart=np.array(rowstart, np.int64), colstart=np.array(colstart, np.int64),
+                size=(n, n), x=vector(seed, n, dtype))
+    return prob, [(I * bs + 1, (I + 1) * bs) for I in sorted(want_r)], [(J * bs + 1, (J + 1) * bs) for J in sorted(want_c)]
+
+
 def config4(ngrid=15625, bs=128, per_row=16, dtype=np.float32, seed=0xB5A4, row_lo=0, row_hi=None,
             on_device=False):
     """C4: VBCRS (ngrid*bs)^2, bs x bs blocks, per_row distinct block columns per block row (one on
@@ -221,14 +255,7 @@ def config4(ngrid=15625, bs=128, per_row=16, dtype=np.float32, seed=0xB5A4, row_
     row_hi = ngrid if row_hi is None else row_hi
     blocks, rowstart, colstart = [], [], []
     for I in range(row_lo, row_hi):
-        colsI = [I]
-        u = draws(seed, I * 4 * per_row, 4 * per_row)
-        k = 0
-        while len(colsI) < min(per_row, ngrid):
-            J = int(u[k % len(u)] % np.uint64(ngrid)) if k < len(u) else (colsI[-1] + 1) % ngrid
-            k += 1
-            if J not in colsI:
-                colsI.append(J)
+        colsI = _config4_cols(seed, I, ngrid, per_row)
         for t, J in enumerate(colsI):
             blocks.append(I * per_row + t if on_device else block_values(seed, I * per_row + t, bs, bs, dtype))
             rowstart.append(I * bs + 1)
@@ -307,6 +334,46 @@ def config5(n=5_000_000, lo=16, hi=256, halfband=4, dtype=np.float64, seed=0xB5A
             cidx.append(np.arange(start[J] + 1, start[J] + sz[J] + 1, dtype=np.int64))
     return dict(kind="symmetric", diagonals=diag, diagonalindices=didx, offdiagonals=off,
                 rowindices=ridx, colindices=cidx, size=(n, n), x=vector(seed, n, dtype))
+
+
+def config5_sample(segs, n=5_000_000, lo=16, hi=256, halfband=4, dtype=np.float64, seed=0xB5A5):
+    """HOST sub-problem of C5 for a sampled-row check at full size: for every sampled diagonal segment I its diagonal
+    block, its off-diagonal blocks (I, J), J = I-1 .. I-halfband (the forward sweep into rows I) and the blocks (I', I),
+    I' = I+1 .. I+halfband (whose transposes reach rows I) -- every contribution to y[rows of I] and nothing else is
+    complete.  Values are bit-identical to config5(on_device=True).  Returns (problem, row ranges 1-based inclusive)."""
+    start, sz = _segments(seed, 0, n, lo, hi)
+    nseg = len(sz)
+    Iall = np.arange(nseg + 1, dtype=np.int64)
+    nbefore = np.where(Iall <= halfband, Iall * (Iall - 1) // 2, halfband * (halfband - 1) // 2 + (Iall - halfband) * halfband)
+    segs = sorted(set(int(i) for i in segs))
+    diag, didx, off, ridx, cidx, pairs = [], [], [], [], [], set()
+    rng_of = lambda i: np.arange(start[i] + 1, start[i] + sz[i] + 1, dtype=np.int64)
+    for I in segs:
+        m = int(sz[I])
+        d = block_values(seed, I, m, m, dtype)
+        diag.append(np.asfortranarray((d + d.T) / 2))
+        didx.append(rng_of(I))
+        for (i, k) in [(I, k) for k in range(1, halfband + 1)] + [(I + k, k) for k in range(1, halfband + 1)]:
+            j = i - k
+            if j < 0 or i >= nseg or (i, j) in pairs:
+                continue
+            pairs.add((i, j))
+            off.append(block_values(seed, int(nseg + nbefore[i] + (k - 1)), int(sz[i]), int(sz[j]), dtype))
+            ridx.append(rng_of(i))
+            cidx.append(rng_of(j))
+    prob = dict(kind="symmetric", diagonals=diag, diagonalindices=didx, offdiagonals=off, rowindices=ridx, colindices=cidx,
+                size=(n, n), x=vector(seed, n, dtype))
+    return prob, [(int(start[I]) + 1, int(start[I] + sz[I])) for I in segs]
+
+
+def sample_ids(count, total, seed=12345, lo=0, hi=None):
+    """`count` distinct ids of lo .. hi-1 (default 0 .. total-1): the two ends and a seeded spread between them"""
+    hi = total if hi is None else hi
+    if hi - lo <= count:
+        return list(range(lo, hi))
+    rng = np.random.default_rng(seed)
+    ids = set([lo, hi - 1]) | set(int(v) for v in rng.choice(np.arange(lo, hi), size=count, replace=False)[:count - 2])
+    return sorted(ids)
 
 
 def build(problem, **kw):

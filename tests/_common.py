@@ -81,6 +81,21 @@ def relerr(a, b):
     return float(np.max(np.abs(a - b)) / den)
 
 
+def sampled_relerr(got, ref, ranges):
+    """max |got - ref| / max |ref| over the sampled 1-based inclusive row ranges only (a sub-problem's oracle product
+    is complete on exactly those rows: synthetic.config4_sample / config5_sample); `got` may be a torch tensor"""
+    num = den = 0.0
+    for a, b in ranges:
+        g = got[a - 1:b]
+        g = g.cpu().numpy() if hasattr(g, "cpu") else np.asarray(g)
+        r = ref[a - 1:b]
+        if not np.all(np.isfinite(g)):
+            return float("inf")
+        num = max(num, float(np.max(np.abs(g - r))))
+        den = max(den, float(np.max(np.abs(r))))
+    return num / (den if den > 0 else 1.0)
+
+
 def single_color(n):
     return [list(range(1, n + 1))]
 

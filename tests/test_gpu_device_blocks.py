@@ -5,7 +5,7 @@ synthetic configs (include/bsm_synth.h), which must reproduce the numpy streams 
 import numpy as np
 import pytest
 
-from _common import N, T, oracle_mul, rand_vec, relerr
+from _common import N, T, oracle_mul, rand_vec, relerr, sampled_relerr
 
 pytestmark = pytest.mark.gpu
 
@@ -174,6 +174,66 @@ def test_rowcolvals_from_the_device_image(torch_cuda, bsm):
     r, c, v = bsm.rowcolvals_device(bsm.adjoint(A), device=False)
     got = sp.coo_matrix((v, (r - 1, c - 1)), shape=bsm.size(A)).tocsc()
     assert abs(got - bsm.sparse(A).conj().T).max() == 0
+
+
+def test_config5_FULL_size_against_the_oracle_on_sampled_rows(torch_cuda, bsm, oracle):
+    """BASELINE.json configs[4] at its FULL size against the ORACLE: the operator is generated in HBM bit-identically to
+    the numpy streams (test_generator_in_hbm_is_bit_identical_to_the_numpy_streams), so the host regenerates only the
+    blocks that reach ~200 sampled diagonal segments (synthetic.config5_sample: diagonal block, forward blocks (I, J),
+    and the blocks (I', I) whose transposes reach rows I), runs orc_sym_mul on that sub-problem with the full x, and the
+    GPU's y is compared on those rows -- 3-argument form and mul!(y, A, x, alpha, beta); S^T through the same check.
+    Reference procedure: test/test_vbcrs.jl:33-47 (product against an independent one, max |dy| / max |y|), 1e-12."""
+    torch = torch_cuda
+    S_ = bsm.synthetic
+    p = S_.config5(on_device=True)
+    n = p["size"][0]
+    A = S_.build(p)
+    assert A.stats()["stored_entries"] * 8 > 28e9
+    nseg = len(p["diagonals"])
+    sub, rows = S_.config5_sample(S_.sample_ids(200, nseg))
+    assert sum(b - a + 1 for a, b in rows) > 20_000
+    x = p["x"]
+    assert torch.equal(x.cpu(), torch.from_numpy(sub["x"]))
+    y = torch.full((n,), float("nan"), dtype=torch.float64, device="cuda")
+    bsm.mul(y, A, x)
+    ref = oracle_mul(oracle, sub, N, sub["x"], np.zeros(n))
+    assert sampled_relerr(y, ref, rows) < 1e-12
+    bsm.mul(y, bsm.transpose(A), x)
+    assert sampled_relerr(y, oracle_mul(oracle, sub, T, sub["x"], np.zeros(n)), rows) < 1e-12
+    y0 = np.random.default_rng(2).standard_normal(n)
+    yd = torch.from_numpy(y0).cuda()
+    bsm.mul(yd, A, x, -0.5, 2.0)
+    assert sampled_relerr(yd, oracle_mul(oracle, sub, N, sub["x"], y0, -0.5, 2.0, False), rows) < 1e-12
+    # and through the multi-device handle (another partition, halo exchange)
+    del A
+    torch.cuda.empty_cache()
+    B = S_.build(p, devices=[0, 0])
+    y.fill_(float("nan"))
+    bsm.mul(y, B, x)
+    assert sampled_relerr(y, ref, rows) < 1e-12
+
+
+def test_config4_FULL_size_against_the_oracle_on_sampled_rows(torch_cuda, bsm, oracle):
+    """BASELINE.json configs[3] at its FULL size (16.4 GB fp32) against the oracle on ~200 sampled block rows (A x: the 16
+    blocks of each sampled block row) and ~60 sampled block columns (A^T x: every block of the operator whose column is
+    sampled), tolerance 1e-5."""
+    torch = torch_cuda
+    S_ = bsm.synthetic
+    p = S_.config4(on_device=True)
+    n = p["size"][0]
+    A = S_.build(p)
+    sub, rows, cols = S_.config4_sample(S_.sample_ids(200, 15625), S_.sample_ids(60, 15625, seed=3))
+    x = p["x"]
+    assert torch.equal(x.cpu(), torch.from_numpy(sub["x"]))
+    y = torch.full((n,), float("nan"), dtype=torch.float32, device="cuda")
+    bsm.mul(y, A, x)
+    assert sampled_relerr(y, oracle_mul(oracle, sub, N, sub["x"], np.zeros(n, np.float32)), rows) < 1e-5
+    bsm.mul(y, bsm.transpose(A), x)
+    assert sampled_relerr(y, oracle_mul(oracle, sub, T, sub["x"], np.zeros(n, np.float32)), cols) < 1e-5
+    y0 = np.random.default_rng(2).standard_normal(n).astype(np.float32)
+    yd = torch.from_numpy(y0).cuda()
+    bsm.mul(yd, A, x, 0.75, -1.5)
+    assert sampled_relerr(yd, oracle_mul(oracle, sub, N, sub["x"], y0, 0.75, -1.5, False), rows) < 1e-5
 
 
 def test_config5_FULL_size_properties_on_one_gpu(torch_cuda, bsm):

@@ -100,7 +100,7 @@ def test_blocksparse_fixture(torch_cuda, bsm, oracle, key, acc):
 
 
 @pytest.mark.parametrize("key", ["cuboid", "sphere"])
-def test_vbcrs_from_symmetric_matches_symmetric(torch_cuda, bsm, key):
+def test_vbcrs_from_symmetric_matches_symmetric(torch_cuda, bsm, oracle, key):
     # reference test/test_vbcrs.jl:52-88 (structure; the contiguous-index fixture is missing from the
     # mount, so a contiguous synthetic symmetric operator stands in for it)
     p = bsm.synthetic.config5(n=3000, lo=1, hi=40, halfband=3, seed=0xB5A5 + (key == "sphere"))
@@ -112,9 +112,14 @@ def test_vbcrs_from_symmetric_matches_symmetric(torch_cuda, bsm, key):
         rng = np.random.default_rng(2)
         for _ in range(3):
             x = rand_vec(rng, p["size"][1], np.float64)
+            # the ORACLE's symmetric product (src/symmetricblockmatrix.jl:386-435) is what both are held to -- S and V
+            # run the same HIP kernels, so V against S alone would compare the HIP path with itself
+            ref = oracle_mul(oracle, p, N, x, np.zeros_like(x))
             sx = gpu_mul(torch_cuda, bsm, S, N, x, np.zeros_like(x), 1, 0, True)
+            assert relerr(sx, ref) < 1e-12
             for op in (N, T, Cc):
                 vx = gpu_mul(torch_cuda, bsm, V, op if op != Cc else T, x, np.zeros_like(x), 1, 0, True)
+                assert relerr(vx, ref) < 1e-12
                 assert relerr(vx, sx) < 1e-12
 
 
