@@ -375,6 +375,7 @@ def main():
                     "same process) the rest, so the x halo and the partial-y halo travel through grouped self send / recv beside the "
                     "interior launch (distributed.RowPartitioned(loopback=...)): the only way a one-GPU box executes RCCL")
     ap.add_argument("--no-oracle-check", action="store_true", help="--workload c5 / N > 1: skip the sampled-row oracle check of the last timed step")
+    ap.add_argument("--no-anchor", action="store_true", help="N > 1: do not let rank 0 measure the same workload alone afterwards (n1_same_workload)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.pmc_child:
@@ -761,23 +762,65 @@ def run_partitioned(args, bsm, torch, dist, np, rank, world, barrier, reduce_sca
                     "the boundary blocks travel through grouped self send / recv (batch_isend_irecv on device tensors) on the side "
                     "stream beside the interior launch; every row of y is checked against an ordinary single-handle product" % (backend, r5["own"][0], r5["own"][1]),
             "librccl_loaded": bool([ln for ln in open("/proc/self/maps") if "librccl" in ln])}
-    if world > 1 and args.scale == 1.0:
-        # the same operator on ONE GPU (profiles/r04_c5_n1.json: `bench.py --gpus 1 --workload c5` on an MI355X box of this
-        # pool, stamped with the build of the kernels): what this line's value has to be divided by for a speed-up --
-        # the driver's own N = 1 run times C2, another operator
+    if world > 1:
+        # The SAME operator on ONE GPU through the same code path -- what this line's value has to be divided by for a
+        # speed-up (the driver's own N = 1 run times C2: another operator, Infinity-Cache-resident).  Sources, best first:
+        #   1. measured NOW: rank 0 alone, on its own GPU, after the N-rank run (same box, same build; the other ranks wait
+        #      at a host-side barrier); the whole operator (29 GB at the full size) fits one GPU;
+        #   2. the driver-timed extra.c5_n1 of the newest BENCH_r*.json in the tree;
+        #   3. the committed profiles/r0N_c5_n1.json.
         from bsm_amd import _lib
         build = _lib.lib().bsm_version().decode().split("build ")[-1]
-        n1 = read_json(C5N1_FILE)
-        if n1 and n1.get("value"):
-            out["config"]["n1_same_workload_GBps"] = n1["value"]
-            out["config"]["n1_same_workload"] = {"GBps": n1["value"], "ms_per_step": n1.get("ms_per_step"), "build": n1.get("build"),
-                                                 "same_build": n1.get("build") == build, "file": os.path.relpath(C5N1_FILE, ROOT)}
-            out["config"]["speedup_vs_n1_same_workload"] = round(value / n1["value"], 3)
-        else:
-            out["config"]["n1_same_workload_GBps"] = None
+        anchor = None
+        if not getattr(args, "no_anchor", False):
+            wait_group = comm["fallback"] if comm["fallback"] is not None else comm["group"]
+            if rank == 0:
+                try:
+                    torch.cuda.empty_cache()
+                    a1 = argparse.Namespace(**vars(args))
+                    a1.no_extra, a1.no_overlap, a1.note, a1.loopback, a1.no_anchor = True, False, None, False, True
+                    a1.steps, a1.warmup = max(args.steps, 10), max(args.warmup, 3)
+
+                    def bar1():
+                        torch.cuda.synchronize()
+
+                    def red1(elapsed, nbytes):
+                        return elapsed, float(nbytes)
+                    red1.comm = {"group": None, "dev": "cuda", "name": "none", "fallback": None}
+                    o1 = run_partitioned(a1, bsm, torch, None, np, 0, 1, bar1, red1)
+                    if not o1.get("value_invalid"):
+                        anchor = {"GBps": o1["value"], "ms_per_step": o1["ms_per_step"], "steps": a1.steps, "build": build, "same_build": True,
+                                  "parity_vs_oracle_sampled": o1["config"]["parity_vs_oracle_sampled"],
+                                  "source": "measured in THIS run: rank 0 alone on its GPU after the %d-rank run, same box, same build, same code "
+                                            "path (python bench.py --gpus 1 --workload c5)" % world}
+                except Exception as e:  # pragma: no cover
+                    print("[bench] the live N = 1 anchor failed: %r" % (e,), file=sys.stderr, flush=True)
+                torch.cuda.empty_cache()
+            dist.barrier(group=wait_group)
+        if anchor is None and args.scale == 1.0 and rank == 0:
+            import glob
+            for path in sorted(glob.glob(os.path.join(ROOT, "BENCH_r*.json")), reverse=True):
+                d = read_json(path) or {}
+                c5 = ((d.get("parsed") or d).get("extra") or {}).get("c5_n1") or {}
+                if c5.get("value"):
+                    anchor = {"GBps": c5["value"], "ms_per_step": c5.get("ms_per_step"), "build": c5.get("build"),
+                              "same_build": c5.get("build") == build,
+                              "source": "driver-timed extra.c5_n1 of %s (an earlier round's driver run)" % os.path.basename(path)}
+                    break
+            if anchor is None:
+                n1 = read_json(C5N1_FILE)
+                if n1 and n1.get("value"):
+                    anchor = {"GBps": n1["value"], "ms_per_step": n1.get("ms_per_step"), "build": n1.get("build"),
+                              "same_build": n1.get("build") == build, "source": "committed " + os.path.relpath(C5N1_FILE, ROOT)}
+        # top-level, so that a reader needs no knowledge of `config`
+        out["n1_same_workload"] = anchor
+        out["speedup_vs_n1_same_workload"] = round(value / anchor["GBps"], 3) if anchor else None
+        out["config"]["n1_same_workload_GBps"] = anchor["GBps"] if anchor else None
+        out["config"]["n1_same_workload"] = anchor
+        out["config"]["speedup_vs_n1_same_workload"] = out["speedup_vs_n1_same_workload"]
         notes.append("the default N = 1 line of this script times C2 (BASELINE.json's 1-GPU configuration: another operator, "
-                     "Infinity-Cache-resident); the N = 1 figure of THIS workload is config.n1_same_workload (also extra.c5_n1 of the "
-                     "N = 1 line), and config.speedup_vs_n1_same_workload divides by it")
+                     "Infinity-Cache-resident); the N = 1 figure of THIS workload is n1_same_workload (its `source` says where it comes "
+                     "from) and speedup_vs_n1_same_workload divides by it")
     if notes:
         out["config"]["note"] = "; ".join(notes)
     if extra:

@@ -175,6 +175,12 @@ def test_bench_launches_its_own_ranks_and_reports_parity():
     c4 = d["extra"]["c4"]
     assert c4["parity_relerr"] <= 1e-5 and c4["overlap"] is True
     assert "value_invalid" not in d
+    # the oracle saw the last timed step of both workloads (sampled block rows of every rank)
+    assert c["parity_vs_oracle_sampled"] <= 1e-12 and c4["parity_vs_oracle_sampled"] <= 1e-5
+    # the scaling anchor is a figure of THIS run: rank 0 alone on the same operator, same build, same code path
+    a = d["n1_same_workload"]
+    assert a["GBps"] > 0 and a["same_build"] is True and "THIS run" in a["source"]
+    assert d["speedup_vs_n1_same_workload"] == round(d["value"] / a["GBps"], 3)
 
 
 def test_rccl_executes_every_collective_branch_on_one_rank():
