@@ -467,6 +467,7 @@ def run_partitioned(args, bsm, torch, dist, np, rank, world, barrier, reduce_sca
     S = bsm.synthetic
     comm = reduce_scalars.comm
     loopback = bool(getattr(args, "loopback", False)) and world == 1
+    solo = dist is None  # (a process group may exist all the same: rank 0 measuring the N = 1 anchor after an N-rank run)
 
     def c5_share():
         n = int(5_000_000 * args.scale)
@@ -543,7 +544,7 @@ def run_partitioned(args, bsm, torch, dist, np, rank, world, barrier, reduce_sca
             # interior blocks (read x[own], write y[own]) and boundary blocks as two handles: the exchanges
             # and the boundary product run on a side stream beside the interior launch
             P = D.build_overlapped(prob, own, group=comm["group"], symmetric=sym, xmode="halo" if sym else "allgather",
-                                   loopback=own if loopback else None)
+                                   loopback=own if loopback else None, solo=solo)
             handles = [h for h in (P.interior, P.local) if h is not None]
         else:
             touched = D._touched(own, prob["colindices"]) if sym else own
@@ -551,7 +552,7 @@ def run_partitioned(args, bsm, torch, dist, np, rank, world, barrier, reduce_sca
                 touched = (1, n)
             A = D.build_local(prob, touched)
             P = D.RowPartitioned(A, own, touched, group=comm["group"], gather=False, symmetric=sym,
-                                 xneed=touched if sym else None, loopback=own if loopback else None)
+                                 xneed=touched if sym else None, loopback=own if loopback else None, solo=solo)
             handles = [A] if A is not None else []
         t_setup = time.perf_counter() - t0
         if not handles:

@@ -268,7 +268,7 @@ def split_interior(local, own):
     return interior, boundary, btouched, bxneed
 
 
-def build_overlapped(local, own, group=None, symmetric=None, xmode="auto", loopback=None, **kw):
+def build_overlapped(local, own, group=None, symmetric=None, xmode="auto", loopback=None, solo=False, **kw):
     """RowPartitioned for the partitioned-vector forward product with the exchange OVERLAPPED with the
     interior rows (mul_overlapped): two handles per rank -- interior blocks with own = the rank's
     rows, boundary blocks with own = the rows they touch.  xmode: "halo" (the x entries the boundary
@@ -282,7 +282,7 @@ def build_overlapped(local, own, group=None, symmetric=None, xmode="auto", loopb
         extra = max(0, own[0] - bxneed[0]) + max(0, bxneed[1] - own[1]) if bxneed[1] >= bxneed[0] else 0
         xmode = "halo" if extra <= max(own[1] - own[0] + 1, 0) else "allgather"
     P = RowPartitioned(A_bnd, own, btouched, group=group, gather=False, symmetric=sym,
-                       xneed=(bxneed if xmode == "halo" else None), interior=A_int, loopback=loopback)
+                       xneed=(bxneed if xmode == "halo" else None), interior=A_int, loopback=loopback, solo=solo)
     P.xmode = xmode
     return P
 
@@ -300,8 +300,11 @@ class RowPartitioned:
     its beta pass covers exactly the rows it touches), or None for a rank without blocks."""
 
     def __init__(self, local, own, touched=None, group=None, gather=False, axis=0, symmetric=None, xneed=None,
-                 interior=None, loopback=None):
+                 interior=None, loopback=None, solo=False):
         self.local = local
+        # solo: this object takes no part in the process group although one is initialised (rank 0 of a finished N-rank
+        # run measuring the whole operator alone: bench.py's n1_same_workload) -- rank 0 of a world of one
+        self.solo = bool(solo)
         # LOOPBACK rehearsal (one rank, any backend -- meant for "nccl" on the single GPU of a test box, where RCCL
         # refuses two ranks per device): every collective and point-to-point branch of this class runs against the
         # rank ITSELF instead of being skipped at world == 1.
@@ -334,8 +337,9 @@ class RowPartitioned:
         self.gather = gather
         self.axis = axis
         self.symmetric = isinstance(local, M.SymmetricBlockMatrix) if symmetric is None else symmetric
-        self.rank = dist.get_rank(group) if dist is not None and dist.is_initialized() else 0
-        self.world = dist.get_world_size(group) if dist is not None and dist.is_initialized() else 1
+        grouped = dist is not None and dist.is_initialized() and not self.solo
+        self.rank = dist.get_rank(group) if grouped else 0
+        self.world = dist.get_world_size(group) if grouped else 1
         if self.loopback:
             if self.world != 1:
                 raise ValueError("loopback is a one-rank rehearsal")
