@@ -237,8 +237,12 @@ void fill_image(const Analysis &an, const bsm_options &o, bool use_own, DeviceIm
     img.mean_rows = (float)an.mean_rows;
     img.exclusive_fwd = an.exclusive_fwd && (o.accumulate == BSM_ACC_AUTO || o.accumulate == BSM_ACC_DIRECT);
     img.has_off = false;
+    img.max_rows = 1;
     for (const WaveWork &w : an.waves)
-        if (w.work == WORK_PANEL && w.npieces > 0 && (w.first.kind & kKindHasOff)) img.has_off = true;
+        if (w.work == WORK_PANEL && w.npieces > 0) {
+            if (w.first.kind & kKindHasOff) img.has_off = true;
+            img.max_rows = std::max(img.max_rows, (int)w.m);
+        }
     if (!img.exclusive_fwd) img.nwg_total = img.nwg_main;
     img.color_wg_ptr.assign(an.color_wg_ptr.begin(), an.color_wg_ptr.end());
     img.device_bytes = (long long)((size_t)an.value_bytes + an.rows.size() * 4 + an.cols.size() * 4 +
@@ -1005,6 +1009,61 @@ struct WorkspaceClaim {
     }
 };
 
+// The work arrays of the interleaved multi-RHS pass (Xr, W: 128 bytes per vector entry each) belong to the handle like the
+// gather workspace, with the same rules: one product in flight -- a racing thread, a predecessor that may still run on
+// ANOTHER stream, or a stream under graph capture do not get the claim and their product takes the ordinary kernels.
+// Allocated (and grown) here, at the first product that uses them.
+struct ILClaim {
+    bsm_matrix_s *A;
+    hipStream_t st;
+    std::unique_lock<std::mutex> lock;
+    bool held = false;
+    ILClaim(bsm_matrix_s *A_, const DeviceImage &img, bool opT, long long nrhs, hipStream_t st_)
+        : A(A_), st(st_), lock(A_->il_mu, std::defer_lock) {
+        if (!il_applies(img, opT, nrhs) || !lock.try_lock()) return;
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &cs) != hipSuccess) {
+            (void)hipGetLastError();
+            cs = hipStreamCaptureStatusNone;
+        }
+        if (cs != hipStreamCaptureStatusNone) return;
+        if (A->il_pending && A->il_stream != st) {  // the stream changed: is the previous one idle?
+            const hipError_t q = hipStreamQuery(A->il_stream);
+            if (q != hipSuccess) {
+                (void)hipGetLastError();
+                if (q != hipErrorNotReady) A->il_pending = false;
+                return;
+            }
+            A->il_pending = false;
+        }
+        const long long need = std::max(img.nrows, img.ncols);
+        if (A->il.rows < need) {
+            if (A->il_pending && hipStreamSynchronize(A->il_stream) != hipSuccess) (void)hipGetLastError();
+            A->il_pending = false;
+            if (A->il.xr) (void)hipFree(A->il.xr);
+            if (A->il.w) (void)hipFree(A->il.w);
+            A->il = ILWork{};
+            void *xr = nullptr, *w = nullptr;
+            if (hipMalloc(&xr, (size_t)need * 128) != hipSuccess || hipMalloc(&w, (size_t)need * 128) != hipSuccess) {
+                (void)hipGetLastError();
+                if (xr) (void)hipFree(xr);
+                return;  // no memory for the work arrays: the ordinary kernels need none
+            }
+            A->il.xr = xr;
+            A->il.w = w;
+            A->il.rows = need;
+            A->il.w_clean = false;
+        }
+        held = true;
+    }
+    ILWork *work() { return held ? &A->il : nullptr; }
+    void mark() {
+        if (!held) return;
+        A->il_stream = st;
+        A->il_pending = true;
+    }
+};
+
 extern "C" int bsm_mul(bsm_matrix_t A, int op, const void *x, void *y, const void *alpha,
                        const void *beta, int beta_strong_zero, int memspace, void *stream) {
     if (!A) return fail(BSM_ERR_INVALID, "null handle");
@@ -1088,9 +1147,11 @@ extern "C" int bsm_mul_multi(bsm_matrix_t A, int op, int64_t nrhs, const void *X
     hipError_t e = guard.enter(img.device);
     if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
     hipStream_t st = (hipStream_t)stream;
+    ILClaim il(A, img, opT, nrhs, st);
     if (memspace == BSM_MEM_DEVICE) {
-        e = launch_mul_multi(img, opT, conj, nrhs, X, ldx, Y, ldy, alpha, beta, beta_strong_zero, st);
+        e = launch_mul_multi(img, opT, conj, nrhs, X, ldx, Y, ldy, alpha, beta, beta_strong_zero, st, nullptr, il.work());
         if (e != hipSuccess) return hip_fail(e, "kernel launch");
+        il.mark();
         return BSM_OK;
     }
     if (memspace != BSM_MEM_HOST) return fail(BSM_ERR_INVALID, "bad memspace");
@@ -1106,7 +1167,8 @@ extern "C" int bsm_mul_multi(bsm_matrix_t A, int op, int64_t nrhs, const void *X
         e = hipMemcpy2DAsync(dy, (size_t)ylen * es, Y, (size_t)ldy * es, (size_t)ylen * es, (size_t)nrhs,
                              hipMemcpyHostToDevice, st);
     if (e == hipSuccess)
-        e = launch_mul_multi(img, opT, conj, nrhs, dx, xlen, dy, ylen, alpha, beta, beta_strong_zero, st);
+        e = launch_mul_multi(img, opT, conj, nrhs, dx, xlen, dy, ylen, alpha, beta, beta_strong_zero, st, nullptr, il.work());
+    il.mark();
     if (e == hipSuccess)
         e = hipMemcpy2DAsync(Y, (size_t)ldy * es, dy, (size_t)ylen * es, (size_t)ylen * es, (size_t)nrhs,
                              hipMemcpyDeviceToHost, st);
@@ -1265,6 +1327,8 @@ extern "C" int bsm_destroy(bsm_matrix_t A) {
         free_image(A->img_t);
         if (A->stage_x) (void)hipFree(A->stage_x);
         if (A->stage_y) (void)hipFree(A->stage_y);
+        if (A->il.xr) (void)hipFree(A->il.xr);
+        if (A->il.w) (void)hipFree(A->il.w);
     }
     delete A;
     return BSM_OK;

@@ -35,6 +35,12 @@ struct bsm_matrix_s {
     std::mutex gather_mu;  // the gather workspace admits one product in flight per handle
     hipStream_t ws_stream = nullptr;  // stream of the last gather-mode product
     bool ws_pending = false;          // ... which may still be running (see WorkspaceClaim)
+    // work arrays of the interleaved multi-RHS pass (bsm_kernels.h: ILWork): allocated at the first product that takes
+    // it, one product in flight (ILClaim in bsm_capi.cpp: same rules as the gather workspace)
+    std::mutex il_mu;
+    bsm::ILWork il;
+    hipStream_t il_stream = nullptr;
+    bool il_pending = false;
     // device staging buffers of the BSM_MEM_HOST path, kept between calls (grow-only); a second
     // concurrent host call on the same handle falls back to temporary buffers
     std::mutex host_mu;

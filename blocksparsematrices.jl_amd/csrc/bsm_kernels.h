@@ -19,6 +19,7 @@ struct DeviceImage {
     long long nwg_multi = 0;
     float mean_rows = 64.f;  // Analysis::mean_rows: fused fp32 products of short panels keep 4 loads per lane in flight
     float lane_fill = 1.f;  // Analysis::lane_fill: two right-hand sides go through a padded 4-column pass above 0.85
+    int max_rows = 64;      // tallest row group of the image (the interleaved multi-RHS kernels: row blocks per panel)
     bool exclusive_fwd = false;
     bool has_off = false;  // SymmetricBlockMatrix off-diagonal pieces present
     long long device_bytes = 0;
@@ -66,10 +67,22 @@ hipError_t launch_vec_finish(int dtype, void *y, long long ldy, void *w, long lo
 // y[lo_c + i] += base_c[i] for npieces <= kMaxVecPieces disjoint segments [lo_c, hi_c) of y, one launch
 hipError_t launch_vec_add_segments(int dtype, void *y, const VecPieces &pc, int npieces, hipStream_t stream);
 
+// Work arrays of the INTERLEAVED multi-RHS pass (bsm_kernels.hip: panel_kernel_il_*): X and the accumulated Y row-major,
+// one 128-byte line per vector index.  Owned by the handle (bsm_capi.cpp: ILClaim), one product in flight.
+struct ILWork {
+    void *xr = nullptr;   // rows x 128 bytes: alpha * X, K-interleaved
+    void *w = nullptr;    // rows x 128 bytes: the sums; zero between products (the finish pass zeroes behind its read)
+    long long rows = 0;   // capacity of both, in vector entries
+    bool w_clean = false; // w is known to be zero
+};
+// whether launch_mul_multi would take the interleaved pass for this image / op / batch (so that the caller only claims
+// -- and allocates -- the work arrays when they will be used)
+bool il_applies(const DeviceImage &img, bool opT, long long nrhs);
+
 // nrhs right-hand sides: X (ldx) and Y (ldy) column-major; A is streamed once per batch of <= 8.
 hipError_t launch_mul_multi(const DeviceImage &img, bool opT, bool conj, long long nrhs, const void *x,
                             long long ldx, void *y, long long ldy, const void *alpha, const void *beta,
-                            int strong_zero, hipStream_t stream, const long long *zrange = nullptr);
+                            int strong_zero, hipStream_t stream, const long long *zrange = nullptr, ILWork *il = nullptr);
 
 // rowcolvals(A): COO triples (1-based int64 rows / cols, values of the image's element type) written from
 // the packed device image; d_out_off[w] = first output slot of wave descriptor w (host prefix sum of

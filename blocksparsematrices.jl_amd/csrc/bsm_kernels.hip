@@ -1728,6 +1728,321 @@ __global__ void __launch_bounds__(64 * kWavesPerWg, ((kMfmaPath32<T, K> || (kMfm
     }
 }
 
+// ----------------------------------------------------------------------------------------
+// INTERLEAVED multi-RHS pass (round 5): 8 ComplexF64 right-hand sides with X and the accumulated Y held ROW-major
+// ("K-interleaved") in two work arrays of the handle:
+//     Xr[i][c], W[i][c],  c = 2 k + (0: Re, 1: Im),  16 doubles = ONE 128-byte line per vector index
+// Xr = alpha * X is written by il_pack_kernel in front of the pass, Y = beta * Y + W is read back (and W zeroed behind)
+// by il_finish_kernel.  What it changes against panel_kernel_multi's matrix-pipe path (counters of round 4: 9.7 M atomic
+// line requests and 11.6 M read requests per BEM launch, the vector L1 stalled on pending requests 87 % of the time):
+//   * the x operand of an MFMA (component on lane % 16) is ONE coalesced 128-byte line per column / row index, loaded
+//     straight from Xr into the operand register -- no K-fold gather of column-major X, no x slice in LDS (32 KB per
+//     workgroup: 3 workgroups per CU), no dependent "column list -> x gather -> LDS" round trips per 64 columns;
+//   * both halves are computed with the COMPONENT on the lane (A = the matrix tile, B = the x lines), so a sum leaves as
+//     16 consecutive doubles of one line of W: 4 lines per atomic wave-instruction whatever the column list looks like
+//     (column-major Y: one line per (index, k) -- 16-32 per instruction for the scattered lists of a BEM panel);
+//   * the whole column list of a panel (<= 256 columns per refill) is staged once, so a wave's start is descriptor ->
+//     {row list -> x rows, column list, first tile}: three round trips for the whole panel.
+// One step = one row block (16 rows) of one column tile (16 columns), operands one step ahead, as in the path above.
+// ----------------------------------------------------------------------------------------
+#ifndef BSM_IL_WGS  // resident workgroups per CU the interleaved kernels are compiled for
+#define BSM_IL_WGS(MRMAX) 3
+#endif
+constexpr int kIlCols = 256;            // columns of a panel staged per refill of the index list
+constexpr int IL_NOFWD = 1 << 30;       // staged column entry: takes no part in the forward half
+constexpr int IL_NOTRN = (int)(1u << 31);  // ... in the transposed half
+constexpr int IL_MASK = (1 << 30) - 1;
+
+// The loop is written BRANCH-FREE on purpose.  hipcc places its own s_waitcnt in front of the first use of every loaded
+// register, and wherever control flow (a lane-masked `if` around a load or an atomic, a scratch reload, paths with different
+// numbers of memory operations) keeps it from counting the operations in flight exactly it waits for ALL of them:
+// the first version of this kernel -- loads and atomics under `if (row < m && w < ncols)` -- compiled to a
+// `s_waitcnt vmcnt(0)` in front of every step's MFMAs, i.e. the operands requested one step ahead were drained at once
+// and every step cost a full memory round trip (tools/il_trace.py: 3.5 us per step, 35 us per 19 KB panel).  Here every
+// load and every atomic of the loop is issued unconditionally, with indices clamped into the panel (rows >= m read row
+// m - 1, columns >= ncols the last column) and the VALUES masked instead: rows beyond m meet x rows that are zero and
+// their forward sums are never delivered, columns beyond the panel get a zero x operand and deliver +0.0.  One body per
+// number of row blocks (NRB), so that a step is the same instruction sequence every time.
+// atomic add of the lanes with `ok`, WITHOUT control flow: the other lanes are switched off for the one instruction
+// (EXEC), not branched around -- a lane-masked `if` around an atomic becomes a branch, and hipcc then no longer knows how
+// many operations are in flight behind it (above).  Masked lanes must not be routed to a dummy target instead: lanes of
+// one instruction that add to the SAME address are serialised on the memory side (measured with +0.0 deliveries to a
+// clamped index: the atomics of the BEM pass went from 30 to 390 us).  hipcc does not count the instruction either; it is
+// always issued IN FRONT of the step's loads, so every wait it computes for those is still sufficient.
+__device__ __forceinline__ void il_atomic_add(double *p, double v, bool ok) {
+    unsigned long long save;
+    const int flag = ok ? 1 : 0;
+    asm volatile(
+        "s_mov_b64 %0, exec\n\t"
+        "v_cmpx_ne_u32_e32 0, %1\n\t"
+        "global_atomic_add_f64 %2, %3, off\n\t"
+        "s_mov_b64 exec, %0"
+        : "=&s"(save)
+        : "v"(flag), "v"(p), "v"(v)
+        : "vcc", "memory");
+}
+
+template <int NRB, bool FWD, bool TRN>
+__device__ __forceinline__ void il_panel_c128(const WaveD &wd, const uint4 *__restrict__ values, const int *__restrict__ rows,
+                                              const int *__restrict__ cols, const double *__restrict__ xr,
+                                              double *__restrict__ wacc, int flags, int lane, Vec16<c128> *tile, int *cix) {
+    using T = c128;
+    const bool opT = (flags & FLAG_OPT) != 0;
+    const bool cjf = (flags & FLAG_CONJ) != 0;
+    const int m = wd.m;
+    const int ln = lane & 15, lk = lane >> 4;
+    const PieceD pc = wd.first;
+    const int xbase = pc.xbase, col_off = pc.col_off, ncols = pc.ncols, kinds = pc.kind;
+    const bool has_off = (kinds & kKindHasOff) != 0;
+    const bool fwd_en = FWD && (!opT || has_off);
+    const bool trn_en = TRN && (opT || has_off);
+    const Vec16<T> *__restrict__ vb = reinterpret_cast<const Vec16<T> *>(values + (((uint64_t)pc.val_hi << 32) | pc.val_lo));
+    const int s1w = wd.seg1_w, s1x = wd.seg1_x - wd.seg1_w;
+    const int s2w = wd.seg2_w, s2x = pc.seg2_x - wd.seg2_w;
+    // the sign of X'' = i X (conj(B): -i X) on this lane: component 2 k takes -Im, component 2 k + 1 takes +Re
+    const bool neg2 = ((ln & 1) == 0) != cjf;
+    auto second = [&](double v1) {
+        const double v2 = dppx<DPP_QUAD_XOR1>(v1);
+        return neg2 ? -v2 : v2;
+    };
+    // matrix operand of step (t0, rb): lane = (row rb * 16 + ln, column t0 + 4 j + lk), indices clamped into the panel
+    const int rowc[NRB > 1 ? NRB : 1] = {};
+    auto mat = [&](int t0, int rb, int j) -> c128 {
+        const int w = min(t0 + 4 * j + lk, ncols - 1);
+        const int row = min(rb * 16 + ln, m - 1);
+        if (BSM_DBG(DBG_NO_MATRIX)) return c128{0.0, 0.0};
+        return load_stream16(&vb[(uint32_t)(w * m + row)]).v[0];
+    };
+    (void)rowc;
+    // ---- first batch of requests: the column list of the first block, the row list, the first tile -- all need the
+    // descriptor only
+    int craw[kIlCols / 64];
+    const int nq0 = (min(ncols, kIlCols) + 63) >> 6;  // (wave-uniform)
+#pragma unroll
+    for (int q = 0; q < kIlCols / 64; ++q) {
+        craw[q] = 0;
+        if (xbase < 0 && q < nq0) craw[q] = cols[col_off + min(q * 64 + lane, ncols - 1)];
+    }
+    int ri[4 * NRB];
+#pragma unroll
+    for (int q = 0; q < 4 * NRB; ++q) {
+        const int r = min(4 * q + lk, m - 1);
+        ri[q] = wd.rbase + r;
+    }
+    if (wd.rbase < 0) {  // (wave-uniform)
+#pragma unroll
+        for (int q = 0; q < 4 * NRB; ++q) ri[q] = rows[wd.row_off + min(4 * q + lk, m - 1)];
+    }
+    c128 nb[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) nb[j] = mat(0, 0, j);
+    // x / y index of panel column w with its roles (IL_NOFWD / IL_NOTRN)
+    auto entry = [&](int w, int raw) -> int {
+        bool off;
+        int xi;
+        if (xbase < 0) {
+            off = raw >= 0 && (kinds & 3) == KIND_OFF;
+            xi = raw & 0x7fffffff;
+        } else {
+            const int sh = w < s1w ? 0 : (w < s2w ? 2 : 4);
+            off = ((kinds >> sh) & 3) == KIND_OFF;
+            xi = w + (w < s1w ? xbase : (w < s2w ? s1x : s2x));
+        }
+        return xi | ((!opT || off) ? 0 : IL_NOFWD) | ((opT || off) ? 0 : IL_NOTRN);
+    };
+    // ---- second batch: the x rows of the panel (operand of the transposed half), one line of Xr per row
+    double rr[4 * NRB];
+#pragma unroll
+    for (int q = 0; q < 4 * NRB; ++q) rr[q] = (TRN && !BSM_DBG(DBG_NO_XGATHER)) ? xr[(size_t)ri[q] * 16 + ln] : 0.0;
+    v4f64 facc[NRB];
+#pragma unroll
+    for (int rb = 0; rb < NRB; ++rb) facc[rb] = v4f64{0.0, 0.0, 0.0, 0.0};
+    double pd[4] = {0.0, 0.0, 0.0, 0.0};
+    int pe[4] = {0, 0, 0, 0};
+    bool pok[4] = {false, false, false, false};
+    for (int cb = 0; cb < ncols; cb += kIlCols) {
+        const int c_end = min(ncols, cb + kIlCols);
+        // (re)fill the staged index list of [cb, c_end)
+        const int nq = (c_end - cb + 63) >> 6;
+        if (cb > 0) {
+#pragma unroll
+            for (int q = 0; q < kIlCols / 64; ++q)
+                if (xbase < 0 && q < nq) craw[q] = cols[col_off + min(cb + q * 64 + lane, ncols - 1)];
+        }
+#pragma unroll
+        for (int q = 0; q < kIlCols / 64; ++q)
+            if (q < nq) cix[q * 64 + lane] = entry(min(cb + q * 64 + lane, ncols - 1), craw[q]);
+        // entry of column w of this block (clamped into it) and whether w really is one of its columns
+        auto ent = [&](int w) { return cix[min(w, c_end - 1) - cb]; };
+        auto xop = [&](int t0, int j) -> double {
+            if (!FWD || BSM_DBG(DBG_NO_XGATHER)) return 0.0;
+            return xr[(size_t)(ent(t0 + 4 * j + lk) & IL_MASK) * 16 + ln];
+        };
+        if (cb == 0) {
+#pragma unroll
+            for (int q = 0; q < 4 * NRB; ++q) rr[q] = (trn_en && 4 * q + lk < m) ? rr[q] : 0.0;
+        }
+        double xn[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xn[j] = xop(cb, j);
+        for (int t0 = cb; t0 < c_end; t0 += 16) {
+            // this tile's x operand (requested one tile ago), masked: columns beyond the block / without a forward role
+            double xq[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int w = t0 + 4 * j + lk;
+                const int e = ent(w);  // (read unconditionally: a short-circuit around an LDS read is a branch)
+                const bool ok = fwd_en & (w < c_end) & ((e & IL_NOFWD) == 0);
+                xq[j] = ok ? xn[j] : 0.0;
+            }
+            // the PREVIOUS tile's sums first (vector-memory operations retire in order: they have the whole step, and the
+            // latency of the requests behind them, to complete), then the next tile's operands
+            if (!BSM_DBG(DBG_NO_GLOBAL_ATOMICS)) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) il_atomic_add(&wacc[(size_t)pe[r] * 16 + ln], pd[r], pok[r]);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) xn[j] = xop(t0 + 16, j);
+            v4f64 dt = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb) {
+                c128 b[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) b[j] = nb[j];
+                // the next step's tile: the next row block of these columns, or the first one of the next 16 columns
+#pragma unroll
+                for (int j = 0; j < 4; ++j) nb[j] = (rb + 1 < NRB) ? mat(t0, rb + 1, j) : mat(t0 + 16, 0, j);
+                if (FWD && !BSM_DBG(DBG_NO_FWD_HALF)) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const double x2 = second(xq[j]);
+                        facc[rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(b[j].re, xq[j], facc[rb], 0, 0, 0);
+                        facc[rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(b[j].im, x2, facc[rb], 0, 0, 0);
+                    }
+                }
+                if (TRN && !BSM_DBG(DBG_NO_TRN_HALF)) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) tile[(4 * j + lk) * 17 + ln].v[0] = b[j];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const c128 u = tile[ln * 17 + 4 * q + lk].v[0];
+                        const double r1 = rr[rb * 4 + q];
+                        const double r2 = second(r1);
+                        dt = __builtin_amdgcn_mfma_f64_16x16x4f64(u.re, r1, dt, 0, 0, 0);
+                        dt = __builtin_amdgcn_mfma_f64_16x16x4f64(u.im, r2, dt, 0, 0, 0);
+                    }
+                }
+            }
+            // lane (component ln, lk) holds the sums of columns t0 + lk + 4 r: parked until the next step's requests are out
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int w = t0 + lk + 4 * r;
+                const int e = ent(w);
+                pe[r] = e & IL_MASK;
+                pd[r] = dt[r];
+                pok[r] = trn_en & (w < c_end) & ((e & IL_NOTRN) == 0);
+            }
+        }
+    }
+    if (!BSM_DBG(DBG_NO_GLOBAL_ATOMICS)) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) il_atomic_add(&wacc[(size_t)pe[r] * 16 + ln], pd[r], pok[r]);
+    }
+    if (fwd_en && !BSM_DBG(DBG_NO_FWD_OUT)) {
+        // lane (component ln, lk), register r of row block rb: row rb * 16 + lk + 4 r -- every wave adds its own partial
+        // sums (rows beyond m deliver +0.0 to row m - 1)
+#pragma unroll
+        for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = rb * 16 + lk + 4 * r;  // = 4 q + lk for q = 4 rb + r: the row whose index ri[q] holds
+                il_atomic_add(&wacc[(size_t)ri[4 * rb + r] * 16 + ln], facc[rb][r], row < m);
+            }
+    }
+}
+
+template <int MRMAX, bool FWD, bool TRN>
+__global__ void __launch_bounds__(64 * kWavesPerWg, BSM_IL_WGS(MRMAX))
+    panel_kernel_il_c128(const WaveWork *__restrict__ waves, const uint4 *__restrict__ values, const int *__restrict__ rows,
+                         const int *__restrict__ cols, const double *__restrict__ xr, double *__restrict__ wacc, int flags,
+                         unsigned wg_base) {
+    __shared__ Vec16<c128> tl[kWavesPerWg][TRN ? 16 * 17 : 1];
+    __shared__ int cixs[kWavesPerWg][kIlCols];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    BSM_TSTAMP(0);  // wave started
+    const WaveD wd = load_wave(waves + ((size_t)(blockIdx.x + wg_base) * kWavesPerWg + wave));
+    if (wd.work != WORK_PANEL || wd.npieces <= 0 || wd.first.ncols <= 0 || wd.m <= 0) return;
+#ifdef BSM_TRACE
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    BSM_TSTAMP(1);  // descriptor arrived
+    if (lane == 0) {
+        t_trace[threadIdx.x >> 6][6] = (unsigned long long)((long long)wd.first.ncols * 65536 + wd.m);
+        t_trace[threadIdx.x >> 6][7] = wall_clock64();
+    }
+#endif
+    const int nrb = (wd.m + 15) >> 4;  // (wave-uniform)
+    if (nrb == 1)
+        il_panel_c128<1, FWD, TRN>(wd, values, rows, cols, xr, wacc, flags, lane, tl[wave], cixs[wave]);
+    else if (nrb == 2 || MRMAX <= 2)
+        il_panel_c128<2, FWD, TRN>(wd, values, rows, cols, xr, wacc, flags, lane, tl[wave], cixs[wave]);
+    else if (nrb == 3)
+        il_panel_c128<(MRMAX > 2 ? 3 : 2), FWD, TRN>(wd, values, rows, cols, xr, wacc, flags, lane, tl[wave], cixs[wave]);
+    else
+        il_panel_c128<(MRMAX > 2 ? 4 : 2), FWD, TRN>(wd, values, rows, cols, xr, wacc, flags, lane, tl[wave], cixs[wave]);
+#ifdef BSM_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    BSM_TSTAMP(5);  // everything stored
+    if (lane == 0) t_trace[threadIdx.x >> 6][8] = wall_clock64();
+    if (g_trace && lane < 16)
+        g_trace[((size_t)blockIdx.x * kWavesPerWg + (threadIdx.x >> 6)) * 16 + lane] = t_trace[threadIdx.x >> 6][lane];
+#endif
+}
+
+// Xr[i][2 k .. 2 k + 1] = alpha * X[i + kc(k) * ldx] (k >= kact: the last active column again, as the padded passes read it):
+// 256 rows per workgroup, read down the columns of X, written along the lines of Xr (LDS transposition, row stride 9 units)
+__global__ void __launch_bounds__(256) il_pack_kernel_c128(const c128 *__restrict__ x, long long ldx, long long n, c128 alpha, int kact,
+                                                           c128 *__restrict__ xr) {
+    __shared__ c128 s[256 * 9];
+    const long long r0 = (long long)blockIdx.x * 256;
+    const int t = threadIdx.x;
+    if (r0 + t < n) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s[t * 9 + k] = mul(alpha, x[r0 + t + (long long)(k < kact ? k : kact - 1) * ldx]);
+    }
+    __syncthreads();
+    const long long cnt = (n - r0 < 256 ? n - r0 : 256) * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int idx = j * 256 + t;
+        if (idx < cnt) xr[r0 * 8 + idx] = s[(idx >> 3) * 9 + (idx & 7)];
+    }
+}
+// Y[i + k * ldy] = (strong zero ? 0 : beta * Y) + W[i][k] for i in [lo, hi), k < kact;  W[i][:] = 0 behind the read
+__global__ void __launch_bounds__(256) il_finish_kernel_c128(c128 *__restrict__ y, long long ldy, long long lo, long long hi, c128 beta,
+                                                             int strong_zero, int kact, c128 *__restrict__ wacc) {
+    __shared__ c128 s[256 * 9];
+    const long long r0 = lo + (long long)blockIdx.x * 256;
+    const int t = threadIdx.x;
+    const long long cnt = (hi - r0 < 256 ? hi - r0 : 256) * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int idx = j * 256 + t;
+        if (idx < cnt) {
+            s[(idx >> 3) * 9 + (idx & 7)] = wacc[r0 * 8 + idx];
+            wacc[r0 * 8 + idx] = c128{0.0, 0.0};
+        }
+    }
+    __syncthreads();
+    if (r0 + t < hi) {
+        for (int k = 0; k < kact; ++k) {
+            c128 *yp = &y[r0 + t + (long long)k * ldy];
+            const c128 v = s[t * 9 + k];
+            *yp = strong_zero ? v : madd(v, beta, *yp);
+        }
+    }
+}
+
 // y[lo .. hi) = beta * y  (or 0 for the strong zero) -- `y .*= beta`,
 // reference src/blockmatrix.jl:231, src/symmetricblockmatrix.jl:392, src/vbcrs.jl:273,313.
 // A streaming pass: one 16-byte unit per lane and step (the element-per-thread form took 5.6 us for the 1.6 MB
@@ -2006,11 +2321,99 @@ static hipError_t launch_typed_multi(const DeviceImage &img, bool opT, bool conj
     return hipGetLastError();
 }
 
+// ---- the interleaved pass (panel_kernel_il_c128): policy and launch ---------------------------------------
+// BSM_MULTI_IL: 0 = never, 1 = automatic (default: ComplexF64 images of short panels -- mean group height below 32 --
+// that accumulate with atomics), 2 = every ComplexF64 image that accumulates with atomics (A / B)
+static int il_mode() {
+    static const int v = [] {
+        const char *e = std::getenv("BSM_MULTI_IL");
+        return e ? std::atoi(e) : 1;
+    }();
+    return v;
+}
+static int mfma_min_cols() {
+    static const int v = [] {
+        const char *e = std::getenv("BSM_MFMA_MIN_COLS");
+        return e ? std::atoi(e) : 3;  // (BEM fixture x 4: 362 us padded against 486 us through the 4-column kernel)
+    }();
+    return v;
+}
+bool il_applies(const DeviceImage &img, bool opT, long long nrhs) {
+    if (img.dtype != 3 || il_mode() == 0 || nrhs < mfma_min_cols()) return false;
+    if (!opT && img.exclusive_fwd) return false;   // plain stores with beta fused: nothing to gain
+    if (!img.color_wg_ptr.empty()) return false;   // coloured launches keep their bitwise reproducible read-modify-write
+    if (std::max(img.nrows, img.ncols) >= (1ll << 30)) return false;  // (staged entries carry two role bits)
+    return il_mode() == 2 || img.mean_rows < 32.f;
+}
+static hipError_t launch_il_c128(const DeviceImage &img, bool opT, bool conj, const c128 *xd, long long ldx, c128 *yd, long long ldy,
+                                 c128 alpha, c128 beta, int strong_zero, hipStream_t stream, int kact, ILWork &il) {
+    const long long xlen = opT ? img.nrows : img.ncols, ylen = opT ? img.ncols : img.nrows;
+    if (xlen > il.rows || ylen > il.rows) return hipErrorInvalidValue;
+    int flags = 0;
+    if (opT) flags |= FLAG_OPT;
+    if (conj) flags |= FLAG_CONJ;
+#ifdef BSM_EXPERIMENT
+    if (const char *v = std::getenv("BSM_DEBUG_FLAGS")) flags |= std::atoi(v) << 16;
+#endif
+    hipError_t e = hipSuccess;
+    if (!il.w_clean) e = hipMemsetAsync(il.w, 0, (size_t)il.rows * 128, stream);
+    il.w_clean = false;  // (until the finish pass has been enqueued)
+    if (e != hipSuccess) return e;
+    if (xlen > 0)
+        hipLaunchKernelGGL(il_pack_kernel_c128, dim3((unsigned)((xlen + 255) / 256)), dim3(256), 0, stream, xd, ldx, xlen, alpha, kact,
+                           (c128 *)il.xr);
+    const WaveWork *waves = (const WaveWork *)(img.d_waves_multi ? img.d_waves_multi : img.d_waves);
+    const long long nwg = img.d_waves_multi ? img.nwg_multi : img.nwg_main;
+    const uint4 *values = (const uint4 *)img.d_values;
+    const int *rows = (const int *)img.d_rows, *cols = (const int *)img.d_cols;
+    const double *xr = (const double *)il.xr;
+    double *w = (double *)il.w;
+    if (nwg > 0) {
+        const dim3 grid((unsigned)nwg), block(64 * kWavesPerWg);
+        const bool small = img.max_rows <= 32;
+#define BSM_IL_LAUNCH(MR)                                                                                                       \
+    do {                                                                                                                        \
+        if (!opT && !img.has_off)                                                                                               \
+            hipLaunchKernelGGL((panel_kernel_il_c128<MR, true, false>), grid, block, 0, stream, waves, values, rows, cols, xr, w, \
+                               flags, 0u);                                                                                      \
+        else if (img.has_off)                                                                                                   \
+            hipLaunchKernelGGL((panel_kernel_il_c128<MR, true, true>), grid, block, 0, stream, waves, values, rows, cols, xr, w,  \
+                               flags, 0u);                                                                                      \
+        else                                                                                                                    \
+            hipLaunchKernelGGL((panel_kernel_il_c128<MR, false, true>), grid, block, 0, stream, waves, values, rows, cols, xr, w, \
+                               flags, 0u);                                                                                      \
+    } while (0)
+        if (small)
+            BSM_IL_LAUNCH(2);
+        else
+            BSM_IL_LAUNCH(4);
+#undef BSM_IL_LAUNCH
+    }
+    // Y = beta * Y + W over the rows this handle scales (all of them for op T / C), Y += W elsewhere; W = 0 behind
+    long long lo = 0, hi = ylen;
+    if (!opT) {
+        lo = img.own_lo;
+        hi = img.own_hi;
+    }
+    const c128 one = make_scalar<c128>(1.0);
+    auto finish = [&](long long a, long long b, c128 bt, int sz) {
+        if (b > a)
+            hipLaunchKernelGGL(il_finish_kernel_c128, dim3((unsigned)((b - a + 255) / 256)), dim3(256), 0, stream, yd, ldy, a, b, bt, sz,
+                               kact, (c128 *)il.w);
+    };
+    finish(0, lo, one, 0);
+    finish(lo, hi, beta, strong_zero);
+    finish(hi, ylen, one, 0);
+    e = hipGetLastError();
+    if (e == hipSuccess) il.w_clean = true;
+    return e;
+}
+
 template <typename T>
 static hipError_t launch_multi_typed(const DeviceImage &img, bool opT, bool conj, long long nrhs,
                                      const void *x, long long ldx, void *y, long long ldy,
                                      const void *alpha_p, const void *beta_p, int strong_zero,
-                                     hipStream_t stream, const long long *zrange) {
+                                     hipStream_t stream, const long long *zrange, ILWork *il) {
     const T alpha = load_scalar<T>(alpha_p, 1.0);
     const T beta = load_scalar<T>(beta_p, 0.0);
     const T *xd = (const T *)x;
@@ -2030,6 +2433,16 @@ static hipError_t launch_multi_typed(const DeviceImage &img, bool opT, bool conj
     // padded pass against an 8-column pass + a single product).  Short scattered panels (the BEM fixture: mean group
     // height below 32) gain nothing below 15 columns: their passes are bound by the x gather and the atomics, which
     // grow with the padded width (fp64 x 16: 615 us against 2 x 320).  BSM_MFMA_REAL_MIN_COLS overrides (17: off).
+    if constexpr (std::is_same<T, c128>::value) {
+        // ComplexF64 over short scattered panels: the interleaved pass (above), batches of 8 and one padded remainder
+        if (il && !zrange && il_applies(img, opT, nrhs)) {
+            while (e == hipSuccess && nrhs - k >= mfma_min_cols()) {
+                const int kact = (int)std::min<long long>(8, nrhs - k);
+                e = launch_il_c128(img, opT, conj, xd + k * ldx, ldx, yd + k * ldy, ldy, alpha, beta, strong_zero, stream, kact, *il);
+                k += kact;
+            }
+        }
+    }
     if constexpr (kMfmaReal<T, 16>) {
         static const int mr_env = [] {
             const char *v = std::getenv("BSM_MFMA_REAL_MIN_COLS");
@@ -2053,10 +2466,7 @@ static hipError_t launch_multi_typed(const DeviceImage &img, bool opT, bool conj
     }
     // (ComplexF64: the 8-column pass runs on the matrix pipe -- a padded pass beats the 4-column register kernel
     // from 3 columns on: BSM_MFMA_MIN_COLS)
-    static const int mf_min = [] {
-        const char *v = std::getenv("BSM_MFMA_MIN_COLS");
-        return v ? std::atoi(v) : 3;  // (BEM fixture x 4: 362 us padded against 486 us through the 4-column kernel)
-    }();
+    const int mf_min = mfma_min_cols();
     if (e == hipSuccess && nrhs - k >= (kMfmaAny<T, 8> ? mf_min : 5)) {
         const int rem = (int)(nrhs - k);
         e = launch_typed_multi<T, 4, 8>(img, opT, conj, xd + k * ldx, ldx, yd + k * ldy, ldy, alpha, beta,
@@ -2086,12 +2496,12 @@ static hipError_t launch_multi_typed(const DeviceImage &img, bool opT, bool conj
 
 hipError_t launch_mul_multi(const DeviceImage &img, bool opT, bool conj, long long nrhs, const void *x,
                             long long ldx, void *y, long long ldy, const void *alpha, const void *beta,
-                            int strong_zero, hipStream_t stream, const long long *zrange) {
+                            int strong_zero, hipStream_t stream, const long long *zrange, ILWork *il) {
     switch (img.dtype) {
-        case 0: return launch_multi_typed<float>(img, opT, conj, nrhs, x, ldx, y, ldy, alpha, beta, strong_zero, stream, zrange);
-        case 1: return launch_multi_typed<double>(img, opT, conj, nrhs, x, ldx, y, ldy, alpha, beta, strong_zero, stream, zrange);
-        case 2: return launch_multi_typed<c64>(img, opT, conj, nrhs, x, ldx, y, ldy, alpha, beta, strong_zero, stream, zrange);
-        case 3: return launch_multi_typed<c128>(img, opT, conj, nrhs, x, ldx, y, ldy, alpha, beta, strong_zero, stream, zrange);
+        case 0: return launch_multi_typed<float>(img, opT, conj, nrhs, x, ldx, y, ldy, alpha, beta, strong_zero, stream, zrange, il);
+        case 1: return launch_multi_typed<double>(img, opT, conj, nrhs, x, ldx, y, ldy, alpha, beta, strong_zero, stream, zrange, il);
+        case 2: return launch_multi_typed<c64>(img, opT, conj, nrhs, x, ldx, y, ldy, alpha, beta, strong_zero, stream, zrange, il);
+        case 3: return launch_multi_typed<c128>(img, opT, conj, nrhs, x, ldx, y, ldy, alpha, beta, strong_zero, stream, zrange, il);
     }
     return hipErrorInvalidValue;
 }
