@@ -1745,13 +1745,18 @@ __global__ void __launch_bounds__(64 * kWavesPerWg, ((kMfmaPath32<T, K> || (kMfm
 //     {row list -> x rows, column list, first tile}: three round trips for the whole panel.
 // One step = one row block (16 rows) of one column tile (16 columns), operands one step ahead, as in the path above.
 // ----------------------------------------------------------------------------------------
-#ifndef BSM_IL_WGS  // resident workgroups per CU the interleaved kernels are compiled for
-#define BSM_IL_WGS(MRMAX) 3
-#endif
+// resident workgroups per CU the interleaved kernels are compiled for (their natural register need, fused instances:
+// Float32 / ComplexF32 90-92 VGPRs with two row blocks, 125 with four; Float64 122 / 163; ComplexF64 143 / 199)
+template <typename T, int MRMAX> constexpr int il_wgs() {
+    return (sizeof(T) == 4 || sizeof(T) == 8 && !std::is_same<T, double>::value) ? (MRMAX <= 2 ? 5 : 4)
+           : std::is_same<T, double>::value                                       ? (MRMAX <= 2 ? 4 : 3)
+                                                                                   : (MRMAX <= 2 ? 3 : 2);
+}
 constexpr int kIlCols = 256;            // columns of a panel staged per refill of the index list
 constexpr int IL_NOFWD = 1 << 30;       // staged column entry: takes no part in the forward half
 constexpr int IL_NOTRN = (int)(1u << 31);  // ... in the transposed half
 constexpr int IL_MASK = (1 << 30) - 1;
+constexpr int FLAG_IL_XCD = 1 << 12;  // panel_kernel_il: XCD-aware workgroup order
 
 // The loop is written BRANCH-FREE on purpose.  hipcc places its own s_waitcnt in front of the first use of every loaded
 // register, and wherever control flow (a lane-masked `if` around a load or an atomic, a scratch reload, paths with different
@@ -1781,39 +1786,79 @@ __device__ __forceinline__ void il_atomic_add(double *p, double v, bool ok) {
         : "v"(flag), "v"(p), "v"(v)
         : "vcc", "memory");
 }
+__device__ __forceinline__ void il_atomic_add(float *p, float v, bool ok) {
+    unsigned long long save;
+    const int flag = ok ? 1 : 0;
+    asm volatile(
+        "s_mov_b64 %0, exec\n\t"
+        "v_cmpx_ne_u32_e32 0, %1\n\t"
+        "global_atomic_add_f32 %2, %3, off\n\t"
+        "s_mov_b64 exec, %0"
+        : "=&s"(save)
+        : "v"(flag), "v"(p), "v"(v)
+        : "vcc", "memory");
+}
 
-template <int NRB, bool FWD, bool TRN>
-__device__ __forceinline__ void il_panel_c128(const WaveD &wd, const uint4 *__restrict__ values, const int *__restrict__ rows,
-                                              const int *__restrict__ cols, const double *__restrict__ xr,
-                                              double *__restrict__ wacc, int flags, int lane, Vec16<c128> *tile, int *cix) {
-    using T = c128;
+// The four element types of the interleaved pass: 16 real COMPONENTS per vector index -- 8 complex right-hand sides
+// (component 2 k + Re / Im) or 16 real ones -- of type R, one N = 16 of v_mfma_{f64,f32}_16x16x4.  A 16-byte load holds E
+// columns of one row; a step (16 rows x 16 columns) is NLD = 4 / E loads per lane (lane = row ln, strip 4 j + lk).
+template <typename T> struct ILT;
+template <> struct ILT<c128> { using R = double; using V4 = v4f64; static constexpr bool CPLX = true; static constexpr int KK = 8; };
+template <> struct ILT<double> { using R = double; using V4 = v4f64; static constexpr bool CPLX = false; static constexpr int KK = 16; };
+template <> struct ILT<c64> { using R = float; using V4 = v4f32; static constexpr bool CPLX = true; static constexpr int KK = 8; };
+template <> struct ILT<float> { using R = float; using V4 = v4f32; static constexpr bool CPLX = false; static constexpr int KK = 16; };
+__device__ __forceinline__ double il_re(const c128 &a) { return a.re; }
+__device__ __forceinline__ double il_im(const c128 &a) { return a.im; }
+__device__ __forceinline__ float il_re(const c64 &a) { return a.re; }
+__device__ __forceinline__ float il_im(const c64 &a) { return a.im; }
+__device__ __forceinline__ double il_re(double a) { return a; }
+__device__ __forceinline__ double il_im(double) { return 0.0; }
+__device__ __forceinline__ float il_re(float a) { return a; }
+__device__ __forceinline__ float il_im(float) { return 0.f; }
+
+// CS = components stored per vector index: 16, or 8 for real types with at most 8 right-hand sides (half a tile of the
+// MFMA stays empty -- lanes ln >= 8 carry a zero x operand and deliver nothing -- but a vector index is 64 bytes of Xr and
+// of W instead of 128: what bounds this pass over short panels is its vector-side traffic, not the matrix pipe)
+template <typename T, int NRB, bool FWD, bool TRN, int CS>
+__device__ __forceinline__ void il_panel(const WaveD &wd, const uint4 *__restrict__ values, const int *__restrict__ rows,
+                                         const int *__restrict__ cols, const typename ILT<T>::R *__restrict__ xr,
+                                         typename ILT<T>::R *__restrict__ wacc, int flags, int lane, T *tile, int *cix) {
+    using R = typename ILT<T>::R;
+    using V4 = typename ILT<T>::V4;
+    constexpr bool CPLX = ILT<T>::CPLX;
+    constexpr bool F64MAP = sizeof(R) == 8;  // accumulator rows: lk + 4 r (f64) / 4 lk + r (f32)
+    constexpr int E = TT<T>::E;
+    constexpr int NLD = 4 / E;
     const bool opT = (flags & FLAG_OPT) != 0;
     const bool cjf = (flags & FLAG_CONJ) != 0;
     const int m = wd.m;
     const int ln = lane & 15, lk = lane >> 4;
+    const int lc = CS == 16 ? ln : min(ln, CS - 1);  // the component this lane addresses
+    const bool live = CS == 16 || ln < CS;           // ... and whether it carries one at all
     const PieceD pc = wd.first;
-    const int xbase = pc.xbase, col_off = pc.col_off, ncols = pc.ncols, kinds = pc.kind;
+    const int xbase = pc.xbase, col_off = pc.col_off, ncols = pc.ncols, nstrips = pc.nstrips, kinds = pc.kind;
     const bool has_off = (kinds & kKindHasOff) != 0;
     const bool fwd_en = FWD && (!opT || has_off);
     const bool trn_en = TRN && (opT || has_off);
     const Vec16<T> *__restrict__ vb = reinterpret_cast<const Vec16<T> *>(values + (((uint64_t)pc.val_hi << 32) | pc.val_lo));
     const int s1w = wd.seg1_w, s1x = wd.seg1_x - wd.seg1_w;
     const int s2w = wd.seg2_w, s2x = pc.seg2_x - wd.seg2_w;
-    // the sign of X'' = i X (conj(B): -i X) on this lane: component 2 k takes -Im, component 2 k + 1 takes +Re
+    // complex: the sign of X'' = i X (conj(B): -i X) on this lane: component 2 k takes -Im, component 2 k + 1 takes +Re
     const bool neg2 = ((ln & 1) == 0) != cjf;
-    auto second = [&](double v1) {
-        const double v2 = dppx<DPP_QUAD_XOR1>(v1);
+    auto second = [&](R v1) {
+        const R v2 = dppx<DPP_QUAD_XOR1>(v1);
         return neg2 ? -v2 : v2;
     };
-    // matrix operand of step (t0, rb): lane = (row rb * 16 + ln, column t0 + 4 j + lk), indices clamped into the panel
-    const int rowc[NRB > 1 ? NRB : 1] = {};
-    auto mat = [&](int t0, int rb, int j) -> c128 {
-        const int w = min(t0 + 4 * j + lk, ncols - 1);
+    auto mfma = [&](R a, R b, V4 c) { return mfma16(a, b, c); };
+    auto accrow = [&](int r) { return F64MAP ? lk + 4 * r : 4 * lk + r; };  // accumulator register r of this lane -> row of D
+    // matrix operand of step (t0, rb): lane = (row rb * 16 + ln, strip t0 / E + 4 j + lk), indices clamped into the panel
+    // (the last strip of a panel is zero-padded to E columns)
+    auto mat = [&](int t0, int rb, int j) -> Vec16<T> {
+        const int sidx = min(t0 / E + 4 * j + lk, nstrips - 1);
         const int row = min(rb * 16 + ln, m - 1);
-        if (BSM_DBG(DBG_NO_MATRIX)) return c128{0.0, 0.0};
-        return load_stream16(&vb[(uint32_t)(w * m + row)]).v[0];
+        if (BSM_DBG(DBG_NO_MATRIX)) return Vec16<T>{};
+        return load_stream16(&vb[(uint32_t)(sidx * m + row)]);
     };
-    (void)rowc;
     // ---- first batch of requests: the column list of the first block, the row list, the first tile -- all need the
     // descriptor only
     int craw[kIlCols / 64];
@@ -1823,19 +1868,24 @@ __device__ __forceinline__ void il_panel_c128(const WaveD &wd, const uint4 *__re
         craw[q] = 0;
         if (xbase < 0 && q < nq0) craw[q] = cols[col_off + min(q * 64 + lane, ncols - 1)];
     }
-    int ri[4 * NRB];
+    // rows 4 q + lk (the k index of the transposed half's MFMA q) and, where the accumulator map differs, the rows the
+    // forward sums of this lane belong to
+    int ri[4 * NRB], ro[F64MAP ? 1 : 4 * NRB];
 #pragma unroll
     for (int q = 0; q < 4 * NRB; ++q) {
-        const int r = min(4 * q + lk, m - 1);
-        ri[q] = wd.rbase + r;
+        ri[q] = wd.rbase + min(4 * q + lk, m - 1);
+        if (!F64MAP) ro[q] = wd.rbase + min((q >> 2) * 16 + accrow(q & 3), m - 1);
     }
     if (wd.rbase < 0) {  // (wave-uniform)
 #pragma unroll
-        for (int q = 0; q < 4 * NRB; ++q) ri[q] = rows[wd.row_off + min(4 * q + lk, m - 1)];
+        for (int q = 0; q < 4 * NRB; ++q) {
+            ri[q] = rows[wd.row_off + min(4 * q + lk, m - 1)];
+            if (!F64MAP) ro[q] = rows[wd.row_off + min((q >> 2) * 16 + accrow(q & 3), m - 1)];
+        }
     }
-    c128 nb[4];
+    Vec16<T> nb[NLD];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) nb[j] = mat(0, 0, j);
+    for (int j = 0; j < NLD; ++j) nb[j] = mat(0, 0, j);
     // x / y index of panel column w with its roles (IL_NOFWD / IL_NOTRN)
     auto entry = [&](int w, int raw) -> int {
         bool off;
@@ -1851,13 +1901,13 @@ __device__ __forceinline__ void il_panel_c128(const WaveD &wd, const uint4 *__re
         return xi | ((!opT || off) ? 0 : IL_NOFWD) | ((opT || off) ? 0 : IL_NOTRN);
     };
     // ---- second batch: the x rows of the panel (operand of the transposed half), one line of Xr per row
-    double rr[4 * NRB];
+    R rr[4 * NRB];
 #pragma unroll
-    for (int q = 0; q < 4 * NRB; ++q) rr[q] = (TRN && !BSM_DBG(DBG_NO_XGATHER)) ? xr[(size_t)ri[q] * 16 + ln] : 0.0;
-    v4f64 facc[NRB];
+    for (int q = 0; q < 4 * NRB; ++q) rr[q] = (TRN && !BSM_DBG(DBG_NO_XGATHER)) ? xr[(size_t)ri[q] * CS + lc] : R(0);
+    V4 facc[NRB];
 #pragma unroll
-    for (int rb = 0; rb < NRB; ++rb) facc[rb] = v4f64{0.0, 0.0, 0.0, 0.0};
-    double pd[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int rb = 0; rb < NRB; ++rb) facc[rb] = V4{0, 0, 0, 0};
+    R pd[4] = {0, 0, 0, 0};
     int pe[4] = {0, 0, 0, 0};
     bool pok[4] = {false, false, false, false};
     for (int cb = 0; cb < ncols; cb += kIlCols) {
@@ -1872,106 +1922,140 @@ __device__ __forceinline__ void il_panel_c128(const WaveD &wd, const uint4 *__re
 #pragma unroll
         for (int q = 0; q < kIlCols / 64; ++q)
             if (q < nq) cix[q * 64 + lane] = entry(min(cb + q * 64 + lane, ncols - 1), craw[q]);
-        // entry of column w of this block (clamped into it) and whether w really is one of its columns
+        // entry of column w of this block (clamped into it)
         auto ent = [&](int w) { return cix[min(w, c_end - 1) - cb]; };
-        auto xop = [&](int t0, int j) -> double {
-            if (!FWD || BSM_DBG(DBG_NO_XGATHER)) return 0.0;
-            return xr[(size_t)(ent(t0 + 4 * j + lk) & IL_MASK) * 16 + ln];
+        // x operand of load j, column e of its strip: lane (component ln, column t0 + E (4 j + lk) + e)
+        auto xop = [&](int t0, int j, int e) -> R {
+            if (!FWD || BSM_DBG(DBG_NO_XGATHER)) return R(0);
+            return xr[(size_t)(ent(t0 + E * (4 * j + lk) + e) & IL_MASK) * CS + lc];
         };
         if (cb == 0) {
+#ifdef BSM_TRACE
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            BSM_TSTAMP(2);  // lists, x rows and the first tile are there
+#endif
 #pragma unroll
-            for (int q = 0; q < 4 * NRB; ++q) rr[q] = (trn_en && 4 * q + lk < m) ? rr[q] : 0.0;
+            for (int q = 0; q < 4 * NRB; ++q) rr[q] = (trn_en && live && 4 * q + lk < m) ? rr[q] : R(0);
         }
-        double xn[4];
+        R xn[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) xn[j] = xop(cb, j);
+        for (int j = 0; j < NLD; ++j)
+#pragma unroll
+            for (int e = 0; e < E; ++e) xn[j * E + e] = xop(cb, j, e);
+#ifdef BSM_TRACE
+        if (cb == 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            BSM_TSTAMP(3);  // first x operands arrived
+        }
+#endif
         for (int t0 = cb; t0 < c_end; t0 += 16) {
             // this tile's x operand (requested one tile ago), masked: columns beyond the block / without a forward role
-            double xq[4];
+            R xq[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int w = t0 + 4 * j + lk;
-                const int e = ent(w);  // (read unconditionally: a short-circuit around an LDS read is a branch)
-                const bool ok = fwd_en & (w < c_end) & ((e & IL_NOFWD) == 0);
-                xq[j] = ok ? xn[j] : 0.0;
+            for (int je = 0; je < 4; ++je) {
+                const int w = t0 + E * (4 * (je / E) + lk) + (je % E);
+                const int en = ent(w);  // (read unconditionally: a short-circuit around an LDS read is a branch)
+                const bool ok = fwd_en & live & (w < c_end) & ((en & IL_NOFWD) == 0);
+                xq[je] = ok ? xn[je] : R(0);
             }
             // the PREVIOUS tile's sums first (vector-memory operations retire in order: they have the whole step, and the
             // latency of the requests behind them, to complete), then the next tile's operands
             if (!BSM_DBG(DBG_NO_GLOBAL_ATOMICS)) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) il_atomic_add(&wacc[(size_t)pe[r] * 16 + ln], pd[r], pok[r]);
+                for (int r = 0; r < 4; ++r) il_atomic_add(&wacc[(size_t)pe[r] * CS + lc], pd[r], pok[r]);
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) xn[j] = xop(t0 + 16, j);
-            v4f64 dt = {0.0, 0.0, 0.0, 0.0};
+            for (int j = 0; j < NLD; ++j)
+#pragma unroll
+                for (int e = 0; e < E; ++e) xn[j * E + e] = xop(t0 + 16, j, e);
+            V4 dt = {0, 0, 0, 0};
 #pragma unroll
             for (int rb = 0; rb < NRB; ++rb) {
-                c128 b[4];
+                Vec16<T> b[NLD];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) b[j] = nb[j];
+                for (int j = 0; j < NLD; ++j) b[j] = nb[j];
                 // the next step's tile: the next row block of these columns, or the first one of the next 16 columns
 #pragma unroll
-                for (int j = 0; j < 4; ++j) nb[j] = (rb + 1 < NRB) ? mat(t0, rb + 1, j) : mat(t0 + 16, 0, j);
+                for (int j = 0; j < NLD; ++j) nb[j] = (rb + 1 < NRB) ? mat(t0, rb + 1, j) : mat(t0 + 16, 0, j);
                 if (FWD && !BSM_DBG(DBG_NO_FWD_HALF)) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const double x2 = second(xq[j]);
-                        facc[rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(b[j].re, xq[j], facc[rb], 0, 0, 0);
-                        facc[rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(b[j].im, x2, facc[rb], 0, 0, 0);
-                    }
+                    for (int j = 0; j < NLD; ++j)
+#pragma unroll
+                        for (int e = 0; e < E; ++e) {
+                            const R x1 = xq[j * E + e];
+                            facc[rb] = mfma(il_re(b[j].v[e]), x1, facc[rb]);
+                            if (CPLX) facc[rb] = mfma(il_im(b[j].v[e]), second(x1), facc[rb]);
+                        }
                 }
                 if (TRN && !BSM_DBG(DBG_NO_TRN_HALF)) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) tile[(4 * j + lk) * 17 + ln].v[0] = b[j];
+                    for (int j = 0; j < NLD; ++j)
+#pragma unroll
+                        for (int e = 0; e < E; ++e) tile[(E * (4 * j + lk) + e) * 17 + ln] = b[j].v[e];
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        const c128 u = tile[ln * 17 + 4 * q + lk].v[0];
-                        const double r1 = rr[rb * 4 + q];
-                        const double r2 = second(r1);
-                        dt = __builtin_amdgcn_mfma_f64_16x16x4f64(u.re, r1, dt, 0, 0, 0);
-                        dt = __builtin_amdgcn_mfma_f64_16x16x4f64(u.im, r2, dt, 0, 0, 0);
+                        const T u = tile[ln * 17 + 4 * q + lk];
+                        const R r1 = rr[rb * 4 + q];
+                        dt = mfma(il_re(u), r1, dt);
+                        if (CPLX) dt = mfma(il_im(u), second(r1), dt);
                     }
                 }
             }
-            // lane (component ln, lk) holds the sums of columns t0 + lk + 4 r: parked until the next step's requests are out
+            // lane (component ln, lk), register r: the sums of column t0 + accrow(r): parked until the next step
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int w = t0 + lk + 4 * r;
-                const int e = ent(w);
-                pe[r] = e & IL_MASK;
+                const int w = t0 + accrow(r);
+                const int en = ent(w);
+                pe[r] = en & IL_MASK;
                 pd[r] = dt[r];
-                pok[r] = trn_en & (w < c_end) & ((e & IL_NOTRN) == 0);
+                pok[r] = trn_en & live & (w < c_end) & ((en & IL_NOTRN) == 0);
             }
         }
     }
+#ifdef BSM_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    BSM_TSTAMP(4);  // every tile done
+#endif
     if (!BSM_DBG(DBG_NO_GLOBAL_ATOMICS)) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) il_atomic_add(&wacc[(size_t)pe[r] * 16 + ln], pd[r], pok[r]);
+        for (int r = 0; r < 4; ++r) il_atomic_add(&wacc[(size_t)pe[r] * CS + lc], pd[r], pok[r]);
     }
     if (fwd_en && !BSM_DBG(DBG_NO_FWD_OUT)) {
-        // lane (component ln, lk), register r of row block rb: row rb * 16 + lk + 4 r -- every wave adds its own partial
-        // sums (rows beyond m deliver +0.0 to row m - 1)
+        // lane (component ln, lk), register r of row block rb: row rb * 16 + accrow(r) -- every wave adds its own partial sums
 #pragma unroll
         for (int rb = 0; rb < NRB; ++rb)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int row = rb * 16 + lk + 4 * r;  // = 4 q + lk for q = 4 rb + r: the row whose index ri[q] holds
-                il_atomic_add(&wacc[(size_t)ri[4 * rb + r] * 16 + ln], facc[rb][r], row < m);
+                const int row = rb * 16 + accrow(r);
+                const int yi = F64MAP ? ri[4 * rb + r] : ro[4 * rb + r];  // (f64 map: row = 4 q + lk for q = 4 rb + r)
+                il_atomic_add(&wacc[(size_t)yi * CS + lc], facc[rb][r], live & (row < m));
             }
     }
 }
 
-template <int MRMAX, bool FWD, bool TRN>
-__global__ void __launch_bounds__(64 * kWavesPerWg, BSM_IL_WGS(MRMAX))
-    panel_kernel_il_c128(const WaveWork *__restrict__ waves, const uint4 *__restrict__ values, const int *__restrict__ rows,
-                         const int *__restrict__ cols, const double *__restrict__ xr, double *__restrict__ wacc, int flags,
-                         unsigned wg_base) {
-    __shared__ Vec16<c128> tl[kWavesPerWg][TRN ? 16 * 17 : 1];
-    __shared__ int cixs[kWavesPerWg][kIlCols];
+// WPW = waves per workgroup: 1 -- the waves of this pass share nothing (no LDS slab, no window, no barrier), and a
+// workgroup's slot is only recycled when its SLOWEST wave is done (tools/il_trace.py: 66 % of the wave slots occupied with
+// four panels of different lengths per workgroup)
+template <typename T, int MRMAX, bool FWD, bool TRN, int WPW, int CS>
+__global__ void __launch_bounds__(64 * WPW, (il_wgs<T, MRMAX>() * kWavesPerWg / WPW))
+    panel_kernel_il(const WaveWork *__restrict__ waves, const uint4 *__restrict__ values, const int *__restrict__ rows,
+                    const int *__restrict__ cols, const typename ILT<T>::R *__restrict__ xr, typename ILT<T>::R *__restrict__ wacc,
+                    int flags, unsigned wg_base) {
+    __shared__ T tl[WPW][TRN ? 16 * 17 : 1];
+    __shared__ int cixs[WPW][kIlCols];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     BSM_TSTAMP(0);  // wave started
-    const WaveD wd = load_wave(waves + ((size_t)(blockIdx.x + wg_base) * kWavesPerWg + wave));
+    // XCD-aware order (flags bit FLAG_IL_XCD): workgroups are dealt to the 8 XCDs round robin, so with the plain order
+    // eight NEIGHBOURING panels -- which read mostly the same lines of Xr and add to the same lines of W -- land in eight
+    // different L2s.  Here XCD c walks the c-th contiguous eighth of the list.
+    unsigned bid = blockIdx.x;
+    if (flags & FLAG_IL_XCD) {
+        const unsigned n8 = gridDim.x >> 3;  // (the launcher pads the grid to a multiple of 8; surplus blocks find NOP records)
+        bid = (bid & 7u) * n8 + (bid >> 3);
+    }
+    if (bid >= wg_base) return;  // wg_base: number of workgroups of the record list (re-used argument)
+    const WaveD wd = load_wave(waves + ((size_t)bid * WPW + wave));
     if (wd.work != WORK_PANEL || wd.npieces <= 0 || wd.first.ncols <= 0 || wd.m <= 0) return;
 #ifdef BSM_TRACE
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1983,61 +2067,63 @@ __global__ void __launch_bounds__(64 * kWavesPerWg, BSM_IL_WGS(MRMAX))
 #endif
     const int nrb = (wd.m + 15) >> 4;  // (wave-uniform)
     if (nrb == 1)
-        il_panel_c128<1, FWD, TRN>(wd, values, rows, cols, xr, wacc, flags, lane, tl[wave], cixs[wave]);
+        il_panel<T, 1, FWD, TRN, CS>(wd, values, rows, cols, xr, wacc, flags, lane, tl[wave], cixs[wave]);
     else if (nrb == 2 || MRMAX <= 2)
-        il_panel_c128<2, FWD, TRN>(wd, values, rows, cols, xr, wacc, flags, lane, tl[wave], cixs[wave]);
+        il_panel<T, 2, FWD, TRN, CS>(wd, values, rows, cols, xr, wacc, flags, lane, tl[wave], cixs[wave]);
     else if (nrb == 3)
-        il_panel_c128<(MRMAX > 2 ? 3 : 2), FWD, TRN>(wd, values, rows, cols, xr, wacc, flags, lane, tl[wave], cixs[wave]);
+        il_panel<T, (MRMAX > 2 ? 3 : 2), FWD, TRN, CS>(wd, values, rows, cols, xr, wacc, flags, lane, tl[wave], cixs[wave]);
     else
-        il_panel_c128<(MRMAX > 2 ? 4 : 2), FWD, TRN>(wd, values, rows, cols, xr, wacc, flags, lane, tl[wave], cixs[wave]);
+        il_panel<T, (MRMAX > 2 ? 4 : 2), FWD, TRN, CS>(wd, values, rows, cols, xr, wacc, flags, lane, tl[wave], cixs[wave]);
 #ifdef BSM_TRACE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     BSM_TSTAMP(5);  // everything stored
     if (lane == 0) t_trace[threadIdx.x >> 6][8] = wall_clock64();
     if (g_trace && lane < 16)
-        g_trace[((size_t)blockIdx.x * kWavesPerWg + (threadIdx.x >> 6)) * 16 + lane] = t_trace[threadIdx.x >> 6][lane];
+        g_trace[((size_t)blockIdx.x * WPW + (threadIdx.x >> 6)) * 16 + lane] = t_trace[threadIdx.x >> 6][lane];
 #endif
 }
 
-// Xr[i][2 k .. 2 k + 1] = alpha * X[i + kc(k) * ldx] (k >= kact: the last active column again, as the padded passes read it):
-// 256 rows per workgroup, read down the columns of X, written along the lines of Xr (LDS transposition, row stride 9 units)
-__global__ void __launch_bounds__(256) il_pack_kernel_c128(const c128 *__restrict__ x, long long ldx, long long n, c128 alpha, int kact,
-                                                           c128 *__restrict__ xr) {
-    __shared__ c128 s[256 * 9];
+// Xr[i][k] = alpha * X[i + kc(k) * ldx], k < KK (k >= kact: the last active column again, as the padded passes read it):
+// 256 rows per workgroup, read down the columns of X, written along the lines of Xr (LDS transposition, row stride KK + 1)
+template <typename T, int KK>
+__global__ void __launch_bounds__(256) il_pack_kernel(const T *__restrict__ x, long long ldx, long long n, T alpha, int kact,
+                                                      T *__restrict__ xr) {
+    __shared__ T s[256 * (KK + 1)];
     const long long r0 = (long long)blockIdx.x * 256;
     const int t = threadIdx.x;
     if (r0 + t < n) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) s[t * 9 + k] = mul(alpha, x[r0 + t + (long long)(k < kact ? k : kact - 1) * ldx]);
+        for (int k = 0; k < KK; ++k) s[t * (KK + 1) + k] = mul(alpha, x[r0 + t + (long long)(k < kact ? k : kact - 1) * ldx]);
     }
     __syncthreads();
-    const long long cnt = (n - r0 < 256 ? n - r0 : 256) * 8;
+    const long long cnt = (n - r0 < 256 ? n - r0 : 256) * KK;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
+    for (int j = 0; j < KK; ++j) {
         const int idx = j * 256 + t;
-        if (idx < cnt) xr[r0 * 8 + idx] = s[(idx >> 3) * 9 + (idx & 7)];
+        if (idx < cnt) xr[r0 * KK + idx] = s[(idx / KK) * (KK + 1) + (idx % KK)];
     }
 }
 // Y[i + k * ldy] = (strong zero ? 0 : beta * Y) + W[i][k] for i in [lo, hi), k < kact;  W[i][:] = 0 behind the read
-__global__ void __launch_bounds__(256) il_finish_kernel_c128(c128 *__restrict__ y, long long ldy, long long lo, long long hi, c128 beta,
-                                                             int strong_zero, int kact, c128 *__restrict__ wacc) {
-    __shared__ c128 s[256 * 9];
+template <typename T, int KK>
+__global__ void __launch_bounds__(256) il_finish_kernel(T *__restrict__ y, long long ldy, long long lo, long long hi, T beta,
+                                                        int strong_zero, int kact, T *__restrict__ wacc) {
+    __shared__ T s[256 * (KK + 1)];
     const long long r0 = lo + (long long)blockIdx.x * 256;
     const int t = threadIdx.x;
-    const long long cnt = (hi - r0 < 256 ? hi - r0 : 256) * 8;
+    const long long cnt = (hi - r0 < 256 ? hi - r0 : 256) * KK;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
+    for (int j = 0; j < KK; ++j) {
         const int idx = j * 256 + t;
         if (idx < cnt) {
-            s[(idx >> 3) * 9 + (idx & 7)] = wacc[r0 * 8 + idx];
-            wacc[r0 * 8 + idx] = c128{0.0, 0.0};
+            s[(idx / KK) * (KK + 1) + (idx % KK)] = wacc[r0 * KK + idx];
+            wacc[r0 * KK + idx] = zero_of(T{});
         }
     }
     __syncthreads();
     if (r0 + t < hi) {
         for (int k = 0; k < kact; ++k) {
-            c128 *yp = &y[r0 + t + (long long)k * ldy];
-            const c128 v = s[t * 9 + k];
+            T *yp = &y[r0 + t + (long long)k * ldy];
+            const T v = s[t * (KK + 1) + k];
             *yp = strong_zero ? v : madd(v, beta, *yp);
         }
     }
@@ -2321,9 +2407,10 @@ static hipError_t launch_typed_multi(const DeviceImage &img, bool opT, bool conj
     return hipGetLastError();
 }
 
-// ---- the interleaved pass (panel_kernel_il_c128): policy and launch ---------------------------------------
-// BSM_MULTI_IL: 0 = never, 1 = automatic (default: ComplexF64 images of short panels -- mean group height below 32 --
-// that accumulate with atomics), 2 = every ComplexF64 image that accumulates with atomics (A / B)
+// ---- the interleaved pass (panel_kernel_il): policy and launch ---------------------------------------------
+// BSM_MULTI_IL: 0 = never, 1 = automatic (default: images that accumulate with atomics -- short scattered panels, mean
+// group height below 32, in every element type; ComplexF64 / ComplexF32 from BSM_MFMA_MIN_COLS columns on, real types
+// from BSM_IL_REAL_MIN_COLS), 2 = every image that accumulates with atomics (A / B)
 static int il_mode() {
     static const int v = [] {
         const char *e = std::getenv("BSM_MULTI_IL");
@@ -2338,15 +2425,31 @@ static int mfma_min_cols() {
     }();
     return v;
 }
+static int il_real_min_cols() {
+    static const int v = [] {
+        const char *e = std::getenv("BSM_IL_REAL_MIN_COLS");
+        // (8 components per index from 5 columns on: BEM fp64 x 8 318 -> 202 us, C3 x 8 256 -> 217 us; 4 columns stay on the
+        // vector kernels: BEM 194 us, C3 195 us against ~ 200 / 217)
+        return e ? std::atoi(e) : 5;
+    }();
+    return v;
+}
 bool il_applies(const DeviceImage &img, bool opT, long long nrhs) {
-    if (img.dtype != 3 || il_mode() == 0 || nrhs < mfma_min_cols()) return false;
+    const bool cplx = img.dtype >= 2;
+    if (il_mode() == 0 || nrhs < (cplx ? mfma_min_cols() : il_real_min_cols())) return false;
     if (!opT && img.exclusive_fwd) return false;   // plain stores with beta fused: nothing to gain
     if (!img.color_wg_ptr.empty()) return false;   // coloured launches keep their bitwise reproducible read-modify-write
     if (std::max(img.nrows, img.ncols) >= (1ll << 30)) return false;  // (staged entries carry two role bits)
-    return il_mode() == 2 || img.mean_rows < 32.f;
+    // automatic: short scattered panels in every type; real types whatever the panels' height (16 right-hand sides fill the
+    // tile: C3 x 16 377 -> 305 us, C5 slice x 16 1607 -> 1131 us; complex types over tall panels: not measured -- no
+    // complex large-block operator among the configurations)
+    return il_mode() == 2 || img.mean_rows < 32.f || !cplx;
 }
-static hipError_t launch_il_c128(const DeviceImage &img, bool opT, bool conj, const c128 *xd, long long ldx, c128 *yd, long long ldy,
-                                 c128 alpha, c128 beta, int strong_zero, hipStream_t stream, int kact, ILWork &il) {
+template <typename T, int KK>
+static hipError_t launch_il(const DeviceImage &img, bool opT, bool conj, const T *xd, long long ldx, T *yd, long long ldy, T alpha,
+                            T beta, int strong_zero, hipStream_t stream, int kact, ILWork &il) {
+    using R = typename ILT<T>::R;
+    constexpr int CS = ILT<T>::CPLX ? 2 * KK : KK;  // components per vector index (8 or 16)
     const long long xlen = opT ? img.nrows : img.ncols, ylen = opT ? img.ncols : img.nrows;
     if (xlen > il.rows || ylen > il.rows) return hipErrorInvalidValue;
     int flags = 0;
@@ -2360,33 +2463,51 @@ static hipError_t launch_il_c128(const DeviceImage &img, bool opT, bool conj, co
     il.w_clean = false;  // (until the finish pass has been enqueued)
     if (e != hipSuccess) return e;
     if (xlen > 0)
-        hipLaunchKernelGGL(il_pack_kernel_c128, dim3((unsigned)((xlen + 255) / 256)), dim3(256), 0, stream, xd, ldx, xlen, alpha, kact,
-                           (c128 *)il.xr);
+        hipLaunchKernelGGL((il_pack_kernel<T, KK>), dim3((unsigned)((xlen + 255) / 256)), dim3(256), 0, stream, xd, ldx, xlen, alpha,
+                           kact, (T *)il.xr);
     const WaveWork *waves = (const WaveWork *)(img.d_waves_multi ? img.d_waves_multi : img.d_waves);
     const long long nwg = img.d_waves_multi ? img.nwg_multi : img.nwg_main;
     const uint4 *values = (const uint4 *)img.d_values;
     const int *rows = (const int *)img.d_rows, *cols = (const int *)img.d_cols;
-    const double *xr = (const double *)il.xr;
-    double *w = (double *)il.w;
+    const R *xr = (const R *)il.xr;
+    R *w = (R *)il.w;
     if (nwg > 0) {
-        const dim3 grid((unsigned)nwg), block(64 * kWavesPerWg);
+        // BSM_IL_WPW = 1: one wave per workgroup (a workgroup's slot is recycled only when its slowest wave is done --
+        // tools/il_trace.py: 66 % of the slots occupied).  Measured: +-0 on the BEM fixture in every type (367 / 208 /
+        // 352 us at 4, 373 / 212 / 354 at 1): the pass is bound by its vector-side requests, not by slots.
+        static const int wpw = [] {
+            const char *v = std::getenv("BSM_IL_WPW");
+            return v && std::atoi(v) == 1 ? 1 : 4;
+        }();
+        // BSM_IL_XCD = 1: XCD-aware workgroup order.  Measured: +-0 too (367 / 204 / 359 us against 374 / 208 / 352).
+        static const int xcd = [] {
+            const char *v = std::getenv("BSM_IL_XCD");
+            return v ? std::atoi(v) : 0;
+        }();
+        const unsigned nblk = (unsigned)(nwg * (kWavesPerWg / wpw));
+        if (xcd) flags |= FLAG_IL_XCD;
+        const dim3 grid(xcd ? (nblk + 7u) / 8u * 8u : nblk), block(64 * wpw);
         const bool small = img.max_rows <= 32;
-#define BSM_IL_LAUNCH(MR)                                                                                                       \
-    do {                                                                                                                        \
-        if (!opT && !img.has_off)                                                                                               \
-            hipLaunchKernelGGL((panel_kernel_il_c128<MR, true, false>), grid, block, 0, stream, waves, values, rows, cols, xr, w, \
-                               flags, 0u);                                                                                      \
-        else if (img.has_off)                                                                                                   \
-            hipLaunchKernelGGL((panel_kernel_il_c128<MR, true, true>), grid, block, 0, stream, waves, values, rows, cols, xr, w,  \
-                               flags, 0u);                                                                                      \
-        else                                                                                                                    \
-            hipLaunchKernelGGL((panel_kernel_il_c128<MR, false, true>), grid, block, 0, stream, waves, values, rows, cols, xr, w, \
-                               flags, 0u);                                                                                      \
+#define BSM_IL_LAUNCH(MR, WPW)                                                                                                     \
+    do {                                                                                                                           \
+        if (!opT && !img.has_off)                                                                                                  \
+            hipLaunchKernelGGL((panel_kernel_il<T, MR, true, false, WPW, CS>), grid, block, 0, stream, waves, values, rows, cols, xr, w,  \
+                               flags, nblk);                                                                                        \
+        else if (img.has_off)                                                                                                      \
+            hipLaunchKernelGGL((panel_kernel_il<T, MR, true, true, WPW, CS>), grid, block, 0, stream, waves, values, rows, cols, xr, w,   \
+                               flags, nblk);                                                                                        \
+        else                                                                                                                       \
+            hipLaunchKernelGGL((panel_kernel_il<T, MR, false, true, WPW, CS>), grid, block, 0, stream, waves, values, rows, cols, xr, w,  \
+                               flags, nblk);                                                                                        \
     } while (0)
-        if (small)
-            BSM_IL_LAUNCH(2);
+        if (small && wpw == 1)
+            BSM_IL_LAUNCH(2, 1);
+        else if (small)
+            BSM_IL_LAUNCH(2, 4);
+        else if (wpw == 1)
+            BSM_IL_LAUNCH(4, 1);
         else
-            BSM_IL_LAUNCH(4);
+            BSM_IL_LAUNCH(4, 4);
 #undef BSM_IL_LAUNCH
     }
     // Y = beta * Y + W over the rows this handle scales (all of them for op T / C), Y += W elsewhere; W = 0 behind
@@ -2395,11 +2516,11 @@ static hipError_t launch_il_c128(const DeviceImage &img, bool opT, bool conj, co
         lo = img.own_lo;
         hi = img.own_hi;
     }
-    const c128 one = make_scalar<c128>(1.0);
-    auto finish = [&](long long a, long long b, c128 bt, int sz) {
+    const T one = make_scalar<T>(1.0);
+    auto finish = [&](long long a, long long b, T bt, int sz) {
         if (b > a)
-            hipLaunchKernelGGL(il_finish_kernel_c128, dim3((unsigned)((b - a + 255) / 256)), dim3(256), 0, stream, yd, ldy, a, b, bt, sz,
-                               kact, (c128 *)il.w);
+            hipLaunchKernelGGL((il_finish_kernel<T, KK>), dim3((unsigned)((b - a + 255) / 256)), dim3(256), 0, stream, yd, ldy, a, b, bt,
+                               sz, kact, (T *)il.w);
     };
     finish(0, lo, one, 0);
     finish(lo, hi, beta, strong_zero);
@@ -2433,14 +2554,25 @@ static hipError_t launch_multi_typed(const DeviceImage &img, bool opT, bool conj
     // padded pass against an 8-column pass + a single product).  Short scattered panels (the BEM fixture: mean group
     // height below 32) gain nothing below 15 columns: their passes are bound by the x gather and the atomics, which
     // grow with the padded width (fp64 x 16: 615 us against 2 x 320).  BSM_MFMA_REAL_MIN_COLS overrides (17: off).
-    if constexpr (std::is_same<T, c128>::value) {
-        // ComplexF64 over short scattered panels: the interleaved pass (above), batches of 8 and one padded remainder
-        if (il && !zrange && il_applies(img, opT, nrhs)) {
-            while (e == hipSuccess && nrhs - k >= mfma_min_cols()) {
-                const int kact = (int)std::min<long long>(8, nrhs - k);
-                e = launch_il_c128(img, opT, conj, xd + k * ldx, ldx, yd + k * ldy, ldy, alpha, beta, strong_zero, stream, kact, *il);
-                k += kact;
+    // short scattered panels: the interleaved pass (above) -- complex types in batches of 8 columns, real types of 16,
+    // then one padded remainder
+    if (il && !zrange && il_applies(img, opT, nrhs)) {
+        constexpr int KK = ILT<T>::KK;
+        const int least = ILT<T>::CPLX ? mfma_min_cols() : il_real_min_cols();
+        while (e == hipSuccess && nrhs - k >= least) {
+            const int kact = (int)std::min<long long>(KK, nrhs - k);
+            if constexpr (!ILT<T>::CPLX) {
+                if (kact <= 8)  // real types, at most 8 columns left: 8 components per index (64-byte lines)
+                    e = launch_il<T, 8>(img, opT, conj, xd + k * ldx, ldx, yd + k * ldy, ldy, alpha, beta, strong_zero, stream, kact, *il);
+                else
+                    e = launch_il<T, 16>(img, opT, conj, xd + k * ldx, ldx, yd + k * ldy, ldy, alpha, beta, strong_zero, stream, kact, *il);
+            } else {
+                if (kact <= 4)  // complex types, at most 4 columns left: 8 components per index likewise
+                    e = launch_il<T, 4>(img, opT, conj, xd + k * ldx, ldx, yd + k * ldy, ldy, alpha, beta, strong_zero, stream, kact, *il);
+                else
+                    e = launch_il<T, 8>(img, opT, conj, xd + k * ldx, ldx, yd + k * ldy, ldy, alpha, beta, strong_zero, stream, kact, *il);
             }
+            k += kact;
         }
     }
     if constexpr (kMfmaReal<T, 16>) {

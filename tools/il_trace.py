@@ -63,4 +63,4 @@ ev = np.concatenate([np.stack([us[:, 0], np.ones(len(us))], 1), np.stack([us[:, 
 ev = ev[np.argsort(ev[:, 0])]
 res = np.cumsum(ev[:, 1])
 dur = np.diff(ev[:, 0], append=ev[-1, 0])
-print(f"  resident waves (time-weighted mean) {np.sum(res * dur) / np.sum(dur):.0f} of {256 * 16} slots at 4 per SIMD")
+print(f"  resident waves (time-weighted mean) {np.sum(res * dur) / np.sum(dur):.0f}")

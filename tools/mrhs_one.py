@@ -18,12 +18,15 @@ def bem(tiles, dtype, part):
     prob = dict(kind="symmetric", diagonals=p["diagonals"] * tiles, diagonalindices=tile(p["diagonalindices"]),
                 offdiagonals=p["offdiagonals"] * tiles, rowindices=tile(p["rowindices"]), colindices=tile(p["colindices"]),
                 size=(n0 * tiles, n0 * tiles))
-    xh = np.random.default_rng(0).standard_normal(n0 * tiles) + 1j * np.random.default_rng(1).standard_normal(n0 * tiles)
+    xh = np.random.default_rng(0).standard_normal(n0 * tiles)
+    if np.dtype(dtype).kind == "c":
+        xh = xh + 1j * np.random.default_rng(1).standard_normal(n0 * tiles)
     prob["x"] = torch.from_numpy(xh.astype(dtype)).cuda()
     return prob
 
 
 prob = {"bem_c128": lambda: bem(400, np.complex128, "full"), "bem_c64": lambda: bem(400, np.complex64, "full"),
+        "bem_f64": lambda: bem(400, np.float64, "real"), "bem_f32": lambda: bem(400, np.float32, "real"),
         "c2": lambda: S.config2(on_device=True), "c3": lambda: S.config3(on_device=True),
         "c2x20": lambda: S.config2(n=2_000_000, nblocks=100_000, on_device=True),
         "c4s": lambda: S.config4(on_device=True, row_lo=0, row_hi=1953),
