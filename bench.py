@@ -258,10 +258,13 @@ def leg(bsm, torch, prob, reps, multi_rhs=0, **kw):
         torch.cuda.synchronize()
         out[key] = {"nrhs": K, "us": round(tk * 1e6, 2), "single_products": round(tk / t, 3),
                     "relerr_vs_single_products": worst}
-        if x.dtype.is_complex and K == 8:  # (csrc/bsm_kernels.hip: kMfmaPath / kMfmaPath32; counters: profiles/r04_multirhs_mfma_counters.txt)
-            out[key]["pipe"] = "matrix pipe: 8 complex columns = N = 16 of v_mfma_%s_16x16x4" % ("f64" if x.dtype == torch.complex128 else "f32")
-        if not x.dtype.is_complex and K == 16:  # (kMfmaReal)
-            out[key]["pipe"] = "matrix pipe: 16 real columns = N = 16 of v_mfma_%s_16x16x4" % ("f64" if x.dtype == torch.float64 else "f32")
+        # (csrc/bsm_kernels.hip: panel_kernel_il -- the interleaved pass wherever the product accumulates with atomics;
+        # exclusive VBCRS products keep kMfmaReal / the vector kernels; counters: profiles/r05_il_counters.txt)
+        mf = "f64" if x.dtype in (torch.complex128, torch.float64) else "f32"
+        if x.dtype.is_complex and K == 8:
+            out[key]["pipe"] = "matrix pipe: 8 complex columns = N = 16 of v_mfma_%s_16x16x4; X and Y row-major in work arrays (interleaved pass)" % mf
+        if not x.dtype.is_complex and K in (8, 16):
+            out[key]["pipe"] = "matrix pipe: %d real columns in N = 16 of v_mfma_%s_16x16x4 (interleaved pass where the product accumulates with atomics)" % (K, mf)
         del X, Y
     del plan, A
     return out, y
@@ -1060,7 +1063,7 @@ def run_c2(args, bsm, torch, dist, np, rank, world, barrier, reduce_scalars):
         for tname, dtn, part, tol in BEM_TYPES:
             try:
                 bp, fx, n0 = bem_tiled_problem(torch, np, 400, dtn, part)
-                one, yb = leg(bsm, torch, bp, 50, multi_rhs=8 if tname in ("c128", "f64", "c64") else 0)
+                one, yb = leg(bsm, torch, bp, 50, multi_rhs=8)
                 one["dtype"] = tname
                 # parity of the leg: tile 0 of y against the fixture's own product through an independent COO sum
                 ref = fixture_coo(np, fx, n0) @ bp["x"][:n0].cpu().numpy().astype(np.complex128 if np.dtype(dtn).kind == "c" else np.float64)

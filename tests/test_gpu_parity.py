@@ -386,6 +386,74 @@ def test_multi_rhs_real_fused_and_transposed_tile_pipeline(torch_cuda, bsm, orac
     _check_multi(torch_cuda, bsm, oracle, v, bsm.synthetic.build(v), dtype, nrhs_list=(8,), ops=[T])
 
 
+def test_multi_rhs_interleaved_pass_state_and_ownership(torch_cuda, bsm, oracle):
+    """The interleaved multi-RHS pass (csrc/bsm_kernels.hip: panel_kernel_il -- X and the accumulated Y row-major in work
+    arrays of the handle, csrc/bsm_capi.cpp: ILClaim): what the oracle comparisons of the other multi-RHS tests do not
+    reach --
+      * the work arrays are kept and re-used: alternating ops, batch widths and component counts (8 / 16 per index) on ONE
+        handle, rectangular operator (x and y of different lengths), the accumulator must be zero again after every pass;
+      * one product in flight per handle: two streams issuing on the same handle without synchronisation -- the one that
+        does not get the claim takes the ordinary kernels -- both against the oracle;
+      * a handle that owns a row range (bsm_options.own_lo / own_hi): beta applies to the owned rows only, rows outside it
+        that blocks reach receive their sums on top of what was there (the single product's semantics)."""
+    torch = torch_cuda
+    rng = np.random.default_rng(31)
+    # rectangular BlockSparseMatrix with index lists, complex: atomics in both directions
+    nr, nc, nb = 700, 1100, 60
+    blocks, ri, ci = [], [], []
+    for b in range(nb):
+        m_, n_ = int(rng.integers(3, 30)), int(rng.integers(2, 70))
+        blocks.append(np.asfortranarray(rng.standard_normal((m_, n_)) + 1j * rng.standard_normal((m_, n_))))
+        ri.append(np.sort(rng.choice(nr, m_, replace=False)) + 1)
+        ci.append(rng.choice(nc, n_, replace=False) + 1)
+    p = dict(kind="blocksparse", blocks=blocks, rowindices=ri, colindices=ci, size=(nr, nc))
+    A = bsm.synthetic.build(p)
+    for op, k in ((N, 8), (T, 3), (Cc, 8), (N, 2), (T, 13), (N, 4), (Cc, 5), (N, 8)):
+        xl, yl = (nc, nr) if op == N else (nr, nc)
+        X = np.asfortranarray(rng.standard_normal((xl, k)) + 1j * rng.standard_normal((xl, k)))
+        Y0 = np.asfortranarray(rng.standard_normal((yl, k)) + 1j * rng.standard_normal((yl, k)))
+        Xd, Yd = torch.from_numpy(X.T.copy()).cuda().t(), torch.from_numpy(Y0.T.copy()).cuda().t()
+        bsm.mul(Yd, wrap(bsm, A, op), Xd, 0.5 - 1j, 2j)
+        torch.cuda.synchronize()
+        ref = np.stack([oracle_mul(oracle, p, op, X[:, j].copy(), Y0[:, j].copy(), 0.5 - 1j, 2j, False) for j in range(k)], axis=1)
+        assert relerr(Yd.cpu().numpy().ravel(), ref.ravel()) < 1e-12, (op, k)
+    # two streams, one handle, no synchronisation in between
+    f = fixture_problem("cuboid")
+    F = bsm.synthetic.build(f)
+    n = f["size"][0]
+    Xs = [np.asfortranarray(rng.standard_normal((n, 8)) + 1j * rng.standard_normal((n, 8))) for _ in range(2)]
+    Xd = [torch.from_numpy(x.T.copy()).cuda().t() for x in Xs]
+    Yd = [torch.full((8, n), float("nan"), dtype=torch.complex128, device="cuda").t() for _ in range(2)]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    torch.cuda.synchronize()
+    for rep in range(6):
+        for q in range(2):
+            with torch.cuda.stream(streams[q]):
+                bsm.mul(Yd[q], F, Xd[q])
+    torch.cuda.synchronize()
+    for q in range(2):
+        ref = np.stack([oracle_mul(oracle, f, N, Xs[q][:, j].copy(), np.zeros(n, np.complex128)) for j in range(8)], axis=1)
+        assert relerr(Yd[q].cpu().numpy().ravel(), ref.ravel()) < 1e-12, q
+    # a handle that owns the middle rows only
+    s_ = bsm.synthetic.config5(n=9000, lo=8, hi=40, halfband=3)
+    n = s_["size"][0]
+    own = (3001, 6000)
+    S = bsm.synthetic.build(s_, own=own)
+    for k in (8, 16, 5):
+        X = np.asfortranarray(rng.standard_normal((n, k)))
+        Y0 = np.asfortranarray(rng.standard_normal((n, k)))
+        Xd, Yd = torch.from_numpy(X.T.copy()).cuda().t(), torch.from_numpy(Y0.T.copy()).cuda().t()
+        bsm.mul(Yd, S, Xd, 0.75, -1.5)
+        torch.cuda.synchronize()
+        got = Yd.cpu().numpy()
+        for j in range(k):  # the single product through the same handle defines the semantics outside the owned range
+            y1 = torch.from_numpy(Y0[:, j].copy()).cuda()
+            bsm.mul(y1, S, torch.from_numpy(X[:, j].copy()).cuda(), 0.75, -1.5)
+            assert relerr(got[:, j], y1.cpu().numpy()) < 1e-12, (k, j)
+        ref = oracle_mul(oracle, s_, N, X[:, 0].copy(), Y0[:, 0].copy(), 0.75, -1.5, False)
+        assert relerr(got[own[0] - 1:own[1], 0], ref[own[0] - 1:own[1]]) < 1e-12
+
+
 @pytest.mark.parametrize("kind", ["symmetric", "vbcrs", "fixture"])
 def test_multi_rhs_padded_batches_touch_only_their_columns(torch_cuda, bsm, oracle, kind):
     """2, 3 and 5-7 right-hand sides run as PADDED 4- / 8-column passes (idle slots repeat the last column and
