@@ -41,9 +41,9 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("OMP_NUM_THREADS", str(min(len(os.sched_getaffinity(0)), 16)))
 
 HBM_PEAK_GBPS = 8000.0  # MI355X spec (MI355X_MICROARCH.md); measured-copy ceiling 6290
-PMC_FILE = os.path.join(ROOT, "profiles", "r04_c2_pmc.json")  # written by tools/pmc_summary.py, stamped with the build id
-MFMA_FILE = os.path.join(ROOT, "profiles", "r04_c4_mfma.json")
-C5N1_FILE = os.path.join(ROOT, "profiles", "r04_c5_n1.json")  # the N > 1 workload on ONE GPU (tools/profile_round.sh)
+PMC_FILE = os.path.join(ROOT, "profiles", "r05_c2_pmc.json")  # written by tools/pmc_summary.py, stamped with the build id
+MFMA_FILE = os.path.join(ROOT, "profiles", "r05_c4_mfma.json")
+C5N1_FILE = os.path.join(ROOT, "profiles", "r05_c5_n1.json")  # the N > 1 workload on ONE GPU (tools/profile_round.sh)
 ORACLE_SAMPLES = 48  # sampled block rows per rank of the full-size oracle check of the partitioned workloads
 SETUP_STEPS = 30    # N > 1 / --workload c5: untimed steps of a freshly built operator before the W warm-up steps (config.setup_steps)
 MIN_TIMED_S = 5e-3  # a timed region shorter than this is repeated (config.replays) so that host synchronisation stays below 1 %
@@ -524,9 +524,14 @@ def run_partitioned(args, bsm, torch, dist, np, rank, world, barrier, reduce_sca
         # find no free CU beside a launch that fills the chip and would finish when the launch does: DESIGN.md 5b)
         reserve = int(os.environ.get("BSM_RESERVE_CUS", "8")) if (overlap and dist is not None and comm["name"] == "nccl") else 0
         if reserve:
-            torch.cuda.synchronize()
-            prev_stream = torch.cuda.current_stream()
-            torch.cuda.set_stream(D.compute_stream(reserve=reserve))
+            try:
+                cs = D.compute_stream(reserve=reserve)
+                torch.cuda.synchronize()
+                prev_stream = torch.cuda.current_stream()
+                torch.cuda.set_stream(cs)
+            except Exception as e:  # (a stream with a CU mask is an optimisation: without it the step is measured all the same)
+                print("[bench] no compute stream with reserved CUs (%r): the products run on the current stream" % (e,), file=sys.stderr, flush=True)
+                reserve = 0
         try:
             r = run_on_current_stream(share, steps, warmup, overlap)
         finally:
