@@ -52,6 +52,7 @@ CASES = {
     "bem_c128": lambda: bem(400, np.complex128, "full"),
     "bem_c64": lambda: bem(400, np.complex64, "full"),
     "bem_f64": lambda: bem(400, np.float64, "real"),
+    "bem_f32": lambda: bem(400, np.float32, "real"),
 }
 names = sys.argv[1:] or list(CASES)
 for name in names:

@@ -102,7 +102,7 @@ say "interleaved multi-RHS pass: counters, ablations, wave timeline"
 { python3 tools/ablate_multi.py bem_c128 8 2> /dev/null | tail -14; python3 tools/ablate_multi.py bem_c64 8 2> /dev/null | tail -14; python3 tools/ablate_multi.py bem_f64 8 2> /dev/null | tail -14; python3 tools/ablate_multi.py bem_f64 16 2> /dev/null | tail -14
   echo; echo "(tools/ablate_multi.py on the experiment build; the times include the pack and finish passes of the interleaved pass: 24 + 30 us ComplexF64, see r05_il_counters.txt)"; } > $O/r05_il_ablation.txt
 { BSM_LIB=$R/blocksparsematrices.jl_amd/libbsmrocm_trace.so python3 tools/il_trace.py bem_c128 8 2> /dev/null | tail -10; BSM_LIB=$R/blocksparsematrices.jl_amd/libbsmrocm_trace.so python3 tools/il_trace.py bem_c64 8 2> /dev/null | tail -10; } > $O/r05_il_wavetrace.txt
-{ echo "BSM_MULTI_IL=0 (the round-4 kernels):"; BSM_MULTI_IL=0 python3 tools/multirhs.py bem_c128 bem_c64 bem_f64 c3 c5s 2> /dev/null | grep rhs; echo "default (interleaved pass):"; python3 tools/multirhs.py bem_c128 bem_c64 bem_f64 c3 c5s 2> /dev/null | grep rhs; } > $O/r05_il_ab.txt
+{ echo "BSM_MULTI_IL=0 (the round-4 kernels):"; BSM_MULTI_IL=0 python3 tools/multirhs.py bem_c128 bem_c64 bem_f64 bem_f32 c3 c3_f32 c5s 2> /dev/null | grep rhs; echo "default (interleaved pass):"; python3 tools/multirhs.py bem_c128 bem_c64 bem_f64 bem_f32 c3 c3_f32 c5s 2> /dev/null | grep rhs; } > $O/r05_il_ab.txt
 say "one-rank RCCL loopback of the N > 1 step"
 { for a in "0 1" "8 1"; do python3 tools/loopback_trace.py 0.125 nccl $a 2>&1 | grep "rows\|compute\|first"; done; } > $O/r05_loopback_first_steps.txt
 cd /tmp
