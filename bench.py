@@ -331,6 +331,23 @@ def self_launch(args):
     return (rc or 3) if '"value_invalid": true' in line else 0
 
 
+class stdout_to_stderr:
+    """RCCL prints a version banner ("RCCL version : ...", five lines) on STDOUT when its first communicator is created; this
+    script's stdout carries ONE JSON line.  File descriptor 1 points at stderr while a process group is being set up."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+        return False
+
+
 def init_one_rank(backend, torch, dev_index):
     """torch.distributed with ONE rank (the loopback rehearsal): own rendezvous on 127.0.0.1"""
     import datetime
@@ -349,7 +366,11 @@ def init_one_rank(backend, torch, dev_index):
     if backend == "nccl":
         from bsm_amd import distributed as D
         kw = {"device_id": torch.device("cuda", dev_index), "pg_options": D.nccl_options()}
-    dist.init_process_group(backend, rank=0, world_size=1, timeout=datetime.timedelta(minutes=5), **kw)
+    with stdout_to_stderr():
+        dist.init_process_group(backend, rank=0, world_size=1, timeout=datetime.timedelta(minutes=5), **kw)
+        if backend == "nccl":  # (the communicator -- and its banner -- may be created lazily, at the first collective)
+            dist.barrier()
+            torch.cuda.synchronize()
     return dist
 
 
@@ -418,14 +439,15 @@ def main():
     if world > 1:
         import datetime
         import torch.distributed as dist
-        if args.backend == "nccl":
-            from bsm_amd import distributed as D
-            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index), pg_options=D.nccl_options(),
-                                    timeout=datetime.timedelta(minutes=5))
-        else:
-            dist.init_process_group(args.backend)
-            comm["dev"] = "cpu"
-        comm["fallback"] = dist.new_group(backend="gloo", timeout=datetime.timedelta(minutes=5))
+        with stdout_to_stderr():
+            if args.backend == "nccl":
+                from bsm_amd import distributed as D
+                dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index), pg_options=D.nccl_options(),
+                                        timeout=datetime.timedelta(minutes=5))
+            else:
+                dist.init_process_group(args.backend)
+                comm["dev"] = "cpu"
+            comm["fallback"] = dist.new_group(backend="gloo", timeout=datetime.timedelta(minutes=5))
         seen = [None] * world
         dist.all_gather_object(seen, "rank %d: cuda:%d %s" % (rank, dev_index, torch.cuda.get_device_name(dev_index)),
                                group=comm["fallback"])
