@@ -1747,10 +1747,13 @@ __global__ void __launch_bounds__(64 * kWavesPerWg, ((kMfmaPath32<T, K> || (kMfm
 // ----------------------------------------------------------------------------------------
 // resident workgroups per CU the interleaved kernels are compiled for (their natural register need, fused instances:
 // Float32 / ComplexF32 90-92 VGPRs with two row blocks, 125 with four; Float64 122 / 163; ComplexF64 143 / 199)
+#ifndef BSM_IL_C128_WGS
+#define BSM_IL_C128_WGS 3
+#endif
 template <typename T, int MRMAX> constexpr int il_wgs() {
     return (sizeof(T) == 4 || sizeof(T) == 8 && !std::is_same<T, double>::value) ? (MRMAX <= 2 ? 5 : 4)
            : std::is_same<T, double>::value                                       ? (MRMAX <= 2 ? 4 : 3)
-                                                                                   : (MRMAX <= 2 ? 3 : 2);
+                                                                                   : (MRMAX <= 2 ? BSM_IL_C128_WGS : 2);
 }
 constexpr int kIlCols = 256;            // columns of a panel staged per refill of the index list
 constexpr int IL_NOFWD = 1 << 30;       // staged column entry: takes no part in the forward half
