@@ -2443,12 +2443,13 @@ bool il_applies(const DeviceImage &img, bool opT, long long nrhs) {
     if (!opT && img.exclusive_fwd) return false;   // plain stores with beta fused: nothing to gain
     if (!img.color_wg_ptr.empty()) return false;   // coloured launches keep their bitwise reproducible read-modify-write
     if (std::max(img.nrows, img.ncols) >= (1ll << 30)) return false;  // (staged entries carry two role bits)
-    // automatic: short scattered panels in every type; real types over tall panels where the product is FUSED (symmetric
-    // operators: both halves, the transposed one all atomics -- C3 x 16 377 -> 305 us, x 8 264 -> 220, C5 slice x 16 1607 ->
-    // 1131).  Forward-only products of tall panels keep their kernels: on the C4 slice (128 x 128 fp32 blocks of one GPU of
-    // eight, vectors of the full 2 M entries) the pass's two vector sweeps cost more than it saves (x 8 363 -> 457 us,
-    // x 16 453 -> 562).  Complex types over tall panels: not measured -- no such operator among the configurations.
-    return il_mode() == 2 || img.mean_rows < 32.f || (!cplx && img.has_off);
+    // automatic: short scattered panels, and tall panels where the product is FUSED (symmetric operators: both halves, the
+    // transposed one all atomics -- C3 x 16 377 -> 305 us, x 8 264 -> 220, C5 slice x 16 1607 -> 1131; the C3 structure with
+    // complex entries, tools/c3_complex.py: ComplexF64 x 8 175 -> 138 us, ComplexF32 76 -> 63).  Forward-only products of
+    // tall panels keep their kernels: on the C4 slice (128 x 128 fp32 blocks of one GPU of eight, vectors of the full 2 M
+    // entries) the pass's two vector sweeps cost more than it saves (x 8 363 -> 457 us, x 16 453 -> 562).
+    (void)cplx;
+    return il_mode() == 2 || img.mean_rows < 32.f || img.has_off;
 }
 template <typename T, int KK>
 static hipError_t launch_il(const DeviceImage &img, bool opT, bool conj, const T *xd, long long ldx, T *yd, long long ldy, T alpha,
