@@ -581,7 +581,10 @@ __device__ __forceinline__ T run_panel(const WaveD &wd, const uint4 *__restrict_
                 // kernels and lost every time (tiled BEM fixture, fused: ComplexF64 153 -> 160 us, fp64
                 // 82 -> 117 us with 36 B of scratch): the memory system serves requests first come, first
                 // served, occupancy provides the parallelism of a long launch, and the extra iterations
-                // cost issue slots.)
+                // cost issue slots.)  Round 5, once more for the forward-only kernels with BRANCH-FREE loads (strip and
+                // row clamped, so that hipcc counts the loads in flight exactly -- docs/experiments_r05.md): 108 VGPRs = 4
+                // waves instead of 6; C2 9.5 -> 12.1 us, C4 slice 301 -> 358, 1 GB VBCRS 166-175 -> 173-191: a wave of one
+                // iteration issues a second, redundant batch, and the waves lost cost more than the overlap gains.
                 Vec16<T> b[L];
                 // a wave about to request matrix bytes is served before its SIMD's other waves (which are in
                 // their butterfly / FMA phases): +0.3-2 % on every operator, nothing it costs
