@@ -69,3 +69,23 @@ def test_random_operators_match_the_oracle(env, kind, dtype):
                     ref = oracle_mul(oracle, p, op, X[:, j].copy(), Y0[:, j].copy(), am, bm, False)
                     scale = max(np.max(np.abs(ref)), 1e-30)
                     assert np.max(np.abs(got[:, j] - ref)) / scale < TOL[dtype], (kind, dtype, case, acc, op, "multi", j)
+
+
+@pytest.mark.parametrize("env_extra", [{"BSM_MULTI_IL": "2"}, {"BSM_MULTI_IL": "2", "BSM_IL_WPW": "1", "BSM_IL_XCD": "1"},
+                                       {"BSM_MULTI_IL": "0"}])
+def test_multi_rhs_fuzz_with_the_interleaved_pass_forced_and_switched_off(env_extra):
+    """The interleaved multi-RHS pass is chosen per image (csrc/bsm_kernels.hip: il_applies) from switches read once per
+    process.  In child processes: the pass FORCED onto every image that accumulates with atomics (tall panels,
+    transposed-only and forward-only products included), the same with one wave per workgroup in XCD-aware order, and the
+    pass switched OFF (the round-4 kernels) -- random operators of the three types and four element types, every
+    accumulation mode, ops N / T / C, 2-35 columns, every column against the oracle (tools/fuzz_multi_seeds.py, one seed)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_multi_seeds.py"), "4100", "1"], env=dict(os.environ, **env_extra),
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    out = r.stdout.decode()
+    assert r.returncode == 0 and "MISMATCH" not in out, out[-2000:] + r.stderr.decode()[-2000:]
+    last = [ln for ln in out.splitlines() if ln.startswith("seed ")][-1]
+    assert last.endswith(" 0 mismatches") and int(last.split(":")[1].split()[0]) > 1000, last
