@@ -82,6 +82,41 @@ int main() {
     }
     CHECK(bsm_destroy(S));
     CHECK(bsm_ctx_destroy(ctx));
+    {
+        /* the two helpers of a process-per-GPU layer above this ABI: a compute stream whose CU mask leaves CUs to the
+         * collective layer's kernels, and the one-launch delivery of received partial-y segments; an ordinary handle's
+         * product on that stream, then y[0..1] += {1, 2}, y[3] += 40 */
+        void *st = NULL;
+        CHECK(bsm_stream_create_reserved(0, 8, &st));
+        bsm_options o1;
+        bsm_options_default(&o1);
+        bsm_matrix_t S1 = NULL;
+        CHECK(bsm_symmetric_create(BSM_F64, 4, 4, 1, dd, ds, dl, di, 1, oo, om, on, old_, orr, occ, &o1, &S1));
+        double *dx = NULL, *dy = NULL, *seg = NULL;
+        const double xh[4] = {1, 2, 3, 4}, add[3] = {1, 2, 40};
+        HCHECK(hipSetDevice(0));
+        HCHECK(hipMalloc((void **)&dx, 32));
+        HCHECK(hipMalloc((void **)&dy, 32));
+        HCHECK(hipMalloc((void **)&seg, 24));
+        HCHECK(hipMemcpy(dx, xh, 32, hipMemcpyHostToDevice));
+        HCHECK(hipMemcpy(seg, add, 24, hipMemcpyHostToDevice));
+        CHECK(bsm_mul(S1, BSM_OP_N, dx, dy, NULL, NULL, 1, BSM_MEM_DEVICE, st));
+        const int64_t off[2] = {0, 3}, len[2] = {2, 1};
+        const void *src[2] = {seg, seg + 2};
+        CHECK(bsm_vec_add_segments(BSM_F64, dy, 2, off, src, len, st));
+        HCHECK(hipStreamSynchronize((hipStream_t)st));
+        double yh[4];
+        HCHECK(hipMemcpy(yh, dy, 32, hipMemcpyDeviceToHost));
+        printf("product on the CU-reserved stream + segment add: [%g %g %g %g]\n", yh[0], yh[1], yh[2], yh[3]);
+        if (yh[0] != 12 || yh[1] != 16 || yh[2] != 1 || yh[3] != 42) return 1;
+        const int64_t bad_off[2] = {0, 1};
+        if (bsm_vec_add_segments(BSM_F64, dy, 2, bad_off, src, len, st) == BSM_OK) return 1; /* overlapping segments are refused */
+        (void)hipFree(dx);
+        (void)hipFree(dy);
+        (void)hipFree(seg);
+        CHECK(bsm_destroy(S1));
+        CHECK(bsm_stream_destroy(st));
+    }
     printf("OK\n");
     return 0;
 }
