@@ -68,7 +68,32 @@ struct Part {
     bool w_clean = false;               // d_w is zero everywhere (DistState::rezero)
     void *d_x = nullptr, *d_w = nullptr, *d_recv = nullptr;
     Range colpart;  // the part's share of the COLUMN partition (vectors of length ncols held in parts)
+    // work arrays of the interleaved multi-RHS pass (bsm_kernels.h: ILWork) of this part's image, allocated at the first
+    // multi-RHS product that takes it.  A part's successive products are ordered by the fan-out itself (a product waits for
+    // the part's own previous delivery, or everything runs on one stream), which is all the arrays need.
+    ILWork il;
+    bool il_failed = false;  // no memory for them: the ordinary kernels from then on
 };
+
+// the part's work arrays if its image / this product take the interleaved pass (and they can be had), else null
+static ILWork *part_il(Part &pt, bool opT, int K) {
+    if (pt.il_failed || !il_applies(pt.img, opT, K)) return nullptr;
+    const long long need = std::max(pt.img.nrows, pt.img.ncols);
+    if (pt.il.rows < need) {
+        void *xr = nullptr, *w = nullptr;
+        if (hipMalloc(&xr, (size_t)need * 128) != hipSuccess || hipMalloc(&w, (size_t)need * 128) != hipSuccess) {
+            (void)hipGetLastError();
+            if (xr) (void)hipFree(xr);
+            pt.il_failed = true;
+            return nullptr;
+        }
+        pt.il.xr = xr;
+        pt.il.w = w;
+        pt.il.rows = need;
+        pt.il.w_clean = false;
+    }
+    return &pt.il;
+}
 
 // One persistent thread per part, bound to the part's device once.  run(f) executes f(p) on every
 // worker and returns when all are done (first failure wins; its message is handed to the caller's
@@ -332,7 +357,7 @@ void dist_destroy(bsm_matrix_s *A) {
         (void)g.enter(p.device);
         if (p.stream) (void)hipStreamSynchronize(p.stream);
         free_image(p.img);
-        for (void *q : {p.d_x, p.d_w, p.d_recv})
+        for (void *q : {p.d_x, p.d_w, p.d_recv, p.il.xr, p.il.w})
             if (q) (void)hipFree(q);
         if (p.ev_prod) (void)hipEventDestroy(p.ev_prod);
         if (p.ev_done) (void)hipEventDestroy(p.ev_done);
@@ -797,7 +822,7 @@ static int dist_mul_fused_issue(DistState &D, int op, int K, const std::vector<V
                 if (K == 1)
                     DCHECK(launch_mul(pt.img, opT, conj, xp, target, alpha, b, sz, st, false, z), "kernel launch");
                 else
-                    DCHECK(launch_mul_multi(pt.img, opT, conj, K, xp, xld, target, tld, alpha, b, sz, st, z), "kernel launch");
+                    DCHECK(launch_mul_multi(pt.img, opT, conj, K, xp, xld, target, tld, alpha, b, sz, st, z, part_il(pt, opT, K)), "kernel launch");
             } else if (rezero) {
                 if (!pt.w_clean) DCHECK(hipMemsetAsync(pt.d_w, 0, (size_t)D.kcap * vlen * es, st), "memset");
                 pt.w_clean = false;
@@ -984,7 +1009,7 @@ static int dist_mul_copies(bsm_matrix_s *A, int op, int K, const void *x, long l
                            "kernel launch");
                 else
                     DCHECK(launch_mul_multi(pt.img, opT, conj, K, xp, xld, pt.d_w, (long long)vlen, alpha, nullptr, 1,
-                                            pt.stream, z), "kernel launch");
+                                            pt.stream, z, part_il(pt, opT, K)), "kernel launch");
             } else if (!zr.empty()) {
                 for (int k = 0; k < K; k++)
                     DCHECK(hipMemsetAsync((char *)pt.d_w + ((size_t)k * vlen + zr.lo) * es, 0, (size_t)zr.len() * es, pt.stream),

@@ -2456,7 +2456,7 @@ bool il_applies(const DeviceImage &img, bool opT, long long nrhs) {
 }
 template <typename T, int KK>
 static hipError_t launch_il(const DeviceImage &img, bool opT, bool conj, const T *xd, long long ldx, T *yd, long long ldy, T alpha,
-                            T beta, int strong_zero, hipStream_t stream, int kact, ILWork &il) {
+                            T beta, int strong_zero, hipStream_t stream, int kact, ILWork &il, const long long *zrange) {
     using R = typename ILT<T>::R;
     constexpr int CS = ILT<T>::CPLX ? 2 * KK : KK;  // components per vector index (8 or 16)
     const long long xlen = opT ? img.nrows : img.ncols, ylen = opT ? img.ncols : img.nrows;
@@ -2525,6 +2525,10 @@ static hipError_t launch_il(const DeviceImage &img, bool opT, bool conj, const T
         lo = img.own_lo;
         hi = img.own_hi;
     }
+    if (zrange) {  // multi-device fan-out: the y entries this part's `y .*= beta` covers (see launch_typed)
+        lo = zrange[0];
+        hi = zrange[1];
+    }
     const T one = make_scalar<T>(1.0);
     auto finish = [&](long long a, long long b, T bt, int sz) {
         if (b > a)
@@ -2565,21 +2569,21 @@ static hipError_t launch_multi_typed(const DeviceImage &img, bool opT, bool conj
     // grow with the padded width (fp64 x 16: 615 us against 2 x 320).  BSM_MFMA_REAL_MIN_COLS overrides (17: off).
     // short scattered panels: the interleaved pass (above) -- complex types in batches of 8 columns, real types of 16,
     // then one padded remainder
-    if (il && !zrange && il_applies(img, opT, nrhs)) {
+    if (il && il_applies(img, opT, nrhs)) {
         constexpr int KK = ILT<T>::KK;
         const int least = ILT<T>::CPLX ? mfma_min_cols() : il_real_min_cols();
         while (e == hipSuccess && nrhs - k >= least) {
             const int kact = (int)std::min<long long>(KK, nrhs - k);
             if constexpr (!ILT<T>::CPLX) {
                 if (kact <= 8)  // real types, at most 8 columns left: 8 components per index (64-byte lines)
-                    e = launch_il<T, 8>(img, opT, conj, xd + k * ldx, ldx, yd + k * ldy, ldy, alpha, beta, strong_zero, stream, kact, *il);
+                    e = launch_il<T, 8>(img, opT, conj, xd + k * ldx, ldx, yd + k * ldy, ldy, alpha, beta, strong_zero, stream, kact, *il, zrange);
                 else
-                    e = launch_il<T, 16>(img, opT, conj, xd + k * ldx, ldx, yd + k * ldy, ldy, alpha, beta, strong_zero, stream, kact, *il);
+                    e = launch_il<T, 16>(img, opT, conj, xd + k * ldx, ldx, yd + k * ldy, ldy, alpha, beta, strong_zero, stream, kact, *il, zrange);
             } else {
                 if (kact <= 4)  // complex types, at most 4 columns left: 8 components per index likewise
-                    e = launch_il<T, 4>(img, opT, conj, xd + k * ldx, ldx, yd + k * ldy, ldy, alpha, beta, strong_zero, stream, kact, *il);
+                    e = launch_il<T, 4>(img, opT, conj, xd + k * ldx, ldx, yd + k * ldy, ldy, alpha, beta, strong_zero, stream, kact, *il, zrange);
                 else
-                    e = launch_il<T, 8>(img, opT, conj, xd + k * ldx, ldx, yd + k * ldy, ldy, alpha, beta, strong_zero, stream, kact, *il);
+                    e = launch_il<T, 8>(img, opT, conj, xd + k * ldx, ldx, yd + k * ldy, ldy, alpha, beta, strong_zero, stream, kact, *il, zrange);
             }
             k += kact;
         }
