@@ -33,12 +33,17 @@ def bem(tiles, dtype, part):
     prob = dict(kind="symmetric", diagonals=p["diagonals"] * tiles, diagonalindices=tile(p["diagonalindices"]),
                 offdiagonals=p["offdiagonals"] * tiles, rowindices=tile(p["rowindices"]), colindices=tile(p["colindices"]),
                 size=(n0 * tiles, n0 * tiles))
-    prob["x"] = torch.from_numpy(np.random.default_rng(0).standard_normal(n0 * tiles).astype(dtype)).cuda()
+    xh = np.random.default_rng(0).standard_normal(n0 * tiles)
+    if np.dtype(dtype).kind == "c":
+        xh = xh + 1j * np.random.default_rng(1).standard_normal(n0 * tiles)
+    prob["x"] = torch.from_numpy(xh.astype(dtype)).cuda()
     return prob
 
 
 CASES = {"c3": lambda: S.config3(on_device=True), "c5s": lambda: S.config5(n=625_000, on_device=True),
-         "c4s": lambda: S.config4(on_device=True, row_lo=0, row_hi=1953), "bem_f64": lambda: bem(400, np.float64, "real")}
+         "c4s": lambda: S.config4(on_device=True, row_lo=0, row_hi=1953), "bem_f64": lambda: bem(400, np.float64, "real"),
+         "bem_f32": lambda: bem(400, np.float32, "real"), "bem_c128": lambda: bem(400, np.complex128, "full"),
+         "bem_c64": lambda: bem(400, np.complex64, "full")}
 for name in sys.argv[1:] or ["c3"]:
     prob = CASES[name]()
     A = S.build(prob)
