@@ -939,10 +939,10 @@ extern "C" int bsm_vec_add_segments(int dtype, void *y, int32_t nseg, const int6
             if (len[a] > 0 && len[b] > 0 && offset[a] < offset[b] + len[b] && offset[b] < offset[a] + len[a])
                 return fail(BSM_ERR_INVALID, "segments overlap");
     }
-    for (int32_t s0 = 0; s0 < nseg; s0 += kMaxVecPieces) {
+    for (int32_t c = 0; c < nseg;) {  // kMaxVecPieces non-empty segments per launch
         VecPieces pc;
         int np = 0;
-        for (int32_t c = s0; c < nseg && np < kMaxVecPieces; c++) {
+        for (; c < nseg && np < kMaxVecPieces; c++) {
             if (len[c] == 0) continue;
             pc.base[np] = src[c];
             pc.lo[np] = offset[c];
@@ -950,6 +950,7 @@ extern "C" int bsm_vec_add_segments(int dtype, void *y, int32_t nseg, const int6
             pc.strided[np] = 0;
             np++;
         }
+        if (np == 0) break;
         hipError_t e = launch_vec_add_segments(dtype, y, pc, np, (hipStream_t)stream);
         if (e != hipSuccess) return hip_fail(e, "segment add launch");
     }

@@ -232,8 +232,19 @@ def test_segment_add_and_reserved_cu_stream():
             ref[o:o + s_.shape[0]] += 2 * s_
         torch.cuda.synchronize()
         assert torch.allclose(y, ref, rtol=1e-6, atol=0)
+    # more segments than one launch takes (8), empty ones in between: every non-empty segment added exactly once
+    y = torch.zeros(2000, dtype=torch.float64, device="cuda")
+    lens = [5, 0, 7, 0, 0, 3, 11, 2, 0, 9, 4, 6, 0, 8, 1, 0, 13]
+    offs = [100 * i for i in range(len(lens))]
+    srcs = [torch.full((n,), float(i + 1), dtype=torch.float64, device="cuda") for i, n in enumerate(lens)]
+    M.SegmentAdd(y, [y[o:o + n] for o, n in zip(offs, lens)], srcs)()
+    ref = torch.zeros_like(y)
+    for i, (o, n) in enumerate(zip(offs, lens)):
+        ref[o:o + n] = i + 1
+    torch.cuda.synchronize()
+    assert torch.equal(y, ref)
     with pytest.raises(Exception):
-        M.SegmentAdd(y, [y[0:10], y[5:15]], [srcs[1][:10], srcs[1][:10]])()
+        M.SegmentAdd(y, [y[0:10], y[5:15]], [srcs[6][:10], srcs[6][:10]])()
     st = D.compute_stream()
     assert st is D.compute_stream()  # cached
     prob = bsm.synthetic.config3(nseg=40)
