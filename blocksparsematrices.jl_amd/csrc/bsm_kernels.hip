@@ -1753,7 +1753,9 @@ __global__ void __launch_bounds__(64 * kWavesPerWg, ((kMfmaPath32<T, K> || (kMfm
 #ifndef BSM_IL_C128_WGS
 #define BSM_IL_C128_WGS 3
 #endif
-template <typename T, int MRMAX> constexpr int il_wgs() {
+// (DEEP, four row blocks in flight: Float32 128, ComplexF32 ~160, Float64 ~185, ComplexF64 231)
+template <typename T, int MRMAX, bool DEEP = false> constexpr int il_wgs() {
+    if (DEEP) return sizeof(T) == 4 ? 4 : (sizeof(T) == 16 ? 2 : (std::is_same<T, double>::value ? 2 : 3));
     return (sizeof(T) == 4 || sizeof(T) == 8 && !std::is_same<T, double>::value) ? (MRMAX <= 2 ? 5 : 4)
            : std::is_same<T, double>::value                                       ? (MRMAX <= 2 ? 4 : 3)
                                                                                    : (MRMAX <= 2 ? BSM_IL_C128_WGS : 2);
@@ -1762,7 +1764,6 @@ constexpr int kIlCols = 256;            // columns of a panel staged per refill 
 constexpr int IL_NOFWD = 1 << 30;       // staged column entry: takes no part in the forward half
 constexpr int IL_NOTRN = (int)(1u << 31);  // ... in the transposed half
 constexpr int IL_MASK = (1 << 30) - 1;
-constexpr int FLAG_IL_XCD = 1 << 12;  // panel_kernel_il: XCD-aware workgroup order
 
 // The loop is written BRANCH-FREE on purpose.  hipcc places its own s_waitcnt in front of the first use of every loaded
 // register, and wherever control flow (a lane-masked `if` around a load or an atomic, a scratch reload, paths with different
@@ -1825,7 +1826,11 @@ __device__ __forceinline__ float il_im(float) { return 0.f; }
 // CS = components stored per vector index: 16, or 8 for real types with at most 8 right-hand sides (half a tile of the
 // MFMA stays empty -- lanes ln >= 8 carry a zero x operand and deliver nothing -- but a vector index is 64 bytes of Xr and
 // of W instead of 128: what bounds this pass over short panels is its vector-side traffic, not the matrix pipe)
-template <typename T, int NRB, bool FWD, bool TRN, int CS>
+// DEEP (instances for tall panels, MRMAX = 4): the tiles of ALL NRB row blocks of the next 16 columns are requested
+// while the current ones are consumed (each buffer re-requested in place right behind its last use) instead of one step
+// ahead -- with one 16 x 16 tile per wave in flight a pass over 64-row panels is bound by tile latency x resident waves
+// (fp64: 12 waves per CU x 2 KB per 1.8 us = 3.5 TB/s, matrix pipe half idle).
+template <typename T, int NRB, bool FWD, bool TRN, int CS, bool DEEP>
 __device__ __forceinline__ void il_panel(const WaveD &wd, const uint4 *__restrict__ values, const int *__restrict__ rows,
                                          const int *__restrict__ cols, const typename ILT<T>::R *__restrict__ xr,
                                          typename ILT<T>::R *__restrict__ wacc, int flags, int lane, T *tile, int *cix) {
@@ -1889,9 +1894,12 @@ __device__ __forceinline__ void il_panel(const WaveD &wd, const uint4 *__restric
             if (!F64MAP) ro[q] = rows[wd.row_off + min((q >> 2) * 16 + accrow(q & 3), m - 1)];
         }
     }
-    Vec16<T> nb[NLD];
+    constexpr int NBUF = DEEP ? NRB : 1;
+    Vec16<T> nb[NBUF][NLD];
 #pragma unroll
-    for (int j = 0; j < NLD; ++j) nb[j] = mat(0, 0, j);
+    for (int rb = 0; rb < NBUF; ++rb)
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) nb[rb][j] = mat(0, rb, j);
     // x / y index of panel column w with its roles (IL_NOFWD / IL_NOTRN)
     auto entry = [&](int w, int raw) -> int {
         bool off;
@@ -1916,6 +1924,11 @@ __device__ __forceinline__ void il_panel(const WaveD &wd, const uint4 *__restric
     R pd[4] = {0, 0, 0, 0};
     int pe[4] = {0, 0, 0, 0};
     bool pok[4] = {false, false, false, false};
+    auto emit = [&]() {
+        if (BSM_DBG(DBG_NO_GLOBAL_ATOMICS)) return;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) il_atomic_add(&wacc[(size_t)pe[r] * CS + lc], pd[r], pok[r]);
+    };
     for (int cb = 0; cb < ncols; cb += kIlCols) {
         const int c_end = min(ncols, cb + kIlCols);
         // (re)fill the staged index list of [cb, c_end)
@@ -1966,23 +1979,26 @@ __device__ __forceinline__ void il_panel(const WaveD &wd, const uint4 *__restric
             }
             // the PREVIOUS tile's sums first (vector-memory operations retire in order: they have the whole step, and the
             // latency of the requests behind them, to complete), then the next tile's operands
-            if (!BSM_DBG(DBG_NO_GLOBAL_ATOMICS)) {
+            emit();
+            // (DEEP: everything this tile needs was requested a tile ago; hipcc does not count the atomics above and
+            // drains what is in flight at the first use behind them -- so the new requests go out behind that use)
+            if (!DEEP) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) il_atomic_add(&wacc[(size_t)pe[r] * CS + lc], pd[r], pok[r]);
+                for (int j = 0; j < NLD; ++j)
+#pragma unroll
+                    for (int e = 0; e < E; ++e) xn[j * E + e] = xop(t0 + 16, j, e);
             }
-#pragma unroll
-            for (int j = 0; j < NLD; ++j)
-#pragma unroll
-                for (int e = 0; e < E; ++e) xn[j * E + e] = xop(t0 + 16, j, e);
             V4 dt = {0, 0, 0, 0};
 #pragma unroll
             for (int rb = 0; rb < NRB; ++rb) {
                 Vec16<T> b[NLD];
 #pragma unroll
-                for (int j = 0; j < NLD; ++j) b[j] = nb[j];
+                for (int j = 0; j < NLD; ++j) b[j] = nb[DEEP ? rb : 0][j];
                 // the next step's tile: the next row block of these columns, or the first one of the next 16 columns
+                if (!DEEP) {
 #pragma unroll
-                for (int j = 0; j < NLD; ++j) nb[j] = (rb + 1 < NRB) ? mat(t0, rb + 1, j) : mat(t0 + 16, 0, j);
+                    for (int j = 0; j < NLD; ++j) nb[0][j] = (rb + 1 < NRB) ? mat(t0, rb + 1, j) : mat(t0 + 16, 0, j);
+                }
                 if (FWD && !BSM_DBG(DBG_NO_FWD_HALF)) {
 #pragma unroll
                     for (int j = 0; j < NLD; ++j)
@@ -1998,6 +2014,18 @@ __device__ __forceinline__ void il_panel(const WaveD &wd, const uint4 *__restric
                     for (int j = 0; j < NLD; ++j)
 #pragma unroll
                         for (int e = 0; e < E; ++e) tile[(E * (4 * j + lk) + e) * 17 + ln] = b[j].v[e];
+                }
+                if (DEEP) {  // this row block's tile of the next 16 columns, into the registers just consumed
+                    if (rb == 0) {
+#pragma unroll
+                        for (int j = 0; j < NLD; ++j)
+#pragma unroll
+                            for (int e = 0; e < E; ++e) xn[j * E + e] = xop(t0 + 16, j, e);
+                    }
+#pragma unroll
+                    for (int j = 0; j < NLD; ++j) nb[rb][j] = mat(t0 + 16, rb, j);
+                }
+                if (TRN && !BSM_DBG(DBG_NO_TRN_HALF)) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const T u = tile[ln * 17 + 4 * q + lk];
@@ -2022,10 +2050,7 @@ __device__ __forceinline__ void il_panel(const WaveD &wd, const uint4 *__restric
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     BSM_TSTAMP(4);  // every tile done
 #endif
-    if (!BSM_DBG(DBG_NO_GLOBAL_ATOMICS)) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) il_atomic_add(&wacc[(size_t)pe[r] * CS + lc], pd[r], pok[r]);
-    }
+    emit();
     if (fwd_en && !BSM_DBG(DBG_NO_FWD_OUT)) {
         // lane (component ln, lk), register r of row block rb: row rb * 16 + accrow(r) -- every wave adds its own partial sums
 #pragma unroll
@@ -2042,23 +2067,25 @@ __device__ __forceinline__ void il_panel(const WaveD &wd, const uint4 *__restric
 // WPW = waves per workgroup: 1 -- the waves of this pass share nothing (no LDS slab, no window, no barrier), and a
 // workgroup's slot is only recycled when its SLOWEST wave is done (tools/il_trace.py: 66 % of the wave slots occupied with
 // four panels of different lengths per workgroup)
-template <typename T, int MRMAX, bool FWD, bool TRN, int WPW, int CS>
-__global__ void __launch_bounds__(64 * WPW, (il_wgs<T, MRMAX>() * kWavesPerWg / WPW))
+template <typename T, int MRMAX, bool FWD, bool TRN, int WPW, int CS, bool DEEP>
+__global__ void __launch_bounds__(64 * WPW, (il_wgs<T, MRMAX, DEEP>() * kWavesPerWg / WPW))
     panel_kernel_il(const WaveWork *__restrict__ waves, const uint4 *__restrict__ values, const int *__restrict__ rows,
                     const int *__restrict__ cols, const typename ILT<T>::R *__restrict__ xr, typename ILT<T>::R *__restrict__ wacc,
-                    int flags, unsigned wg_base) {
+                    int flags, unsigned wg_base, unsigned xcd_run) {
     __shared__ T tl[WPW][TRN ? 16 * 17 : 1];
     __shared__ int cixs[WPW][kIlCols];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     BSM_TSTAMP(0);  // wave started
-    // XCD-aware order (flags bit FLAG_IL_XCD): workgroups are dealt to the 8 XCDs round robin, so with the plain order
-    // eight NEIGHBOURING panels -- which read mostly the same lines of Xr and add to the same lines of W -- land in eight
-    // different L2s.  Here XCD c walks the c-th contiguous eighth of the list.
+    // XCD-aware order (xcd_run > 0): workgroups are dealt to the 8 XCDs round robin, so with the plain order eight
+    // NEIGHBOURING panels -- which read mostly the same lines of Xr -- land in eight different L2s.  Here every XCD takes
+    // RUNS of xcd_run consecutive workgroups of the list (8 * xcd_run workgroups = one run per XCD), so neighbours share
+    // an L2 while the list is still consumed front to back on all XCDs (its heavy items come first: a contiguous eighth
+    // per XCD, the first form of this, left XCD 0 with all of them -- C5 slice x 8 967 -> 1252 us).
     unsigned bid = blockIdx.x;
-    if (flags & FLAG_IL_XCD) {
-        const unsigned n8 = gridDim.x >> 3;  // (the launcher pads the grid to a multiple of 8; surplus blocks find NOP records)
-        bid = (bid & 7u) * n8 + (bid >> 3);
+    if (xcd_run) {  // (the launcher pads the grid to a multiple of 8 * xcd_run; surplus blocks leave at once)
+        const unsigned span = 8u * xcd_run, in = bid % span;
+        bid = bid - in + (in & 7u) * xcd_run + (in >> 3);
     }
     if (bid >= wg_base) return;  // wg_base: number of workgroups of the record list (re-used argument)
     const WaveD wd = load_wave(waves + ((size_t)bid * WPW + wave));
@@ -2073,13 +2100,13 @@ __global__ void __launch_bounds__(64 * WPW, (il_wgs<T, MRMAX>() * kWavesPerWg / 
 #endif
     const int nrb = (wd.m + 15) >> 4;  // (wave-uniform)
     if (nrb == 1)
-        il_panel<T, 1, FWD, TRN, CS>(wd, values, rows, cols, xr, wacc, flags, lane, tl[wave], cixs[wave]);
+        il_panel<T, 1, FWD, TRN, CS, DEEP>(wd, values, rows, cols, xr, wacc, flags, lane, tl[wave], cixs[wave]);
     else if (nrb == 2 || MRMAX <= 2)
-        il_panel<T, 2, FWD, TRN, CS>(wd, values, rows, cols, xr, wacc, flags, lane, tl[wave], cixs[wave]);
+        il_panel<T, 2, FWD, TRN, CS, DEEP>(wd, values, rows, cols, xr, wacc, flags, lane, tl[wave], cixs[wave]);
     else if (nrb == 3)
-        il_panel<T, (MRMAX > 2 ? 3 : 2), FWD, TRN, CS>(wd, values, rows, cols, xr, wacc, flags, lane, tl[wave], cixs[wave]);
+        il_panel<T, (MRMAX > 2 ? 3 : 2), FWD, TRN, CS, DEEP>(wd, values, rows, cols, xr, wacc, flags, lane, tl[wave], cixs[wave]);
     else
-        il_panel<T, (MRMAX > 2 ? 4 : 2), FWD, TRN, CS>(wd, values, rows, cols, xr, wacc, flags, lane, tl[wave], cixs[wave]);
+        il_panel<T, (MRMAX > 2 ? 4 : 2), FWD, TRN, CS, DEEP>(wd, values, rows, cols, xr, wacc, flags, lane, tl[wave], cixs[wave]);
 #ifdef BSM_TRACE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     BSM_TSTAMP(5);  // everything stored
@@ -2488,35 +2515,46 @@ static hipError_t launch_il(const DeviceImage &img, bool opT, bool conj, const T
             const char *v = std::getenv("BSM_IL_WPW");
             return v && std::atoi(v) == 1 ? 1 : 4;
         }();
-        // BSM_IL_XCD = 1: XCD-aware workgroup order.  Measured: +-0 too (367 / 204 / 359 us against 374 / 208 / 352).
-        static const int xcd = [] {
+        // BSM_IL_XCD = R: XCD-aware workgroup order, runs of R consecutive workgroups per XCD (0: plain order).  Default:
+        // 16 for operators with tall panels (C3 x 16 312 -> 262 us -- neighbouring 64-row panels read the same 9 x 64
+        // lines of Xr, L2 hits 0.5 M -> of 9.5 M read requests with the plain order; R = 4 ... 64 alike), plain for
+        // short scattered panels (the tiled BEM fixture: +-0, 367 / 204 / 359 us against 374 / 208 / 352)
+        static const int xcd_env = [] {
             const char *v = std::getenv("BSM_IL_XCD");
-            return v ? std::atoi(v) : 0;
+            return v ? std::atoi(v) : -1;
         }();
-        const unsigned nblk = (unsigned)(nwg * (kWavesPerWg / wpw));
-        if (xcd) flags |= FLAG_IL_XCD;
-        const dim3 grid(xcd ? (nblk + 7u) / 8u * 8u : nblk), block(64 * wpw);
         const bool small = img.max_rows <= 32;
-#define BSM_IL_LAUNCH(MR, WPW)                                                                                                     \
+        const int xcd = xcd_env >= 0 ? xcd_env : (small ? 0 : 16);
+        const unsigned nblk = (unsigned)(nwg * (kWavesPerWg / wpw));
+        const unsigned xcd_run = xcd > 0 ? (unsigned)xcd : 0u, span = 8u * xcd_run;
+        const dim3 grid(xcd_run ? (nblk + span - 1) / span * span : nblk), block(64 * wpw);
+#define BSM_IL_LAUNCH(MR, WPW, DEEP)                                                                                                   \
     do {                                                                                                                           \
         if (!opT && !img.has_off)                                                                                                  \
-            hipLaunchKernelGGL((panel_kernel_il<T, MR, true, false, WPW, CS>), grid, block, 0, stream, waves, values, rows, cols, xr, w,  \
-                               flags, nblk);                                                                                        \
+            hipLaunchKernelGGL((panel_kernel_il<T, MR, true, false, WPW, CS, DEEP>), grid, block, 0, stream, waves, values, rows, cols, xr, w,  \
+                               flags, nblk, xcd_run);                                                                                        \
         else if (img.has_off)                                                                                                      \
-            hipLaunchKernelGGL((panel_kernel_il<T, MR, true, true, WPW, CS>), grid, block, 0, stream, waves, values, rows, cols, xr, w,   \
-                               flags, nblk);                                                                                        \
+            hipLaunchKernelGGL((panel_kernel_il<T, MR, true, true, WPW, CS, DEEP>), grid, block, 0, stream, waves, values, rows, cols, xr, w,   \
+                               flags, nblk, xcd_run);                                                                                        \
         else                                                                                                                       \
-            hipLaunchKernelGGL((panel_kernel_il<T, MR, false, true, WPW, CS>), grid, block, 0, stream, waves, values, rows, cols, xr, w,  \
-                               flags, nblk);                                                                                        \
+            hipLaunchKernelGGL((panel_kernel_il<T, MR, false, true, WPW, CS, DEEP>), grid, block, 0, stream, waves, values, rows, cols, xr, w,  \
+                               flags, nblk, xcd_run);                                                                                        \
     } while (0)
+        // BSM_IL_DEEP = 0: the tall-panel instances request one step ahead like the short-panel ones (A / B)
+        static const int deep = [] {
+            const char *v = std::getenv("BSM_IL_DEEP");
+            return v ? std::atoi(v) : 1;
+        }();
         if (small && wpw == 1)
-            BSM_IL_LAUNCH(2, 1);
+            BSM_IL_LAUNCH(2, 1, false);
         else if (small)
-            BSM_IL_LAUNCH(2, 4);
+            BSM_IL_LAUNCH(2, 4, false);
         else if (wpw == 1)
-            BSM_IL_LAUNCH(4, 1);
+            BSM_IL_LAUNCH(4, 1, false);
+        else if (!deep)
+            BSM_IL_LAUNCH(4, 4, false);
         else
-            BSM_IL_LAUNCH(4, 4);
+            BSM_IL_LAUNCH(4, 4, true);
 #undef BSM_IL_LAUNCH
     }
     // Y = beta * Y + W over the rows this handle scales (all of them for op T / C), Y += W elsewhere; W = 0 behind

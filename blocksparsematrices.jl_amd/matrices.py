@@ -785,9 +785,10 @@ class SegmentAdd:
             if d.dtype != y.dtype or s_.dtype != y.dtype or d.shape != s_.shape or d.dim() != 1 or \
                     not d.is_contiguous() or not s_.is_contiguous() or d.device != y.device or s_.device != y.device:
                 raise ValueError("segments must be contiguous 1-D tensors of y's type on y's device")
-        self._off = (C.c_int64 * n)(*[(d.data_ptr() - y.data_ptr()) // es for d in dsts])
+        # (an empty view has no address of its own)
+        self._off = (C.c_int64 * n)(*[(d.data_ptr() - y.data_ptr()) // es if d.numel() else 0 for d in dsts])
         self._len = (C.c_int64 * n)(*[d.shape[0] for d in dsts])
-        self._src = (C.c_void_p * n)(*[s_.data_ptr() for s_ in srcs])
+        self._src = (C.c_void_p * n)(*[s_.data_ptr() if s_.numel() else None for s_ in srcs])
         if any(o < 0 or o + l_ > y.numel() for o, l_ in zip(self._off, self._len)):
             raise ValueError("a segment lies outside y")
         self._keep = (y, dsts, srcs)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Developer probe: per-wave timeline of ONE interleaved multi-RHS launch (panel_kernel_il_*) from the trace build
-(make -C csrc trace -> libbsmrocm_trace.so).  usage: BSM_LIB=.../libbsmrocm_trace.so tools/il_trace.py [bem_c128|bem_c64] [K]"""
+(make -C csrc trace -> libbsmrocm_trace.so).  usage: BSM_LIB=.../libbsmrocm_trace.so tools/il_trace.py [bem_c128|bem_c64|bem_f64|bem_f32|c3|c3_f32|c5s] [K]"""
 import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 os.environ.setdefault("BSM_LIB", os.path.join(ROOT, "blocksparsematrices.jl_amd", "libbsmrocm_trace.so"))
@@ -11,15 +11,28 @@ name = sys.argv[1] if len(sys.argv) > 1 else "bem_c128"
 K = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from _common import fixture_problem
-dtype = {"bem_c128": np.complex128, "bem_c64": np.complex64}[name]
-p = fixture_problem("cuboid", dtype, "full")
-n0, tiles = p["size"][0], 400
-tile = lambda lists: [l + k * n0 for k in range(tiles) for l in lists]
-prob = dict(kind="symmetric", diagonals=p["diagonals"] * tiles, diagonalindices=tile(p["diagonalindices"]),
-            offdiagonals=p["offdiagonals"] * tiles, rowindices=tile(p["rowindices"]), colindices=tile(p["colindices"]),
-            size=(n0 * tiles, n0 * tiles))
-xh = np.random.default_rng(0).standard_normal(n0 * tiles) + 1j * np.random.default_rng(1).standard_normal(n0 * tiles)
-x = torch.from_numpy(xh.astype(dtype)).cuda()
+S = bsm.synthetic
+
+
+def bem(dtype, part):
+    p = fixture_problem("cuboid", dtype, part)
+    n0, tiles = p["size"][0], 400
+    tile = lambda lists: [l + k * n0 for k in range(tiles) for l in lists]
+    prob = dict(kind="symmetric", diagonals=p["diagonals"] * tiles, diagonalindices=tile(p["diagonalindices"]),
+                offdiagonals=p["offdiagonals"] * tiles, rowindices=tile(p["rowindices"]), colindices=tile(p["colindices"]),
+                size=(n0 * tiles, n0 * tiles))
+    xh = np.random.default_rng(0).standard_normal(n0 * tiles)
+    if np.dtype(dtype).kind == "c":
+        xh = xh + 1j * np.random.default_rng(1).standard_normal(n0 * tiles)
+    prob["x"] = torch.from_numpy(xh.astype(dtype)).cuda()
+    return prob
+
+
+prob = {"bem_c128": lambda: bem(np.complex128, "full"), "bem_c64": lambda: bem(np.complex64, "full"),
+        "bem_f64": lambda: bem(np.float64, "real"), "bem_f32": lambda: bem(np.float32, "real"),
+        "c3": lambda: S.config3(on_device=True), "c3_f32": lambda: S.config3(on_device=True, dtype=np.float32),
+        "c5s": lambda: S.config5(n=625_000, on_device=True)}[name]()
+x = prob["x"]
 A = bsm.synthetic.build(prob)
 n = x.shape[0]
 X = torch.empty((K, n), dtype=x.dtype, device="cuda").t()
@@ -30,7 +43,7 @@ f = lambda: bsm.mul(Y, A, X)
 for _ in range(10):
     f()
 torch.cuda.synchronize()
-nw = 9800 * 4 + 64
+nw = 400_000  # (more than any of these launches has waves)
 buf = torch.zeros(nw * 16, dtype=torch.int64, device="cuda")
 L = _lib.lib()
 L.bsm_debug_set_trace.argtypes = [C.c_void_p]
