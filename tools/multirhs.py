@@ -49,6 +49,8 @@ CASES = {
     "c3_f32": lambda: S.config3(on_device=True, dtype=np.float32),
     "c4s": lambda: S.config4(on_device=True, row_lo=0, row_hi=1953),
     "c5s": lambda: S.config5(n=625_000, on_device=True),
+    "c5small": lambda: S.config5(n=400_000, lo=8, hi=32, halfband=8, on_device=True),  # banded, panels of 8-32 rows
+    "c5small_f32": lambda: S.config5(n=400_000, lo=8, hi=32, halfband=8, dtype=np.float32, on_device=True),
     "bem_c128": lambda: bem(400, np.complex128, "full"),
     "bem_c64": lambda: bem(400, np.complex64, "full"),
     "bem_f64": lambda: bem(400, np.float64, "real"),
