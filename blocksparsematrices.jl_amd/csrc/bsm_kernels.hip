@@ -1748,17 +1748,16 @@ __global__ void __launch_bounds__(64 * kWavesPerWg, ((kMfmaPath32<T, K> || (kMfm
 //     {row list -> x rows, column list, first tile}: three round trips for the whole panel.
 // One step = one row block (16 rows) of one column tile (16 columns), operands one step ahead, as in the path above.
 // ----------------------------------------------------------------------------------------
-// resident workgroups per CU the interleaved kernels are compiled for (their natural register need, fused instances:
-// Float32 / ComplexF32 90-92 VGPRs with two row blocks, 125 with four; Float64 122 / 163; ComplexF64 143 / 199)
+// resident workgroups per CU the interleaved kernels are compiled for (their natural register need, fused instances --
+// panels of at most 32 rows, two row blocks, one step ahead: Float32 / ComplexF32 84-92 VGPRs, Float64 110, ComplexF64 144;
+// tall panels, four row blocks of the next 16 columns in flight: Float32 128, ComplexF32 145, Float64 184, ComplexF64 231)
 #ifndef BSM_IL_C128_WGS
 #define BSM_IL_C128_WGS 3
 #endif
-// (DEEP, four row blocks in flight: Float32 128, ComplexF32 ~160, Float64 ~185, ComplexF64 231)
-template <typename T, int MRMAX, bool DEEP = false> constexpr int il_wgs() {
-    if (DEEP) return sizeof(T) == 4 ? 4 : (sizeof(T) == 16 ? 2 : (std::is_same<T, double>::value ? 2 : 3));
-    return (sizeof(T) == 4 || sizeof(T) == 8 && !std::is_same<T, double>::value) ? (MRMAX <= 2 ? 5 : 4)
-           : std::is_same<T, double>::value                                       ? (MRMAX <= 2 ? 4 : 3)
-                                                                                   : (MRMAX <= 2 ? BSM_IL_C128_WGS : 2);
+template <typename T, int MRMAX> constexpr int il_wgs() {
+    constexpr bool f64 = std::is_same<T, double>::value;
+    if (MRMAX > 2) return sizeof(T) == 4 ? 4 : (sizeof(T) == 16 || f64 ? 2 : 3);
+    return sizeof(T) == 16 ? BSM_IL_C128_WGS : (f64 ? 4 : 5);
 }
 constexpr int kIlCols = 256;            // columns of a panel staged per refill of the index list
 constexpr int IL_NOFWD = 1 << 30;       // staged column entry: takes no part in the forward half
@@ -2064,14 +2063,15 @@ __device__ __forceinline__ void il_panel(const WaveD &wd, const uint4 *__restric
     }
 }
 
-// WPW = waves per workgroup: 1 -- the waves of this pass share nothing (no LDS slab, no window, no barrier), and a
-// workgroup's slot is only recycled when its SLOWEST wave is done (tools/il_trace.py: 66 % of the wave slots occupied with
-// four panels of different lengths per workgroup)
-template <typename T, int MRMAX, bool FWD, bool TRN, int WPW, int CS, bool DEEP>
-__global__ void __launch_bounds__(64 * WPW, (il_wgs<T, MRMAX, DEEP>() * kWavesPerWg / WPW))
+// (one wave per workgroup -- the waves of this pass share nothing, and a workgroup's slot is only recycled when its
+// SLOWEST wave is done: tools/il_trace.py showed 66 % of the wave slots occupied -- was measured at +-0 and removed)
+template <typename T, int MRMAX, bool FWD, bool TRN, int CS>
+__global__ void __launch_bounds__(64 * kWavesPerWg, (il_wgs<T, MRMAX>()))
     panel_kernel_il(const WaveWork *__restrict__ waves, const uint4 *__restrict__ values, const int *__restrict__ rows,
                     const int *__restrict__ cols, const typename ILT<T>::R *__restrict__ xr, typename ILT<T>::R *__restrict__ wacc,
                     int flags, unsigned wg_base, unsigned xcd_run) {
+    constexpr int WPW = kWavesPerWg;
+    constexpr bool DEEP = MRMAX > 2;  // tall panels: all row blocks of the next 16 columns in flight (il_panel)
     __shared__ T tl[WPW][TRN ? 16 * 17 : 1];
     __shared__ int cixs[WPW][kIlCols];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -2508,13 +2508,6 @@ static hipError_t launch_il(const DeviceImage &img, bool opT, bool conj, const T
     const R *xr = (const R *)il.xr;
     R *w = (R *)il.w;
     if (nwg > 0) {
-        // BSM_IL_WPW = 1: one wave per workgroup (a workgroup's slot is recycled only when its slowest wave is done --
-        // tools/il_trace.py: 66 % of the slots occupied).  Measured: +-0 on the BEM fixture in every type (367 / 208 /
-        // 352 us at 4, 373 / 212 / 354 at 1): the pass is bound by its vector-side requests, not by slots.
-        static const int wpw = [] {
-            const char *v = std::getenv("BSM_IL_WPW");
-            return v && std::atoi(v) == 1 ? 1 : 4;
-        }();
         // BSM_IL_XCD = R: XCD-aware workgroup order, runs of R consecutive workgroups per XCD (0: plain order).  Default:
         // 16 for operators with tall panels (C3 x 16 312 -> 262 us -- neighbouring 64-row panels read the same 9 x 64
         // lines of Xr, L2 hits 0.5 M -> of 9.5 M read requests with the plain order; R = 4 ... 64 alike), plain for
@@ -2525,36 +2518,27 @@ static hipError_t launch_il(const DeviceImage &img, bool opT, bool conj, const T
         }();
         const bool small = img.max_rows <= 32;
         const int xcd = xcd_env >= 0 ? xcd_env : (small ? 0 : 16);
-        const unsigned nblk = (unsigned)(nwg * (kWavesPerWg / wpw));
+        const unsigned nblk = (unsigned)nwg;
         const unsigned xcd_run = xcd > 0 ? (unsigned)xcd : 0u, span = 8u * xcd_run;
-        const dim3 grid(xcd_run ? (nblk + span - 1) / span * span : nblk), block(64 * wpw);
-#define BSM_IL_LAUNCH(MR, WPW, DEEP)                                                                                                   \
+        const dim3 grid(xcd_run ? (nblk + span - 1) / span * span : nblk), block(64 * kWavesPerWg);
+#define BSM_IL_LAUNCH(MR)                                                                                                              \
     do {                                                                                                                           \
         if (!opT && !img.has_off)                                                                                                  \
-            hipLaunchKernelGGL((panel_kernel_il<T, MR, true, false, WPW, CS, DEEP>), grid, block, 0, stream, waves, values, rows, cols, xr, w,  \
+            hipLaunchKernelGGL((panel_kernel_il<T, MR, true, false, CS>), grid, block, 0, stream, waves, values, rows, cols, xr, w,  \
                                flags, nblk, xcd_run);                                                                                        \
         else if (img.has_off)                                                                                                      \
-            hipLaunchKernelGGL((panel_kernel_il<T, MR, true, true, WPW, CS, DEEP>), grid, block, 0, stream, waves, values, rows, cols, xr, w,   \
+            hipLaunchKernelGGL((panel_kernel_il<T, MR, true, true, CS>), grid, block, 0, stream, waves, values, rows, cols, xr, w,   \
                                flags, nblk, xcd_run);                                                                                        \
         else                                                                                                                       \
-            hipLaunchKernelGGL((panel_kernel_il<T, MR, false, true, WPW, CS, DEEP>), grid, block, 0, stream, waves, values, rows, cols, xr, w,  \
+            hipLaunchKernelGGL((panel_kernel_il<T, MR, false, true, CS>), grid, block, 0, stream, waves, values, rows, cols, xr, w,  \
                                flags, nblk, xcd_run);                                                                                        \
     } while (0)
-        // BSM_IL_DEEP = 0: the tall-panel instances request one step ahead like the short-panel ones (A / B)
-        static const int deep = [] {
-            const char *v = std::getenv("BSM_IL_DEEP");
-            return v ? std::atoi(v) : 1;
-        }();
-        if (small && wpw == 1)
-            BSM_IL_LAUNCH(2, 1, false);
-        else if (small)
-            BSM_IL_LAUNCH(2, 4, false);
-        else if (wpw == 1)
-            BSM_IL_LAUNCH(4, 1, false);
-        else if (!deep)
-            BSM_IL_LAUNCH(4, 4, false);
+        // (tall panels: all row blocks of the next 16 columns in flight -- il_panel's DEEP form, worth 1-6 % over one step
+        // ahead with the XCD-aware order, profiles/r05_il_tall_panels.txt)
+        if (small)
+            BSM_IL_LAUNCH(2);
         else
-            BSM_IL_LAUNCH(4, 4, true);
+            BSM_IL_LAUNCH(4);
 #undef BSM_IL_LAUNCH
     }
     // Y = beta * Y + W over the rows this handle scales (all of them for op T / C), Y += W elsewhere; W = 0 behind
