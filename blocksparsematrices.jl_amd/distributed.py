@@ -350,6 +350,7 @@ class RowPartitioned:
         self._gbuf = self._sbuf = self._pad = self._rsout = None
         self._ops = {}
         self._segadd = None
+        self._xplan_m = self._plan_m = self._work_m = None  # mul_multi: plans and the (n, K) work matrix
 
     def out_range(self, n, rank=None):
         """Output rows (1-based, inclusive) rank `rank` holds after a product ACROSS the partition."""
@@ -553,6 +554,135 @@ class RowPartitioned:
         if self.gather and (self.world > 1 or self.loopback):
             self._allgather(y, [(rl, rh) for rl, rh, _, _ in ranges])
         return y
+
+    # ---- A * X: several right-hand sides -------------------------------------------------------------------------
+    @staticmethod
+    def _colmajor_like(t, rows):
+        """(rows, K) matrix whose columns are contiguous, like a column-major t"""
+        return torch.empty((t.shape[1], rows), dtype=t.dtype, device=t.device).t()
+
+    def _p2p_columns(self, pairs, op):
+        """one point-to-point descriptor per COLUMN of every (peer, matrix piece): the row slice of a column-major matrix
+        is K contiguous runs, and all of them travel in the one batch of the exchange (one grouped RCCL call)"""
+        return [dist.P2POp(op, v[:, k], self._peer(r), group=self.group) for r, v in pairs for k in range(v.shape[1])]
+
+    def _fetch_x_multi(self, X):
+        """fetch_x for an (n, K) column-major X partitioned like the rows"""
+        ranges = self._exchange_ranges(X.device)
+        if self.world == 1 and not self.loopback:
+            return X
+        own_ranges = [(rl, rh) for rl, rh, _, _ in ranges]
+        if any(xn == (0, -1) for xn in self._xneeds):  # somebody reads everything: all-gather, column by column
+            for k in range(X.shape[1]):
+                self._allgather(X[:, k], own_ranges)
+            return X
+        if self._xplan_m is None or self._xplan_m[0] is not X:
+            olo, ohi = self.own
+            nlo, nhi = self._xneeds[self.rank]
+            sends, recvs, staged = [], [], []
+            for r, (rlo, rhi) in enumerate(own_ranges):
+                if r == self.rank:
+                    continue
+                a, b = max(self._xneeds[r][0], olo), min(self._xneeds[r][1], ohi)  # what rank r reads of mine
+                if a <= b:
+                    sends.append((r, X[a - 1:b]))
+                a, b = max(nlo, rlo), min(nhi, min(rhi, X.shape[0]))  # what I read of rank r's
+                if a <= b:
+                    recvs.append((r, X[a - 1:b]))
+                    if self._phantom:  # (see fetch_x)
+                        staged.append((self._colmajor_like(X, b - a + 1), X[a - 1:b]))
+                        sends.append((r, staged[-1][0]))
+            ops = self._p2p_columns(sends, dist.isend) + self._p2p_columns(recvs, dist.irecv)
+            self._xplan_m = (X, ops, staged)
+        ops = self._xplan_m[1]
+        if ops:
+            for src, view in self._xplan_m[2]:
+                src.copy_(view)
+                view.fill_(float("nan"))
+            self._host_mediated_fence(X)
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        return X
+
+    def _halo_plan_multi(self, W, ranges):
+        """_halo_plan for the (n, K) work matrix: send views of its rows, receive buffers with contiguous columns"""
+        if self._plan_m is None or self._plan_m[0] is not W:
+            olo, ohi = self.own
+            tlo, thi = self.touched
+            sends, recvs = [], []
+            for r, (rlo, rhi, rtlo, rthi) in enumerate(ranges):
+                if r == self.rank:
+                    continue
+                a, b = max(tlo, rlo), min(thi, min(rhi, W.shape[0]))  # my contributions to rank r's rows
+                if a <= b:
+                    sends.append((r, a, b))
+                a, b = max(rtlo, olo), min(rthi, ohi)  # rank r's contributions to my rows
+                if a <= b:
+                    recvs.append((r, a, b, self._colmajor_like(W, b - a + 1)))
+            if self._phantom:  # the phantom owners receive what this rank produced for their rows
+                for r, a, b in sends:
+                    recvs.append((r, a, b, self._colmajor_like(W, b - a + 1)))
+            ops = self._p2p_columns([(r, W[a - 1:b]) for r, a, b in sends], dist.isend)
+            ops += self._p2p_columns([(r, buf) for r, _, _, buf in recvs], dist.irecv)
+            self._plan_m = (W, ops, recvs)
+        return self._plan_m[1], self._plan_m[2]
+
+    def mul_multi(self, Y, X, alpha=True, beta=False, local_mul=None, x_distributed=False):
+        """Y = alpha * A * X + beta * Y for (n, K) COLUMN-major matrices (torch: `.t()` of a contiguous (K, n) tensor),
+        products ALONG the partition (A * X of a row-partitioned operator, any op of a symmetric one): the local product
+        is ONE multi-RHS product (bsm_mul_multi: A streamed once per batch of columns -- what LinearMaps' column loop of
+        the reference, src/abstractblockmatrix.jl:27-34, does K times), and the K columns of every halo segment travel
+        in the ONE batch of the exchange.  x_distributed: X is valid on the own rows only, as in mul().  After the call
+        the own rows of Y are final (all of Y when gather=True).  local_mul(W_or_Y, X, alpha, beta): test hook."""
+        if Y.dim() != 2 or X.dim() != 2 or X.shape[1] != Y.shape[1]:
+            raise ValueError("mul_multi takes (n, K) matrices with the same number of columns")
+        if Y.stride(0) != 1 or X.stride(0) != 1:
+            raise ValueError("mul_multi takes COLUMN-major matrices (the columns are what the exchanges send)")
+        if not (self.symmetric or self.axis == 0):
+            raise ValueError("mul_multi: products along the partition only (mul() column by column runs across it)")
+        if x_distributed:
+            self._fetch_x_multi(X)
+        if local_mul is not None:
+            lm = local_mul
+        elif self.local is None:
+            lm = None
+        else:
+            A = self.local
+            lm = lambda yy, xx, a, b: M.mul(yy, A, xx, a, b)
+        ranges = self._exchange_ranges(Y.device)
+        halo = any((rl, rh) != (tl, th) for rl, rh, tl, th in ranges)
+        olo, ohi = self.own
+        own_slice = slice(olo - 1, ohi) if ohi >= olo else None
+        if not halo and self.axis == 0:
+            if lm is not None:
+                lm(Y, X, alpha, beta)  # rows outside `own` are left untouched by the handle
+            elif own_slice is not None:
+                self._combine(Y, own_slice, 0, beta)
+            if self._phantom:
+                self._phantom_rows(Y, beta)
+        else:
+            if self._work_m is None or self._work_m.shape != Y.shape or self._work_m.device != Y.device or \
+                    self._work_m.dtype != Y.dtype:
+                self._work_m = torch.zeros((Y.shape[1], Y.shape[0]), dtype=Y.dtype, device=Y.device).t()
+                self._plan_m = None
+            W = self._work_m
+            if lm is not None:
+                lm(W, X, alpha, False)  # strong zero over the touched rows, then accumulate
+            elif own_slice is not None:
+                W[own_slice] = 0
+            ops, recvs = self._halo_plan_multi(W, ranges)
+            if halo and ops:
+                self._exchange(ops, recvs, W)
+            if own_slice is not None:
+                self._combine(Y, own_slice, W[own_slice], beta)
+            if self._phantom:
+                self._phantom_rows(Y, beta)
+            for _, a, b, buf in recvs:
+                Y[a - 1:b] += buf
+        if self.gather and (self.world > 1 or self.loopback):
+            for k in range(Y.shape[1]):
+                self._allgather(Y[:, k], [(rl, rh) for rl, rh, _, _ in ranges])
+        return Y
 
     def mul_overlapped(self, y, x, alpha=True, beta=False, local_mul=None, interior_mul=None):
         """Forward product with x and y PARTITIONED like the rows and the exchange overlapped with the

@@ -160,6 +160,33 @@ def run(backend, port, q):
                 sync()
                 out.append(("%s halo, self send/recv (batch_isend_irecv) %s" % (kind, beta), relerr(y.cpu().numpy(), ref_of(prob, N, y0, alpha, beta))))
             assert torch.equal(x.cpu(), torch.from_numpy(prob["x"])), "x must be whole again after the loopback halo"
+            # ---- (c') A * X, 5 right-hand sides through the same halo: mul_multi -- one local multi-RHS product, the columns of
+            # every halo segment in the one grouped exchange
+            K = 5
+            Xf = np.stack([prob["x"] * (k + 1) + 0.25 * k for k in range(K)], axis=1)
+            Y0m = np.stack([np.random.default_rng(11 + k).standard_normal(n) for k in range(K)], axis=1)
+            colmajor = lambda a: torch.from_numpy(np.ascontiguousarray(a.T)).to(dev).t()
+            Xm = colmajor(Xf)
+            if gpu:
+                hook = None
+            else:
+                one = image_mul(A, touched)
+
+                def hook(YY, XX, a_, b_):
+                    for k in range(K):
+                        one(YY[:, k], XX[:, k], a_, b_)
+                    return YY
+            for alpha, beta in combos:
+                for rep in range(2):
+                    Ym = colmajor(Y0m)
+                    P.mul_multi(Ym, Xm, alpha, beta, x_distributed=True, local_mul=hook)
+                sync()
+                a_ = 1 if alpha is True else alpha
+                got = Ym.cpu().numpy()
+                err = max(relerr(got[:, k], oracle_mul(orc, prob, N, Xf[:, k].copy(), Y0m[:, k].copy(), a_, 0 if beta is False else beta,
+                                                       strong=beta is False)) for k in range(K))
+                out.append(("%s halo, %d right-hand sides (mul_multi) %s" % (kind, K, beta), err))
+            assert np.array_equal(Xm.cpu().numpy(), Xf), "X must be whole again after the loopback halo"
             # ---- (d) the same with the exchange OVERLAPPED with the interior rows (what bench.py --gpus N times)
             for xmode in (("halo", "allgather") if kind != "blocksparse" else ("auto",)):
                 interior, boundary, bt, bx = D.split_interior(prob, own)
