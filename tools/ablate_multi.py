@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Developer probe: timing-only ablations of the pipelined multi-RHS kernel (experiment build, results WRONG
-with any bit set).  usage: ablate_multi.py [c3|c5s|bem_f64] [K]"""
+with any bit set).  usage: ablate_multi.py [c3|c5s|c2x20|c4s|bem_f64|bem_c128|bem_c64] [K]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 os.environ.setdefault("BSM_LIB", os.path.join(ROOT, "blocksparsematrices.jl_amd", "libbsmrocm_exp.so"))
@@ -26,6 +26,8 @@ def bem(tiles, dtype, part):
 
 
 prob = {"c3": lambda: S.config3(on_device=True), "c5s": lambda: S.config5(n=625_000, on_device=True),
+        "c2x20": lambda: S.config2(n=2_000_000, nblocks=100_000, on_device=True),
+        "c4s": lambda: S.config4(on_device=True, row_lo=0, row_hi=1953),
         "bem_f64": lambda: bem(400, np.float64, "real"), "bem_c128": lambda: bem(400, np.complex128, "full"),
         "bem_c64": lambda: bem(400, np.complex64, "full")}[name]()
 A = S.build(prob)
