@@ -117,6 +117,28 @@ def _worker(rank, world, port, kind, q):
                     dist.all_reduce(part)
                     results.append(part.numpy().copy())
                     combos = combos + (((1, 0) if beta is False else (alpha, beta)),)
+        multi = None
+        if kind in ("vbcrs", "symmetric", "blocksparse", "vbcrs_tiny"):
+            # A * X with 6 right-hand sides, X and Y (column-major) PARTITIONED like the rows: mul_multi -- ONE local
+            # multi-RHS HIP product per rank, the columns of every halo segment in the one batch of the exchange
+            sym = prob["kind"] == "symmetric"
+            K = 6
+            Xf = np.stack([prob["x"] * (k + 1) + 0.25 * k for k in range(K)], axis=1)
+            Y0 = np.stack([np.random.default_rng(11 + k).standard_normal(n) for k in range(K)], axis=1)
+            colmajor = lambda a: torch.from_numpy(np.ascontiguousarray(a.T)).cuda().t()
+            P = D.RowPartitioned(A, own, touched, gather=False, symmetric=sym, xneed=touched if sym else None)
+            for _ in range(2):  # again: cached plans and buffers
+                Xd = colmajor(np.full_like(Xf, np.nan))
+                if own[1] >= own[0]:
+                    Xd[own[0] - 1:own[1]] = torch.from_numpy(Xf[own[0] - 1:own[1]]).cuda()
+                Y = colmajor(Y0)
+                P.mul_multi(Y, Xd, 0.5, -2.0, x_distributed=True)
+            torch.cuda.synchronize()
+            part = torch.zeros((n, K), dtype=torch.float64)
+            if own[1] >= own[0]:
+                part[own[0] - 1:own[1]] = Y.cpu()[own[0] - 1:own[1]]
+            dist.all_reduce(part)
+            multi = (Xf, Y0, part.numpy().copy())
         if rank == 0:
             from oracle import load_oracle
             orc = load_oracle()
@@ -124,6 +146,10 @@ def _worker(rank, world, port, kind, q):
             for (alpha, beta), got in zip(combos, results):
                 ref = oracle_mul(orc, prob, op, prob["x"], y0, alpha, beta, strong=(beta == 0))
                 errs.append(relerr(got, ref))
+            if multi is not None:
+                Xf, Y0, got = multi
+                for k in range(Xf.shape[1]):
+                    errs.append(relerr(got[:, k], oracle_mul(orc, prob, N, Xf[:, k].copy(), Y0[:, k].copy(), 0.5, -2.0, strong=False)))
             q.put(("ok", errs))
         dist.barrier()
         dist.destroy_process_group()
